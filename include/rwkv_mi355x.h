@@ -1,0 +1,125 @@
+/*
+ * rwkv_mi355x.h -- C-ABI of the MI355X-native RWKV-v4 uint8 inference engine
+ * (librwkv_mi355x.so).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * This is the drop-in boundary that sits where the reference's backend link
+ * boundary sits: the seven C++-linkage free functions that reference
+ * include/rwkv/rwkv/rwkv.h:63-122 declares and include/rwkv/cuda/rwkv.cu
+ * defines.  The 46-pointer interface of the reference is replaced by an opaque
+ * handle; each entry point cites the reference function it replaces.
+ * The C++ drop-in header include/rwkv.h (class RWKV / RWKVState) and the pybind
+ * module `rwkv` are thin wrappers over these calls.
+ *
+ * All functions return 0 on success and a negative rwkv_status on failure;
+ * rwkv_last_error() gives a human-readable message for the calling thread.
+ * Nothing here falls back to a CPU path: without a gfx950 device every
+ * compute entry point fails with RWKV_E_DEVICE.
+ */
+#ifndef RWKV_MI355X_H
+#define RWKV_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RWKV_VOCAB 50277u /* hard-wired in the reference: rwkv.h:126, rwkv.cu:471,589 */
+#define RWKV_N_TENSORS 46 /* tensor slots of model.bin: enums/enum.h:7-55 */
+
+enum rwkv_mode { RWKV_MODE_PARRALEL = 0, RWKV_MODE_GPT = 1 }; /* enums/enum.h:2-5 (sic) */
+
+enum rwkv_status {
+    RWKV_OK = 0,
+    RWKV_E_ARG = -1,    /* bad argument (reference: std::runtime_error in rwkv.h:285,344,349) */
+    RWKV_E_IO = -2,     /* file missing / truncated (reference: exit(1), rwkv.cu:641-645) */
+    RWKV_E_DEVICE = -3, /* HIP error or no usable device (reference: unchecked) */
+    RWKV_E_STATE = -4   /* called in the wrong state (not loaded / already loaded) */
+};
+
+typedef struct rwkv_ctx rwkv_ctx;
+
+/* State arrays addressable through rwkv_state_device(). */
+enum rwkv_state_id { RWKV_STATE_XY = 0, RWKV_STATE_AA = 1, RWKV_STATE_BB = 2, RWKV_STATE_PP = 3, RWKV_STATE_DD = 4 };
+
+/* Create an empty context bound to HIP device `device`.  (No reference counterpart:
+ * the reference uses the process-default device.) */
+int rwkv_create(rwkv_ctx **out, int device);
+
+/* Replaces load(), rwkv.cu:638-717: read model.bin (2 x u64 header,
+ * 46 raw tensors), upload, re-tile the uint8 matrices into the engine's row-per-output
+ * layout, allocate scratch and state for `max_ctx` tokens/slots (the reference's maxGPT). */
+int rwkv_load_file(rwkv_ctx *ctx, const char *path, uint64_t max_ctx);
+
+/* Same as rwkv_load_file but from memory: `ptrs[i]` is tensor slot i in FILE layout
+ * (host memory if on_device == 0, device memory otherwise).  The 13 scratch/state slots
+ * may be NULL.  Used by the converter path and by bench.py's synthetic 7B/14B models. */
+int rwkv_load_tensors(rwkv_ctx *ctx, uint64_t n_layers, uint64_t n_embed,
+                      const void *const *ptrs, int on_device, uint64_t max_ctx);
+
+uint64_t rwkv_n_layers(const rwkv_ctx *ctx);
+uint64_t rwkv_n_embed(const rwkv_ctx *ctx);
+uint64_t rwkv_max_ctx(const rwkv_ctx *ctx);
+
+/* Replaces cuda_rwkv_parralel(), rwkv.cu:493-593 (and cuda_rwkv, :595-628): run `n_tokens`
+ * tokens.  GPT mode: consecutive tokens of one sequence on state slot 0.  PARRALEL mode: one
+ * step of n_tokens independent sequences on state slots 0..n_tokens-1.  Logits for every
+ * position land in the device logits buffer ([n_tokens][50277] f32); state stays on the device.
+ * Synchronous on return (the reference ends with cudaDeviceSynchronize, rwkv.cu:590). */
+int rwkv_forward(rwkv_ctx *ctx, const uint64_t *tokens, uint64_t n_tokens, int mode);
+
+/* Replaces setState(), rwkv.cu:479-490: upload host state arrays (each [n_slots][L][D] f64). */
+int rwkv_set_state(rwkv_ctx *ctx, const double *xy, const double *aa, const double *bb,
+                   const double *pp, const double *dd, uint64_t n_slots);
+
+/* Replaces getOutput(), rwkv.cu:467-477: download logits ([n_tokens][50277] f32) and the five
+ * state arrays (each [n_tokens][L][D] f64).  Any pointer may be NULL to skip that copy. */
+int rwkv_get_output(rwkv_ctx *ctx, float *logits, double *xy, double *aa, double *bb,
+                    double *pp, double *dd, uint64_t n_tokens);
+
+/* Zero all state slots on the device (what `new RWKVState` + setState does, rwkv.h:163-170). */
+int rwkv_reset_state(rwkv_ctx *ctx);
+
+/* Device-side greedy continuation (storygen's loop, examples/storygen/storygen.cpp:63-69, with
+ * argmax in place of typical(): logit 0 is banned as out[0] = -99 does there).  Feeds
+ * `first_token`, then n_tokens-1 times the argmax of the previous logits, all on state slot 0
+ * without host round trips; writes the n_tokens picked ids to out_tokens (host).  The logits of
+ * the LAST step remain in the device logits buffer (row 0). */
+int rwkv_decode_greedy(rwkv_ctx *ctx, uint64_t first_token, uint64_t n_tokens, uint64_t *out_tokens);
+
+/* Replaces freeTensors(), rwkv.cu:719-730, plus destruction of the handle. */
+void rwkv_free(rwkv_ctx *ctx);
+
+const char *rwkv_last_error(void);
+
+/* ---- introspection / measurement hooks (no reference counterpart) ---- */
+
+/* Device pointer of the logits buffer ([max_ctx][50277] f32). */
+float *rwkv_logits_device(rwkv_ctx *ctx);
+/* Device pointer of a state array ([max_ctx][L][D] f64), rwkv_state_id. */
+double *rwkv_state_device(rwkv_ctx *ctx, int which);
+/* The HIP stream (hipStream_t) all engine work is enqueued on. */
+void *rwkv_stream(rwkv_ctx *ctx);
+/* Algorithmic HBM bytes of one token (13*L*D^2 + V*D uint8 weight bytes
+ * + 168*L*D + 40*D bytes of vectors/state). */
+uint64_t rwkv_bytes_per_token(const rwkv_ctx *ctx);
+
+/* Per-kernel-class device time of the last rwkv_profile_token() call, measured with HIP events
+ * on the engine's stream.  Classes: 0 embed+ln0, 1 att K/V/R+wkv, 2 att_out, 3 ffn r+k,
+ * 4 ffn_v, 5 head, 6 argmax.  ms[c] = total milliseconds over `reps` tokens, bytes[c] =
+ * algorithmic uint8 weight bytes of one launch of that class, launches[c] = launches/token. */
+#define RWKV_N_KCLASS 7
+int rwkv_profile_token(rwkv_ctx *ctx, uint64_t token, int reps, double *ms, uint64_t *bytes,
+                       uint32_t *launches);
+
+/* Standalone launch of the engine's dequant-GEMV on caller-provided device buffers
+ * (the kernel behind cudac_mm8_one(), rwkv.cu:297-311): w is FILE layout [N][M] u8 (one layer),
+ * x f32[N], r/o f32[N]; y f32[M] is overwritten with x . (w*r + o).  Used by the unit tests. */
+int rwkv_mm8_one(rwkv_ctx *ctx, uint64_t N, uint64_t M, const float *x_dev, const uint8_t *w_dev,
+                 const float *r_dev, const float *o_dev, float *y_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RWKV_MI355X_H */

@@ -1,0 +1,79 @@
+"""Build the HIP engine for gfx950 (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+ARCH = "gfx950"
+
+
+def _stale(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _run(cmd, cwd=None):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def build_engine(force: bool = False) -> str:
+    """csrc/engine.hip (+ kernels.hip.h) -> csrc/librwkv_mi355x.so"""
+    out = os.path.join(CSRC, "librwkv_mi355x.so")
+    srcs = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "kernels.hip.h"),
+            os.path.join(ROOT, "include", "rwkv_mi355x.h")]
+    if force or _stale(out, srcs):
+        _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+              "-Wno-unused-result", os.path.join(CSRC, "engine.hip"), "-o", out])
+    return out
+
+
+def build_pybind(force: bool = False):
+    """csrc/pybind_module.cpp -> csrc/rwkv.<abi>.so : the reference's pybind module `rwkv`
+    (bindings/pybind/c_binding.cpp:158-175) on top of include/rwkv.h.  Optional: skipped when the
+    source is not there yet."""
+    src = os.path.join(CSRC, "pybind_module.cpp")
+    if not os.path.exists(src):
+        return None
+    import sysconfig
+    import pybind11
+    ext = sysconfig.get_config_var("EXT_SUFFIX")
+    out = os.path.join(CSRC, "rwkv" + ext)
+    hdrs = [os.path.join(ROOT, "include", f) for f in ("rwkv.h", "rwkv_mi355x.h")]
+    if force or _stale(out, [src] + hdrs):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+              "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src, "-o", out,
+              "-L" + CSRC, "-lrwkv_mi355x", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
+def build_oracle(force: bool = False):
+    """oracle/: the C restatement, and -- only where /root/reference exists -- oracle/_ref."""
+    odir = os.path.join(ROOT, "oracle")
+    so = os.path.join(odir, "librwkv_oracle.so")
+    if force or _stale(so, [os.path.join(odir, "rwkv_oracle.c")]):
+        _run(["make", "-C", odir, "-B", "librwkv_oracle.so"])
+    ref_root = os.environ.get("RWKV_REFERENCE", "/root/reference")
+    ref_so = os.path.join(odir, "_ref", "libref.so")
+    if os.path.isdir(os.path.join(ref_root, "include", "rwkv")):
+        if force or _stale(ref_so, [os.path.join(odir, "ref_driver.cpp")]):
+            _run(["make", "-C", odir, "ref", f"REF={ref_root}"])
+    return so, (ref_so if os.path.exists(ref_so) else None)
+
+
+def build_all(force: bool = False):
+    eng = build_engine(force)
+    pyb = build_pybind(force)
+    ora = build_oracle(force)
+    return dict(engine=eng, pybind=pyb, oracle=ora[0], ref=ora[1])

@@ -1,0 +1,631 @@
+// engine.hip -- host runtime + C-ABI of librwkv_mi355x.so (see include/rwkv_mi355x.h).
+//
+// Replaces the reference's backend translation unit include/rwkv/cuda/rwkv.cu (load / setState /
+// getOutput / freeTensors / cuda_rwkv_parralel, declared rwkv.h:63-122) with an opaque-handle
+// engine: weights are re-tiled once at load, state and the embedding table stay resident on the
+// device, and one token is a replay of a captured hipGraph (4 launches per layer + 2).
+#include "kernels.hip.h"
+#include "../../include/rwkv_mi355x.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rwkvk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(RWKV_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+// tensor slots of model.bin, reference enums/enum.h:7-55
+enum {
+    X, EMBED, LAYERNORMS, STATEXY, STATEAA, STATEBB, STATEPP, STATEDD, BUFFER1, BUFFER2, BUFFER3, BUFFER4,
+    MIXK, MIXV, MIXR, KM, VM, RM, KR, VR, RR, O1, O2, O3, ATTOUT, ATTOUTR, ATTOUTO, FFNMIXK, FFNMIXV,
+    FFNK, FFNV, FFNR, FFNKR, FFNVR, FFNRR, FFNKO, FFNVO, FFNRO, FFNKBUFFER, FFNVBUFFER, FFNRBUFFER,
+    DECAY, BONUS, HEAD, HEADR, HEADO
+};
+// element sizes / counts: reference rwkv.h:84 and rwkv.h:124-128
+const uint64_t kTypes[46] = {8, 4, 8, 8, 8, 8, 8, 8, 8, 4, 4, 4, 8, 8, 8, 1, 1, 1, 4, 4, 4, 4, 4,
+                             4, 1, 4, 4, 8, 8, 1, 1, 1, 4, 4, 4, 4, 4, 4, 8, 8, 4, 8, 8, 1, 4, 4};
+uint64_t tensor_elems(int i, uint64_t a, uint64_t b)
+{
+    const uint64_t V = RWKV_VOCAB;
+    const uint64_t s[46] = {b, V * b, 4 * (a + 1) * b, a * b, a * b, a * b, a * b, a * b, b, V, b, b,
+                            a * b, a * b, a * b, a * b * b, a * b * b, a * b * b, a * b, a * b, a * b, a * b, a * b, a * b,
+                            a * b * b, a * b, a * b, a * b, a * b, a * b * b * 4, a * b * b * 4, a * b * b,
+                            a * b, a * b * 4, a * b, a * b, a * b * 4, a * b, b, b, b * 4, a * b, a * b, V * b, b, b};
+    return s[i];
+}
+
+// where tensor bytes come from during a load
+struct Source {
+    FILE *f = nullptr;                  // model.bin, or
+    const void *const *ptrs = nullptr;  // 46 pointers in file layout
+    bool on_device = false;
+    uint64_t off[46];
+    std::vector<unsigned char> scratch;
+    // returns a pointer (host unless on_device) to bytes [o, o+n) of tensor i
+    const void *get(int i, uint64_t o, uint64_t n)
+    {
+        if (ptrs) return ptrs[i] ? static_cast<const unsigned char *>(ptrs[i]) + o : nullptr;
+        if (scratch.size() < n) scratch.resize(n);
+        if (fseeko(f, (off_t)(off[i] + o), SEEK_SET) != 0) return nullptr;
+        if (fread(scratch.data(), 1, n, f) != n) return nullptr;
+        return scratch.data();
+    }
+};
+
+} // namespace
+
+struct rwkv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int grid = 256;          // workgroups per launch = compute units
+    bool loaded = false;
+    uint64_t L = 0, D = 0, maxT = 1;
+    int S = 0;               // ceil(D / 1024): 1 KiB row pieces per lane
+
+    // weights (device)
+    float *embed = nullptr;
+    double *ln = nullptr, *mixk = nullptr, *mixv = nullptr, *mixr = nullptr, *fmixk = nullptr, *fmixr = nullptr;
+    float *kr = nullptr, *vr = nullptr, *rr = nullptr, *o1 = nullptr, *o2 = nullptr, *o3 = nullptr;
+    float *attr = nullptr, *atto = nullptr, *fkr = nullptr, *fvr = nullptr, *frr = nullptr;
+    float *fko = nullptr, *fvo = nullptr, *fro = nullptr, *headr = nullptr, *heado = nullptr;
+    double *uw = nullptr, *ew = nullptr;
+    f32x4 *pk_att = nullptr, *pk_ffn = nullptr, *pk_head = nullptr;   // packed prologue parameter tables
+    uint8_t *w_kvr = nullptr, *w_att = nullptr, *w_frk = nullptr, *w_fv = nullptr, *w_head = nullptr;
+    // state + scratch (device)
+    double *state[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *x = nullptr, *xx1 = nullptr, *xx2 = nullptr, *partA = nullptr, *partF = nullptr;
+    float *ybuf = nullptr, *hbuf = nullptr, *rgate = nullptr, *logits = nullptr, *blk_val = nullptr;
+    unsigned *blk_idx = nullptr;
+    Ctl *ctl = nullptr;
+    Ctl *h_ctl = nullptr;    // pinned staging, maxT entries
+    unsigned long long *gen = nullptr;
+    unsigned gen_cap = 0;
+    hipGraphExec_t g_fwd = nullptr, g_greedy = nullptr;
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+template <typename T> int dalloc(rwkv_ctx *c, T **p, size_t count)
+{
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16)));
+    c->allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return 0;
+}
+
+size_t smem_att(int S, int gpb) { return RED_BYTES + 3 * (size_t)S * 4096 + (size_t)gpb * 3 * 4; }
+size_t smem_attout(int S) { return RED_BYTES + (size_t)S * 4096; }
+size_t smem_frk(int S, int gpb) { return RED_BYTES + 2 * (size_t)S * 4096 + (size_t)gpb * 5 * 4; }
+size_t smem_fv(int S) { return RED_BYTES + 4 * (size_t)S * 4096; }
+size_t smem_head(int S) { return RED_BYTES + (size_t)S * 4096 + NW * 8; }
+
+constexpr int ATTOUT_R = 2;
+
+#define DISPATCH_S(S, ...)                                           \
+    switch (S) {                                                     \
+    case 1: { constexpr int S_ = 1; __VA_ARGS__; } break;            \
+    case 2: { constexpr int S_ = 2; __VA_ARGS__; } break;            \
+    case 3: { constexpr int S_ = 3; __VA_ARGS__; } break;            \
+    case 4: { constexpr int S_ = 4; __VA_ARGS__; } break;            \
+    default: { constexpr int S_ = 5; __VA_ARGS__; } break;           \
+    }
+
+template <typename K> int allow_smem(K kernel, size_t bytes)
+{
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+int gpb_of(const rwkv_ctx *c) { return (int)((c->D + c->grid - 1) / c->grid) + 1; }
+
+// enqueue the kernels of one token on the context's stream.  ev: optional array of
+// (4L + 4) events recorded before each launch and after the last (profiling).
+int enqueue_token(rwkv_ctx *c, bool with_argmax, hipEvent_t *ev)
+{
+    const int D = (int)c->D, S = c->S, grid = c->grid;
+    const uint64_t L = c->L;
+    const size_t LD = (size_t)L * D;
+    const int gpb = gpb_of(c);
+    int evi = 0;
+#define EV() do { if (ev) HIPCHK(hipEventRecord(ev[evi++], c->stream)); } while (0)
+
+    EV();
+    EmbedArgs ea{c->embed, c->ln, c->x, c->ctl, D};
+    hipLaunchKernelGGL(k_embed_ln0, dim3(1), dim3(NT), 0, c->stream, ea);
+
+    for (uint64_t l = 0; l < L; l++) {
+        const size_t lo = (size_t)l * D;
+        AttArgs aa;
+        aa.x = c->x; aa.pk = c->pk_att + lo * 3;
+        aa.w = c->w_kvr + (size_t)l * 3 * D * D;
+        aa.uw = c->uw + lo; aa.ew = c->ew + lo;
+        aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
+        aa.sxy = c->state[0] + lo; aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
+        aa.slot_stride = LD; aa.xx_buf = c->xx1; aa.ybuf = c->ybuf; aa.partS = c->partA;
+        aa.ctl = c->ctl; aa.D = D;
+        EV();
+        DISPATCH_S(S, k_att<S_><<<dim3(grid), dim3(NT), smem_att(S, gpb), c->stream>>>(aa));
+
+        AttOutArgs ao;
+        ao.w = c->w_att + (size_t)l * D * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.n_part = grid;
+        ao.x = c->x; ao.xx_buf = c->xx1; ao.sxy = c->state[0] + lo; ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D;
+        EV();
+        DISPATCH_S(S, k_attout<S_, ATTOUT_R><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
+
+        FfnRKArgs fa;
+        fa.x = c->x; fa.pk = c->pk_ffn + lo * 2;
+        fa.w = c->w_frk + (size_t)l * 5 * D * D;
+        fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
+        fa.sdd = c->state[4] + lo; fa.slot_stride = LD; fa.xx_buf = c->xx2;
+        fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.ctl = c->ctl; fa.D = D;
+        EV();
+        DISPATCH_S(S, k_ffn_rk<S_><<<dim3(grid), dim3(NT), smem_frk(S, gpb), c->stream>>>(fa));
+
+        FfnVArgs fv;
+        fv.w = c->w_fv + (size_t)l * 4 * D * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.n_part = grid;
+        fv.rgate = c->rgate; fv.x = c->x; fv.xx_buf = c->xx2; fv.sdd = c->state[4] + lo;
+        fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D;
+        EV();
+        DISPATCH_S(S, k_ffnv<S_><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
+    }
+
+    HeadArgs ha;
+    ha.x = c->x; ha.pk = c->pk_head; ha.w = c->w_head; ha.logits = c->logits;
+    ha.blk_val = c->blk_val; ha.blk_idx = c->blk_idx; ha.ctl = c->ctl; ha.D = D;
+    EV();
+    DISPATCH_S(S, k_head<S_><<<dim3(grid), dim3(NT), smem_head(S), c->stream>>>(ha));
+    EV();
+    if (with_argmax)
+        hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(64), 0, c->stream, c->blk_val, c->blk_idx, grid,
+                           c->ctl, c->gen, c->gen_cap);
+    EV();
+#undef EV
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int build_graph(rwkv_ctx *c, bool with_argmax, hipGraphExec_t *out)
+{
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    int rc = enqueue_token(c, with_argmax, nullptr);
+    hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (rc) return rc;
+    HIPCHK(e);
+    HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(g));
+    return 0;
+}
+
+int retile(rwkv_ctx *c, Source &src, int slot, uint64_t layer, uint64_t N, uint64_t M, uint8_t *dst,
+           int G, int RS, int off, uint8_t *staging)
+{
+    const void *p = src.get(slot, layer * N * M, N * M);
+    if (!p) return fail(RWKV_E_IO, "tensor slot %d: short read / missing", slot);
+    const uint8_t *dsrc = static_cast<const uint8_t *>(p);
+    if (!src.on_device) {
+        HIPCHK(hipMemcpyAsync(staging, p, N * M, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));   // scratch host buffer is reused by the next get()
+        dsrc = staging;
+    }
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
+    hipLaunchKernelGGL(k_retile, grid, dim3(256), 0, c->stream, dsrc, dst, (int)N, (int)M, G, RS, off);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <typename T> int upload(rwkv_ctx *c, Source &src, int slot, T **dst)
+{
+    const uint64_t n = tensor_elems(slot, c->L, c->D);
+    int rc = dalloc(c, dst, n);
+    if (rc) return rc;
+    const void *p = src.get(slot, 0, n * sizeof(T));
+    if (!p) return fail(RWKV_E_IO, "tensor slot %d: short read / missing", slot);
+    HIPCHK(hipMemcpy(*dst, p, n * sizeof(T), src.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return 0;
+}
+
+int set_smem_limits(rwkv_ctx *c)
+{
+    const int S = c->S, gpb = gpb_of(c);
+    int rc = 0;
+    DISPATCH_S(S, rc = allow_smem(k_att<S_>, smem_att(S, gpb))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R>, smem_attout(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_>, smem_frk(S, gpb))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_>, smem_fv(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_head<S_>, smem_head(S))); if (rc) return rc;
+    return 0;
+}
+
+int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_ctx)
+{
+    if (c->loaded) return fail(RWKV_E_STATE, "RWKV already loaded");   // reference: rwkv.h:283-286
+    if (L == 0 || D == 0 || D % 16 != 0 || D > 5120 || L > 4096)
+        return fail(RWKV_E_ARG, "unsupported model shape n_layers=%llu n_embed=%llu (n_embed must be a multiple of 16, <= 5120)",
+                    (unsigned long long)L, (unsigned long long)D);
+    if (max_ctx == 0) max_ctx = 1;
+    HIPCHK(hipSetDevice(c->device));
+    c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
+    const uint64_t V = RWKV_VOCAB;
+    int rc;
+
+    // vectors: as-is
+    if ((rc = upload(c, src, EMBED, &c->embed))) return rc;
+    if ((rc = upload(c, src, LAYERNORMS, &c->ln))) return rc;
+    if ((rc = upload(c, src, MIXK, &c->mixk))) return rc;
+    if ((rc = upload(c, src, MIXV, &c->mixv))) return rc;
+    if ((rc = upload(c, src, MIXR, &c->mixr))) return rc;
+    if ((rc = upload(c, src, KR, &c->kr))) return rc;
+    if ((rc = upload(c, src, VR, &c->vr))) return rc;
+    if ((rc = upload(c, src, RR, &c->rr))) return rc;
+    if ((rc = upload(c, src, O1, &c->o1))) return rc;
+    if ((rc = upload(c, src, O2, &c->o2))) return rc;
+    if ((rc = upload(c, src, O3, &c->o3))) return rc;
+    if ((rc = upload(c, src, ATTOUTR, &c->attr))) return rc;
+    if ((rc = upload(c, src, ATTOUTO, &c->atto))) return rc;
+    if ((rc = upload(c, src, FFNMIXK, &c->fmixk))) return rc;
+    if ((rc = upload(c, src, FFNMIXV, &c->fmixr))) return rc;   // slot named "v" holds time_mix_r
+    if ((rc = upload(c, src, FFNKR, &c->fkr))) return rc;
+    if ((rc = upload(c, src, FFNVR, &c->fvr))) return rc;
+    if ((rc = upload(c, src, FFNRR, &c->frr))) return rc;
+    if ((rc = upload(c, src, FFNKO, &c->fko))) return rc;
+    if ((rc = upload(c, src, FFNVO, &c->fvo))) return rc;
+    if ((rc = upload(c, src, FFNRO, &c->fro))) return rc;
+    if ((rc = upload(c, src, HEADR, &c->headr))) return rc;
+    if ((rc = upload(c, src, HEADO, &c->heado))) return rc;
+    double *decay = nullptr, *bonus = nullptr;
+    if ((rc = upload(c, src, DECAY, &decay))) return rc;
+    if ((rc = upload(c, src, BONUS, &bonus))) return rc;
+    if ((rc = dalloc(c, &c->uw, L * D))) return rc;
+    if ((rc = dalloc(c, &c->ew, L * D))) return rc;
+    hipLaunchKernelGGL(k_prep_wkv, dim3((unsigned)((L * D + 255) / 256)), dim3(256), 0, c->stream, decay, bonus, c->uw, c->ew, (size_t)(L * D));
+
+    // packed prologue parameter tables
+    if ((rc = dalloc(c, &c->pk_att, L * D * 3))) return rc;
+    if ((rc = dalloc(c, &c->pk_ffn, L * D * 2))) return rc;
+    if ((rc = dalloc(c, &c->pk_head, D))) return rc;
+    {
+        const dim3 pg((unsigned)((D + 255) / 256)), pb(256);
+        for (uint64_t l = 0; l < L; l++) {
+            const size_t lo = (size_t)l * D;
+            k_pack_att<<<pg, pb, 0, c->stream>>>(c->pk_att + lo * 3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D,
+                                                 c->mixk + lo, c->mixv + lo, c->mixr + lo, c->kr + lo, c->vr + lo, c->rr + lo,
+                                                 c->o1 + lo, c->o2 + lo, c->o3 + lo, (int)D);
+            k_pack_ffn<<<pg, pb, 0, c->stream>>>(c->pk_ffn + lo * 2, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D,
+                                                 c->fmixk + lo, c->fmixr + lo, c->fkr + lo, c->fko + lo, c->frr + lo, c->fro + lo, (int)D);
+        }
+        k_pack_head<<<pg, pb, 0, c->stream>>>(c->pk_head, c->ln + (4 * L + 2) * D, c->ln + (4 * L + 3) * D, c->headr, c->heado, (int)D);
+        HIPCHK(hipGetLastError());
+    }
+
+    // uint8 matrices: re-tile to row-per-output
+    if ((rc = dalloc(c, &c->w_kvr, L * 3 * D * D))) return rc;
+    if ((rc = dalloc(c, &c->w_att, L * D * D))) return rc;
+    if ((rc = dalloc(c, &c->w_frk, L * 5 * D * D))) return rc;
+    if ((rc = dalloc(c, &c->w_fv, L * 4 * D * D))) return rc;
+    if ((rc = dalloc(c, &c->w_head, V * D))) return rc;
+    uint8_t *staging = nullptr;
+    if (!src.on_device) HIPCHK(hipMalloc(reinterpret_cast<void **>(&staging), std::max<uint64_t>(4 * D * D, V * D)));
+    for (uint64_t l = 0; l < L && !rc; l++) {
+        uint8_t *kvr = c->w_kvr + l * 3 * D * D, *frk = c->w_frk + l * 5 * D * D;
+        if (!rc) rc = retile(c, src, KM, l, D, D, kvr, 1, 3, 0, staging);
+        if (!rc) rc = retile(c, src, VM, l, D, D, kvr, 1, 3, 1, staging);
+        if (!rc) rc = retile(c, src, RM, l, D, D, kvr, 1, 3, 2, staging);
+        if (!rc) rc = retile(c, src, ATTOUT, l, D, D, c->w_att + l * D * D, 1, 1, 0, staging);
+        if (!rc) rc = retile(c, src, FFNK, l, D, 4 * D, frk, 4, 5, 0, staging);
+        if (!rc) rc = retile(c, src, FFNR, l, D, D, frk, 1, 5, 4, staging);
+        if (!rc) rc = retile(c, src, FFNV, l, 4 * D, D, c->w_fv + l * 4 * D * D, 1, 1, 0, staging);
+    }
+    if (!rc) rc = retile(c, src, HEAD, 0, D, V, c->w_head, 1, 1, 0, staging);
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (staging) (void)hipFree(staging);
+    if (rc) return rc;
+    HIPCHK(se);
+
+    // state (zero, as `new RWKVState` does: rwkv.h:163-170) and scratch
+    for (int s = 0; s < 5; s++) {
+        if ((rc = dalloc(c, &c->state[s], max_ctx * L * D))) return rc;
+        HIPCHK(hipMemset(c->state[s], 0, max_ctx * L * D * sizeof(double)));
+    }
+    if ((rc = dalloc(c, &c->x, D))) return rc;
+    if ((rc = dalloc(c, &c->xx1, D))) return rc;
+    if ((rc = dalloc(c, &c->xx2, D))) return rc;
+    if ((rc = dalloc(c, &c->ybuf, D))) return rc;
+    if ((rc = dalloc(c, &c->hbuf, 4 * D))) return rc;
+    if ((rc = dalloc(c, &c->rgate, D))) return rc;
+    if ((rc = dalloc(c, &c->partA, (size_t)c->grid))) return rc;
+    if ((rc = dalloc(c, &c->partF, (size_t)c->grid))) return rc;
+    if ((rc = dalloc(c, &c->blk_val, (size_t)c->grid))) return rc;
+    if ((rc = dalloc(c, &c->blk_idx, (size_t)c->grid))) return rc;
+    if ((rc = dalloc(c, &c->logits, max_ctx * V))) return rc;
+    HIPCHK(hipMemset(c->logits, 0, max_ctx * V * sizeof(float)));
+    if ((rc = dalloc(c, &c->ctl, 1))) return rc;
+    HIPCHK(hipMemset(c->ctl, 0, sizeof(Ctl)));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_ctl), sizeof(Ctl) * max_ctx, hipHostMallocDefault));
+    c->gen_cap = 1u << 16;
+    if ((rc = dalloc(c, &c->gen, (size_t)c->gen_cap))) return rc;
+
+    if ((rc = set_smem_limits(c))) return rc;
+    const char *nograph = getenv("RWKV_NO_GRAPH");
+    if (!(nograph && nograph[0] == '1')) {
+        if ((rc = build_graph(c, false, &c->g_fwd))) return rc;
+        if ((rc = build_graph(c, true, &c->g_greedy))) return rc;
+    }
+    c->loaded = true;
+    return 0;
+}
+
+int run_token(rwkv_ctx *c, bool with_argmax)
+{
+    hipGraphExec_t g = with_argmax ? c->g_greedy : c->g_fwd;
+    if (g) { HIPCHK(hipGraphLaunch(g, c->stream)); return 0; }
+    return enqueue_token(c, with_argmax, nullptr);
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rwkv_last_error(void) { return g_err.c_str(); }
+
+int rwkv_create(rwkv_ctx **out, int device)
+{
+    if (!out) return fail(RWKV_E_ARG, "out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(RWKV_E_DEVICE, "no HIP device available (this engine has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(RWKV_E_ARG, "device %d out of range (have %d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    rwkv_ctx *c = new rwkv_ctx();
+    c->device = device;
+    c->grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const char *g = getenv("RWKV_GRID");
+    if (g && atoi(g) > 0) c->grid = atoi(g);
+    if (c->grid > NT) c->grid = NT;   // consumers sum one partial per thread
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(RWKV_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    *out = c;
+    return 0;
+}
+
+int rwkv_load_file(rwkv_ctx *c, const char *path, uint64_t max_ctx)
+{
+    if (!c || !path) return fail(RWKV_E_ARG, "NULL argument");
+    Source src;
+    src.f = fopen(path, "rb");
+    if (!src.f) return fail(RWKV_E_IO, "Error opening file %s", path);   // reference: rwkv.cu:641-645
+    uint64_t hdr[2];
+    if (fread(hdr, 8, 2, src.f) != 2) { fclose(src.f); return fail(RWKV_E_IO, "%s: truncated header", path); }
+    uint64_t o = 16;
+    for (int i = 0; i < 46; i++) { src.off[i] = o; o += tensor_elems(i, hdr[0], hdr[1]) * kTypes[i]; }
+    int rc = 0;
+    if (fseeko(src.f, 0, SEEK_END) != 0 || (uint64_t)ftello(src.f) < o)
+        rc = fail(RWKV_E_IO, "%s: file shorter than the %llu bytes a %llu-layer, %llu-wide model needs", path,
+                  (unsigned long long)o, (unsigned long long)hdr[0], (unsigned long long)hdr[1]);
+    if (!rc) rc = load_common(c, src, hdr[0], hdr[1], max_ctx);
+    fclose(src.f);
+    return rc;
+}
+
+int rwkv_load_tensors(rwkv_ctx *c, uint64_t n_layers, uint64_t n_embed, const void *const *ptrs,
+                      int on_device, uint64_t max_ctx)
+{
+    if (!c || !ptrs) return fail(RWKV_E_ARG, "NULL argument");
+    Source src;
+    src.ptrs = ptrs;
+    src.on_device = on_device != 0;
+    return load_common(c, src, n_layers, n_embed, max_ctx);
+}
+
+uint64_t rwkv_n_layers(const rwkv_ctx *c) { return c ? c->L : 0; }
+uint64_t rwkv_n_embed(const rwkv_ctx *c) { return c ? c->D : 0; }
+uint64_t rwkv_max_ctx(const rwkv_ctx *c) { return c ? c->maxT : 0; }
+
+int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
+{
+    if (!c || !tokens) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");                                   // rwkv.h:342-345
+    if (T > c->maxT) return fail(RWKV_E_ARG, "Context too large, max context is %llu", (unsigned long long)c->maxT);   // rwkv.h:347-350
+    if (mode != RWKV_MODE_PARRALEL && mode != RWKV_MODE_GPT) return fail(RWKV_E_ARG, "bad mode %d", mode);
+    for (uint64_t t = 0; t < T; t++)
+        if (tokens[t] >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id %llu out of range", (unsigned long long)tokens[t]);
+    HIPCHK(hipSetDevice(c->device));
+    for (uint64_t t = 0; t < T; t++) {
+        c->h_ctl[t].token = tokens[t];
+        c->h_ctl[t].slot = (mode == RWKV_MODE_PARRALEL) ? (unsigned)t : 0u;   // rwkv.cu:236-240
+        c->h_ctl[t].out_row = (unsigned)t;
+        c->h_ctl[t].step = 0; c->h_ctl[t].pad = 0;
+        HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[t], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+        int rc = run_token(c, false);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rwkv_set_state(rwkv_ctx *c, const double *xy, const double *aa, const double *bb, const double *pp,
+                   const double *dd, uint64_t n_slots)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (n_slots > c->maxT) return fail(RWKV_E_ARG, "n_slots %llu > max context %llu", (unsigned long long)n_slots, (unsigned long long)c->maxT);
+    const double *h[5] = {xy, aa, bb, pp, dd};
+    const size_t bytes = n_slots * c->L * c->D * sizeof(double);
+    HIPCHK(hipSetDevice(c->device));
+    for (int s = 0; s < 5; s++)
+        if (h[s]) HIPCHK(hipMemcpyAsync(c->state[s], h[s], bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rwkv_get_output(rwkv_ctx *c, float *logits, double *xy, double *aa, double *bb, double *pp, double *dd,
+                    uint64_t T)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (T > c->maxT) return fail(RWKV_E_ARG, "n_tokens %llu > max context %llu", (unsigned long long)T, (unsigned long long)c->maxT);
+    double *h[5] = {xy, aa, bb, pp, dd};
+    HIPCHK(hipSetDevice(c->device));
+    if (logits) HIPCHK(hipMemcpyAsync(logits, c->logits, T * RWKV_VOCAB * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    const size_t bytes = T * c->L * c->D * sizeof(double);
+    for (int s = 0; s < 5; s++)
+        if (h[s]) HIPCHK(hipMemcpyAsync(h[s], c->state[s], bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rwkv_reset_state(rwkv_ctx *c)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    for (int s = 0; s < 5; s++)
+        HIPCHK(hipMemsetAsync(c->state[s], 0, c->maxT * c->L * c->D * sizeof(double), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rwkv_decode_greedy(rwkv_ctx *c, uint64_t first_token, uint64_t n, uint64_t *out_tokens)
+{
+    if (!c || !out_tokens) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (first_token >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
+    if (n == 0 || n > c->gen_cap) return fail(RWKV_E_ARG, "n_tokens must be in 1..%u", c->gen_cap);
+    HIPCHK(hipSetDevice(c->device));
+    c->h_ctl[0].token = first_token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
+    HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+    for (uint64_t i = 0; i < n; i++) {
+        int rc = run_token(c, true);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(out_tokens, c->gen, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void rwkv_free(rwkv_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->g_fwd) (void)hipGraphExecDestroy(c->g_fwd);
+    if (c->g_greedy) (void)hipGraphExecDestroy(c->g_greedy);
+    for (void *p : c->allocs) (void)hipFree(p);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+float *rwkv_logits_device(rwkv_ctx *c) { return c ? c->logits : nullptr; }
+double *rwkv_state_device(rwkv_ctx *c, int which) { return (c && which >= 0 && which < 5) ? c->state[which] : nullptr; }
+void *rwkv_stream(rwkv_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+uint64_t rwkv_bytes_per_token(const rwkv_ctx *c)
+{
+    if (!c) return 0;
+    const uint64_t L = c->L, D = c->D, V = RWKV_VOCAB;
+    return 13 * L * D * D + V * D + 168 * L * D + 40 * D;
+}
+
+int rwkv_profile_token(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint64_t *bytes, uint32_t *launches)
+{
+    if (!c || !ms) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (token >= RWKV_VOCAB || reps <= 0) return fail(RWKV_E_ARG, "bad token / reps");
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t L = c->L, D = c->D, V = RWKV_VOCAB;
+    const int nev = (int)(4 * L + 4);
+    std::vector<hipEvent_t> ev(nev);
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    for (int k = 0; k < RWKV_N_KCLASS; k++) ms[k] = 0.0;
+    c->h_ctl[0].token = token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
+    HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+    int rc = 0;
+    for (int rep = 0; rep < reps && !rc; rep++) {
+        rc = enqueue_token(c, true, ev.data());
+        if (rc) break;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(RWKV_E_DEVICE, "sync failed"); break; }
+        for (int i = 0; i + 1 < nev; i++) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) != hipSuccess) { rc = fail(RWKV_E_DEVICE, "hipEventElapsedTime failed"); break; }
+            int cls;
+            if (i == 0) cls = 0;
+            else if (i <= (int)(4 * L)) cls = 1 + (i - 1) % 4;
+            else if (i == (int)(4 * L + 1)) cls = 5;
+            else cls = 6;
+            ms[cls] += (double)t;
+        }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (bytes) {
+        bytes[0] = 4 * D; bytes[1] = 3 * D * D; bytes[2] = D * D; bytes[3] = 5 * D * D; bytes[4] = 4 * D * D;
+        bytes[5] = V * D; bytes[6] = 0;
+    }
+    if (launches) {
+        launches[0] = 1; launches[1] = launches[2] = launches[3] = launches[4] = (uint32_t)L; launches[5] = 1; launches[6] = 1;
+    }
+    return rc;
+}
+
+int rwkv_mm8_one(rwkv_ctx *c, uint64_t N, uint64_t M, const float *x, const uint8_t *w, const float *r,
+                 const float *o, float *y)
+{
+    if (!c || !x || !w || !r || !o || !y) return fail(RWKV_E_ARG, "NULL argument");
+    if (N == 0 || M < 4 || N % 16 != 0) return fail(RWKV_E_ARG, "N must be a positive multiple of 16, M >= 4");
+    const bool quarters = N > 5120;
+    if (quarters && (N % 64 != 0 || N / 4 > 5120)) return fail(RWKV_E_ARG, "N > 5120 must be 4*Dq with Dq <= 5120, Dq %% 16 == 0");
+    HIPCHK(hipSetDevice(c->device));
+    uint8_t *wt = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&wt), N * M));
+    dim3 rg((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
+    hipLaunchKernelGGL(k_retile, rg, dim3(256), 0, c->stream, w, wt, (int)N, (int)M, 1, 1, 0);
+    Mm8Args a{wt, x, r, o, y, (int)N, (int)M};
+    const int S = (int)(((quarters ? N / 4 : N) + 1023) / 1024);
+    const size_t smem = RED_BYTES + (size_t)(quarters ? 4 : 1) * S * 4096;
+    int rc = 0;
+    if (quarters) {
+        DISPATCH_S(S, rc = allow_smem(k_mm8<S_, true>, smem));
+        if (!rc) DISPATCH_S(S, k_mm8<S_, true><<<dim3(c->grid), dim3(NT), smem, c->stream>>>(a));
+    } else {
+        DISPATCH_S(S, rc = allow_smem(k_mm8<S_, false>, smem));
+        if (!rc) DISPATCH_S(S, k_mm8<S_, false><<<dim3(c->grid), dim3(NT), smem, c->stream>>>(a));
+    }
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(wt);
+    if (rc) return rc;
+    HIPCHK(e1);
+    HIPCHK(e2);
+    return 0;
+}
+
+} // extern "C"

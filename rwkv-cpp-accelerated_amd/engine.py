@@ -1,0 +1,256 @@
+"""ctypes binding of librwkv_mi355x.so (include/rwkv_mi355x.h) and a Python mirror of the
+reference's host class `RWKV` (include/rwkv/rwkv/rwkv.h:245-429).
+
+Nothing here computes: every forward goes through the C-ABI into the HIP kernels.  There is no
+CPU fallback -- if the shared library is missing or no HIP device is present the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import modelfile as mf
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librwkv_mi355x.so")
+
+MODE_PARRALEL, MODE_GPT = 0, 1   # reference enums/enum.h:2-5
+N_KCLASS = 7
+KCLASS_NAMES = ["embed_ln0", "att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head", "argmax"]
+
+# every entry point declared in include/rwkv_mi355x.h (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "rwkv_create", "rwkv_load_file", "rwkv_load_tensors", "rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx",
+    "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
+    "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
+    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one",
+]
+
+_lib = None
+
+
+class RWKVError(RuntimeError):
+    pass
+
+
+def lib():
+    """dlopen the engine; fail loudly when it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RWKVError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.rwkv_create.argtypes = [C.POINTER(vp), i32]; L.rwkv_create.restype = i32
+    L.rwkv_load_file.argtypes = [vp, C.c_char_p, u64]; L.rwkv_load_file.restype = i32
+    L.rwkv_load_tensors.argtypes = [vp, u64, u64, C.POINTER(vp), i32, u64]; L.rwkv_load_tensors.restype = i32
+    for f in ("rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx", "rwkv_bytes_per_token"):
+        getattr(L, f).argtypes = [vp]; getattr(L, f).restype = u64
+    L.rwkv_forward.argtypes = [vp, C.POINTER(u64), u64, i32]; L.rwkv_forward.restype = i32
+    L.rwkv_set_state.argtypes = [vp] + [vp] * 5 + [u64]; L.rwkv_set_state.restype = i32
+    L.rwkv_get_output.argtypes = [vp] + [vp] * 6 + [u64]; L.rwkv_get_output.restype = i32
+    L.rwkv_reset_state.argtypes = [vp]; L.rwkv_reset_state.restype = i32
+    L.rwkv_decode_greedy.argtypes = [vp, u64, u64, C.POINTER(u64)]; L.rwkv_decode_greedy.restype = i32
+    L.rwkv_free.argtypes = [vp]; L.rwkv_free.restype = None
+    L.rwkv_last_error.argtypes = []; L.rwkv_last_error.restype = C.c_char_p
+    L.rwkv_logits_device.argtypes = [vp]; L.rwkv_logits_device.restype = vp
+    L.rwkv_state_device.argtypes = [vp, i32]; L.rwkv_state_device.restype = vp
+    L.rwkv_stream.argtypes = [vp]; L.rwkv_stream.restype = vp
+    L.rwkv_profile_token.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(C.c_uint32)]
+    L.rwkv_profile_token.restype = i32
+    L.rwkv_mm8_one.argtypes = [vp, u64, u64, vp, vp, vp, vp, vp]; L.rwkv_mm8_one.restype = i32
+    _lib = L
+    return L
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise RWKVError(lib().rwkv_last_error().decode(errors="replace") + f" (status {rc})")
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class RWKVState:
+    """Mirror of reference class RWKVState (rwkv.h:140-242): five host arrays [stateSize][L][D] f64."""
+
+    def __init__(self, num_layers: int, num_embed: int, stateSize: int = 1):
+        self.num_layers, self.num_embed, self.stateSize = num_layers, num_embed, stateSize
+        n = num_layers * num_embed * stateSize
+        self.statexy = np.zeros(n); self.stateaa = np.zeros(n); self.statebb = np.zeros(n)
+        self.statepp = np.zeros(n); self.statedd = np.zeros(n)
+
+    def arrays(self):
+        return [self.statexy, self.stateaa, self.statebb, self.statepp, self.statedd]
+
+    def copy(self) -> "RWKVState":
+        s = RWKVState(self.num_layers, self.num_embed, self.stateSize)
+        for d, a in zip(s.arrays(), self.arrays()):
+            d[:] = a
+        return s
+
+    def getSubState(self, offset: int = 0) -> "RWKVState":                      # rwkv.h:223-228
+        if offset >= self.stateSize:
+            raise RuntimeError(f"State get offset out of bounds, max offset is {self.stateSize}")
+        n = self.num_layers * self.num_embed
+        s = RWKVState(self.num_layers, self.num_embed, 1)
+        for d, a in zip(s.arrays(), self.arrays()):
+            d[:] = a[offset * n:(offset + 1) * n]   # (the reference's ctor ignores the L*D stride, rwkv.h:205; fixed)
+        return s
+
+    def setSubState(self, other: "RWKVState", offset: int = 0):                 # rwkv.h:231-240
+        n = self.num_layers * self.num_embed
+        for d, a in zip(self.arrays(), other.arrays()):
+            d[offset * n:(offset + 1) * n] = a[:n]
+
+
+class RWKV:
+    """Mirror of reference class RWKV (rwkv.h:245-429) on top of the C-ABI.
+
+    Default semantics are the reference's: the HOST state is authoritative and is uploaded before
+    / downloaded after every forward (rwkv.h:353,372).  `resident=True` keeps the state on the
+    device between calls (sync explicitly with pull_state/push_state): the engine's fast path."""
+
+    def __init__(self, device: int = 0, resident: bool = False):
+        self._h = C.c_void_p()
+        _chk(lib().rwkv_create(C.byref(self._h), device))
+        self.ready = False
+        self.resident = resident
+        self.num_layers = self.num_embed = 0
+        self.maxContext = 1
+        self.state = None
+        self.out = None
+
+    # -- loading ---------------------------------------------------------------------------
+    def _after_load(self):
+        L = lib()
+        self.num_layers = int(L.rwkv_n_layers(self._h)); self.num_embed = int(L.rwkv_n_embed(self._h))
+        self.maxContext = int(L.rwkv_max_ctx(self._h))
+        self.state = RWKVState(self.num_layers, self.num_embed, self.maxContext)
+        self.out = np.zeros(mf.VOCAB * self.maxContext, dtype=np.float32)
+        self.ready = True
+
+    def loadFile(self, filename: str, maxGPT: int = 1):                          # rwkv.h:281-310
+        if self.ready:
+            raise RuntimeError("RWKV already loaded")
+        _chk(lib().rwkv_load_file(self._h, os.fsencode(filename), maxGPT))
+        self._after_load()
+
+    def loadTensors(self, n_layers: int, n_embed: int, tensors, maxGPT: int = 1):
+        """46 tensors in file layout: numpy arrays (host) or torch CUDA tensors (device), not mixed;
+        scratch/state slots may be None."""
+        if self.ready:
+            raise RuntimeError("RWKV already loaded")
+        ptrs = (C.c_void_p * mf.N_TENSORS)()
+        on_device = None
+        keep = []
+        for i, t in enumerate(tensors):
+            if t is None:
+                if i not in mf.BUFFER_SLOTS:
+                    raise ValueError(f"tensor {i} ({mf.NAMES[i]}) is required")
+                ptrs[i] = None
+                continue
+            if isinstance(t, np.ndarray):
+                a = np.ascontiguousarray(t, dtype=mf.DTYPES[i]); keep.append(a)
+                ptrs[i] = a.ctypes.data; dev = False
+            else:   # torch tensor
+                tt = t.contiguous(); keep.append(tt)
+                ptrs[i] = tt.data_ptr(); dev = tt.is_cuda
+                if tt.numel() * tt.element_size() != mf.sizes(n_layers, n_embed)[i] * np.dtype(mf.DTYPES[i]).itemsize:
+                    raise ValueError(f"tensor {i} ({mf.NAMES[i]}) has the wrong byte size")
+            if i in mf.BUFFER_SLOTS:
+                continue
+            if on_device is None:
+                on_device = dev
+            elif on_device != dev:
+                raise ValueError("tensors must be all host or all device")
+        if on_device:
+            import torch
+            torch.cuda.synchronize()
+        _chk(lib().rwkv_load_tensors(self._h, n_layers, n_embed, ptrs, 1 if on_device else 0, maxGPT))
+        self._after_load()
+
+    # -- state sync --------------------------------------------------------------------------
+    def push_state(self, n_slots: int | None = None):
+        n = self.maxContext if n_slots is None else n_slots
+        _chk(lib().rwkv_set_state(self._h, *[_ptr(a) for a in self.state.arrays()], n))
+
+    def pull_state(self, n_slots: int | None = None):
+        n = self.maxContext if n_slots is None else n_slots
+        _chk(lib().rwkv_get_output(self._h, None, *[_ptr(a) for a in self.state.arrays()], n))
+
+    def reset_state(self):
+        for a in self.state.arrays():
+            a[:] = 0
+        _chk(lib().rwkv_reset_state(self._h))
+
+    # -- forward -----------------------------------------------------------------------------
+    def forward(self, token, mode: int = MODE_GPT):                               # rwkv.h:339-388
+        if not self.ready:
+            raise RuntimeError("RWKV not loaded")
+        toks = [int(token)] if np.isscalar(token) else [int(t) for t in token]
+        if len(toks) > self.maxContext:
+            raise RuntimeError(f"Context too large, max context is {self.maxContext}")
+        T = len(toks)
+        arr = (C.c_uint64 * T)(*toks)
+        if not self.resident:
+            self.push_state(T)                                                    # setState, rwkv.h:353
+        _chk(lib().rwkv_forward(self._h, arr, T, mode))
+        if self.resident:
+            _chk(lib().rwkv_get_output(self._h, _ptr(self.out), None, None, None, None, None, T))
+        else:
+            _chk(lib().rwkv_get_output(self._h, _ptr(self.out), *[_ptr(a) for a in self.state.arrays()], T))   # rwkv.h:372
+        return self.out
+
+    def decode_greedy(self, first_token: int, n_tokens: int) -> np.ndarray:
+        """device-side greedy continuation on the resident state (slot 0); returns the picked ids."""
+        if not self.ready:
+            raise RuntimeError("RWKV not loaded")
+        out = (C.c_uint64 * n_tokens)()
+        _chk(lib().rwkv_decode_greedy(self._h, int(first_token), n_tokens, out))
+        return np.frombuffer(out, dtype=np.uint64).copy()
+
+    def logits(self, n_tokens: int = 1) -> np.ndarray:
+        _chk(lib().rwkv_get_output(self._h, _ptr(self.out), None, None, None, None, None, n_tokens))
+        return self.out[: n_tokens * mf.VOCAB]
+
+    def emptyState(self) -> RWKVState:                                            # rwkv.h:390-393
+        return RWKVState(self.num_layers, self.num_embed, 1)
+
+    def getTensorSize(self, i: int) -> int:                                       # rwkv.h:325-328
+        return mf.sizes(self.num_layers, self.num_embed)[i]
+
+    def getTensorTypes(self, i: int) -> int:                                      # rwkv.h:331-334
+        return np.dtype(mf.DTYPES[i]).itemsize
+
+    # -- measurement -------------------------------------------------------------------------
+    def bytes_per_token(self) -> int:
+        return int(lib().rwkv_bytes_per_token(self._h))
+
+    def profile_token(self, token: int = 1, reps: int = 8):
+        ms = (C.c_double * N_KCLASS)(); by = (C.c_uint64 * N_KCLASS)(); ln = (C.c_uint32 * N_KCLASS)()
+        _chk(lib().rwkv_profile_token(self._h, token, reps, ms, by, ln))
+        return [dict(name=KCLASS_NAMES[k], ms_total=ms[k], reps=reps, launches_per_token=int(ln[k]),
+                     bytes_per_launch=int(by[k])) for k in range(N_KCLASS)]
+
+    def stream(self) -> int:
+        return int(lib().rwkv_stream(self._h) or 0)
+
+    def mm8_one(self, N, M, x_dev, w_dev, r_dev, o_dev, y_dev):
+        _chk(lib().rwkv_mm8_one(self._h, N, M, x_dev, w_dev, r_dev, o_dev, y_dev))
+
+    def close(self):
+        if self._h:
+            lib().rwkv_free(self._h)
+            self._h = C.c_void_p()
+            self.ready = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,13 @@
+"""Import shim: the package directory is named `rwkv-cpp-accelerated_amd` (hyphen, mirroring the
+reference repo's name), which Python cannot import directly.  `import rwkv_cpp_accelerated_amd`
+loads that directory as a regular package under this module name."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rwkv-cpp-accelerated_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,187 @@
+"""GPU parity tests proper: the HIP engine (through the C-ABI) against the CPU oracle on the same
+seeded inputs.  Run on the MI355X box with `-m gpu`."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from rwkv_cpp_accelerated_amd import modelfile as mf
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_mod(built):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    from rwkv_cpp_accelerated_amd import engine
+    engine.lib()   # raises if the HIP extension is missing: no fallback
+    return engine
+
+
+def _model(eng_mod, L, D, seed, maxGPT=1, resident=True):
+    t = mf.synthetic_tensors(L, D, seed=seed)
+    m = eng_mod.RWKV(resident=resident)
+    m.loadTensors(L, D, t, maxGPT=maxGPT)
+    return m, t
+
+
+# the five mm8 shapes of a model (N -> M): att_out/ffn_r D->D, ffn_k D->4D, ffn_v 4D->D, head D->V
+@pytest.mark.parametrize("N,M", [(768, 768), (768, 3072), (3072, 768), (2048, 2048), (1024, 50277),
+                                 (4096, 4096), (16384, 4096), (5120, 1000), (20480, 64), (2560, 37), (16, 4)])
+def test_mm8_one_shapes(eng_mod, oracle, N, M):
+    import torch
+    rng = np.random.default_rng(N * 7 + M)
+    x = rng.standard_normal(N).astype(np.float32)
+    w = rng.integers(0, 256, (N, M), dtype=np.uint8)
+    a = (1.0 / np.sqrt(N)) * (0.5 + rng.random(N))
+    r = (2 * a / 255).astype(np.float32); o = (-a * (1 + 0.1 * rng.standard_normal(N))).astype(np.float32)
+    ref = oracle.mm8_one(x[None, :], w, r, o)[0]
+    m = eng_mod.RWKV()
+    dx, dw, dr, do_ = (torch.from_numpy(v).cuda() for v in (x, w, r, o))
+    dy = torch.full((M,), float("nan"), device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    m.mm8_one(N, M, dx.data_ptr(), dw.data_ptr(), dr.data_ptr(), do_.data_ptr(), dy.data_ptr())
+    got = dy.cpu().numpy()
+    exact = x.astype(np.float64) @ (w.astype(np.float64) * r.astype(np.float64)[:, None] + o.astype(np.float64)[:, None])
+    scale = np.abs(exact).max()
+    assert np.abs(got - ref).max() <= 1e-4 * scale          # engine vs oracle (both f32 accumulations)
+    assert np.abs(got - exact).max() <= 1e-4 * scale        # and vs exact arithmetic
+    m.close()
+
+
+@pytest.mark.parametrize("L,D", [(2, 64), (3, 768), (2, 1024), (2, 2048), (1, 2560), (1, 4096), (1, 5120)])
+def test_token_logits_vs_oracle(eng_mod, oracle, L, D):
+    """teacher-forced single-token decode: per-step logits and state vs the CPU restatement"""
+    m, t = _model(eng_mod, L, D, seed=100 + D)
+    om = oracle.from_tensors(L, D, t)
+    st = om.new_state()
+    toks = [11, 50276, 1, 4097, 11, 333]
+    for step, tk in enumerate(toks):
+        ref = om.forward([tk], st)[0]
+        got = m.forward(tk)[: mf.VOCAB]
+        parity.check_logits(got, ref, f"L{L} D{D} step {step}")
+        parity.check_argmax(got, ref, f"L{L} D{D} step {step}")
+    m.pull_state(1)
+    for name, g, r in zip("xy aa bb pp dd".split(), m.state.arrays(), st):
+        scale = max(1.0, np.abs(r).max())
+        assert np.abs(g[: L * D] - r).max() <= 1e-4 * scale, name
+    om.close(); m.close()
+
+
+def test_gpt_mode_chunk_equals_token_by_token(eng_mod, oracle):
+    """GPT mode: T consecutive tokens of one sequence (rwkv.cu:227-240); logits for every position"""
+    L, D, T = 2, 768, 5
+    m, t = _model(eng_mod, L, D, seed=5, maxGPT=8)
+    om = oracle.from_tensors(L, D, t)
+    toks = [9, 8, 7, 50000, 6]
+    ref = om.forward(toks, om.new_state())
+    got = m.forward(toks, eng_mod.MODE_GPT)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+    for i in range(T):
+        parity.check_logits(got[i], ref[i], f"pos {i}")
+    m.reset_state()
+    one = np.stack([m.forward(tk)[: mf.VOCAB].copy() for tk in toks])
+    assert np.array_equal(one, got)          # deterministic: chunked == token-by-token, bit for bit
+    om.close(); m.close()
+
+
+def test_parralel_mode_independent_slots(eng_mod, oracle):
+    """PARRALEL mode: one step of T independent sequences, state slot t (rwkv.cu:238-240)"""
+    L, D, T = 2, 768, 3
+    m, t = _model(eng_mod, L, D, seed=6, maxGPT=4, resident=False)
+    om = oracle.from_tensors(L, D, t)
+    sp = om.new_state(slots=T)
+    for rnd, toks in enumerate([[3, 4, 5], [6, 7, 3]]):
+        ref = om.forward(toks, sp, mode=0)
+        got = m.forward(toks, eng_mod.MODE_PARRALEL)[: T * mf.VOCAB].reshape(T, mf.VOCAB)
+        for i in range(T):
+            parity.check_logits(got[i], ref[i], f"round {rnd} slot {i}")
+    for g, r in zip(m.state.arrays(), sp):      # host-authoritative (drop-in) mode: state came back
+        assert np.abs(g[: T * L * D] - r).max() <= 1e-4 * max(1.0, np.abs(r).max())
+    om.close(); m.close()
+
+
+def test_load_file_equals_load_tensors(eng_mod, tmp_path):
+    L, D = 2, 768
+    t = mf.synthetic_tensors(L, D, seed=8)
+    p = str(tmp_path / "model.bin")
+    mf.write_bin(p, L, D, t)
+    a = eng_mod.RWKV(resident=True); a.loadFile(p)
+    b = eng_mod.RWKV(resident=True); b.loadTensors(L, D, t)
+    import torch
+    tt = [None if (x is None or i in mf.BUFFER_SLOTS) else torch.from_numpy(np.ascontiguousarray(x)).cuda() for i, x in enumerate(t)]
+    c = eng_mod.RWKV(resident=True); c.loadTensors(L, D, tt)
+    assert (a.num_layers, a.num_embed) == (L, D)
+    for tk in (5, 6):
+        la = a.forward(tk).copy(); lb = b.forward(tk).copy(); lc = c.forward(tk).copy()
+        assert np.array_equal(la, lb) and np.array_equal(la, lc)
+    with pytest.raises(RuntimeError, match="already loaded"):
+        a.loadFile(p)
+    with pytest.raises(eng_mod.RWKVError, match="Error opening file"):
+        eng_mod.RWKV().loadFile(str(tmp_path / "nope.bin"))
+    with pytest.raises(RuntimeError, match="Context too large"):
+        a.forward([1, 2], eng_mod.MODE_GPT)
+    for x in (a, b, c):
+        x.close()
+
+
+def test_state_roundtrip_and_snapshot(eng_mod):
+    """RWKVState value semantics (rwkv.h:140-242): snapshot, diverge, restore => identical logits"""
+    L, D = 2, 768
+    m, _ = _model(eng_mod, L, D, seed=9, resident=False)
+    for tk in (1, 2, 3):
+        m.forward(tk)
+    snap = m.state.getSubState(0)
+    l_a = m.forward(10).copy()
+    m.forward(11)
+    m.state.setSubState(snap, 0)
+    l_b = m.forward(10).copy()
+    assert np.array_equal(l_a, l_b)
+    m.close()
+
+
+def test_decode_greedy_matches_host_loop(eng_mod):
+    """device-side argmax feedback == host loop of forward + argmax(out[0] banned)"""
+    L, D, n = 2, 1024, 24
+    m, _ = _model(eng_mod, L, D, seed=10)
+    ids = m.decode_greedy(42, n)
+    last = m.logits(1).copy()
+    m.reset_state()
+    tk, want = 42, []
+    for _ in range(n):
+        lg = m.forward(tk)[: mf.VOCAB]
+        tk = parity.argmax_ban0(lg); want.append(tk)
+    assert list(map(int, ids)) == want
+    assert np.array_equal(last, m.out[: mf.VOCAB])
+    m.close()
+
+
+def test_full_size_properties_7b_layer(eng_mod):
+    """BASELINE.json full width (D=4096) through size-independent properties: determinism (no float
+    atomics => bit-identical reruns), state-slot independence, and linearity of the GEMV in x."""
+    import torch
+    L, D = 2, 4096
+    t = mf.synthetic_tensors_torch(L, D, seed=3)
+    m = eng_mod.RWKV(resident=True); m.loadTensors(L, D, t, maxGPT=2)
+    a = m.forward([7, 9], eng_mod.MODE_PARRALEL)[: 2 * mf.VOCAB].copy()
+    m.reset_state()
+    b = m.forward([9, 7], eng_mod.MODE_PARRALEL)[: 2 * mf.VOCAB].copy()
+    assert np.array_equal(a[: mf.VOCAB], b[mf.VOCAB:]) and np.array_equal(a[mf.VOCAB:], b[: mf.VOCAB])
+    m.reset_state()
+    c = m.forward([7, 9], eng_mod.MODE_PARRALEL)[: 2 * mf.VOCAB].copy()
+    assert np.array_equal(a, c)
+    # linearity: mm8(x1 + x2) == mm8(x1) + mm8(x2) up to f32 rounding, at the ffn_v shape 16384 -> 4096
+    N, M = 16384, 4096
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    w = torch.randint(0, 256, (N, M), generator=g, device="cuda", dtype=torch.uint8)
+    r = torch.rand(N, generator=g, device="cuda") * 1e-4; o = -r * 127
+    x1 = torch.randn(N, generator=g, device="cuda"); x2 = torch.randn(N, generator=g, device="cuda")
+    ys = []
+    for x in (x1, x2, x1 + x2):
+        y = torch.empty(M, device="cuda"); torch.cuda.synchronize()
+        m.mm8_one(N, M, x.data_ptr(), w.data_ptr(), r.data_ptr(), o.data_ptr(), y.data_ptr()); ys.append(y)
+    err = (ys[2] - ys[0] - ys[1]).abs().max().item()
+    assert err <= 1e-4 * ys[2].abs().max().item()
+    m.close()
