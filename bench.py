@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: tokens/s of single-stream greedy decode of an RWKV-4 uint8
+model on MI355X, with the achieved fraction of the HBM-read roofline of the dominant kernel and
+the CPU restatement timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model 7B] [--no-cpu-baseline]
+
+A "step" is one pass of the hot path: one token through embed+ln0, L x {time-mix, channel-mix},
+ln_out + head, and the device-side greedy pick that feeds the next step (storygen's loop with
+argmax, examples/storygen/storygen.cpp:63-69).  Weights are synthetic (seeded, real shapes; there
+is no network for checkpoints), resident in HBM before the timed region; state never leaves the
+device inside it.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): single-stream decode is a strict
+chain of layers, so it does not speed up across GPUs; each rank decodes its own independent
+stream on its own GPU ("replicas only", weak scaling, no data-path collective).  The only
+collectives are the barrier and the MAX-reduction of the timing that the contract asks for.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1024)     # BASELINE: 1024-token greedy continuation
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--model", default=os.environ.get("RWKV_BENCH_MODEL", "7B"))
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--profile-reps", type=int, default=16)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+
+    import rwkv_cpp_accelerated_amd as pkg
+    from rwkv_cpp_accelerated_amd import engine, modelfile as mf
+    pkg.build.build_engine()
+
+    L, D = mf.SHAPES[args.model]
+    dev = f"cuda:{local_rank}"
+    tensors = mf.synthetic_tensors_torch(L, D, seed=args.seed + rank, device=dev)
+    torch.cuda.synchronize()
+    m = engine.RWKV(device=local_rank, resident=True)
+    t0 = time.time()
+    m.loadTensors(L, D, tensors, maxGPT=1)
+    load_s = time.time() - t0
+
+    rng = np.random.default_rng(1)
+    prompt = [int(x) for x in rng.integers(2, mf.VOCAB, 32)]     # fixed 32-token prompt
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: prompt ingestion + W warm-up steps
+    for tk in prompt:
+        m.forward(tk)
+    first = int(np.argmax(m.out[1:mf.VOCAB])) + 1
+    if args.warmup > 0:
+        ids = m.decode_greedy(first, args.warmup)
+        first = int(ids[-1])
+
+    sync_all()
+    t0 = time.perf_counter()
+    ids = m.decode_greedy(first, args.steps)          # synchronises the engine stream before returning
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    tok_s = args.steps * world / dt
+    B_tok = m.bytes_per_token()
+
+    # ---- per-kernel HIP-event timing on the engine's stream (same stream, same token chain) ----
+    prof = m.profile_token(token=int(ids[-1]), reps=args.profile_reps)
+    per_launch = {}
+    for p in prof:
+        n = p["reps"] * p["launches_per_token"]
+        us = 1e3 * p["ms_total"] / n if n else 0.0
+        per_launch[p["name"]] = dict(us=us, bytes=p["bytes_per_launch"],
+                                     gbps=(p["bytes_per_launch"] / (us * 1e-6) / 1e9) if us > 0 else 0.0,
+                                     launches_per_token=p["launches_per_token"])
+    # dominant kernel = the class with the most device time per token
+    dom = max((k for k in per_launch if per_launch[k]["bytes"] > 0 and k != "embed_ln0"),
+              key=lambda k: per_launch[k]["us"] * per_launch[k]["launches_per_token"])
+    roof = dict(bound="hbm", kernel=dom, achieved=round(per_launch[dom]["gbps"], 1), peak=HBM_PEAK_GBPS,
+                unit="GB/s", frac=round(per_launch[dom]["gbps"] / HBM_PEAK_GBPS, 4),
+                launch_us=round(per_launch[dom]["us"], 3), bytes_per_launch=per_launch[dom]["bytes"],
+                traffic=None,
+                method="hipEvent pairs around every launch of an eager replay of the token chain on the engine stream, "
+                       f"{args.profile_reps} tokens, right after the timed region")
+    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # filled from rocprofv3 --pmc passes (see profiles/)
+    if os.path.exists(traffic_file):
+        try:
+            roof["traffic"] = json.load(open(traffic_file)).get(args.model, {}).get(dom)
+        except Exception:
+            pass
+
+    line = dict(
+        metric="tokens/sec single-stream RWKV-4 uint8 greedy decode",
+        value=round(tok_s, 2), unit="tokens/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+        ms_per_step=round(1e3 * dt / args.steps, 5), higher_is_better=True, scaling="weak",
+        vs_baseline=None, dtype="u8 weights x f32 activations, f32 accumulate, f64 state", data="synthetic",
+        config=dict(workload=f"RWKV-4-Raven-{args.model} uint8 single-stream greedy decode "
+                             f"(L={L}, D={D}, V={mf.VOCAB}), 32-token prompt then {args.steps}-token continuation, "
+                             "device-resident state",
+                    parallelism=("1 GPU" if world == 1 else f"{world} independent replicas, one stream per GPU (replicas only)"),
+                    launches_per_token=4 * L + 3, bytes_per_token=B_tok),
+        roofline=roof,
+        end_to_end=dict(achieved_GBps=round(B_tok * tok_s / world / 1e9, 1),
+                        frac_of_8TBps=round(B_tok * tok_s / world / 1e9 / HBM_PEAK_GBPS, 4)),
+        kernels={k: dict(us=round(v["us"], 3), GBps=round(v["gbps"], 1)) for k, v in per_launch.items()},
+        load_s=round(load_s, 2),
+    )
+
+    # ---- drop-in mode: host-authoritative state, uploaded/downloaded every token (rwkv.h:353,372) ----
+    if rank == 0:
+        m.resident = False
+        m.pull_state(1)
+        n_di = min(64, args.steps)
+        t0 = time.perf_counter()
+        tk = int(ids[-1])
+        for _ in range(n_di):
+            lg = m.forward(tk)
+            tk = int(np.argmax(lg[1:mf.VOCAB])) + 1
+        line["drop_in_mode"] = dict(tokens_per_s=round(n_di / (time.perf_counter() - t0), 2),
+                                    note="host state authoritative: 5xLxD f64 up + down and logits down per token (PCIe-inclusive)")
+        m.resident = True
+
+    # ---- CPU baseline: the oracle (CPU restatement of rwkv.cu:493-593) on this box's host cores ----
+    if rank == 0 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(pkg, mf, tensors, L, D, prompt, args.cpu_seconds)
+
+    m.close()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, mf, tensors, L, D, prompt, budget_s):
+    """rank 0, N=1 leg: time the oracle on a bounded sample of the same workload."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    pkg.build.build_oracle()
+    import oracle_lib
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    host = [None if t is None else t.cpu().numpy() for t in tensors]
+    copy_s = time.time() - t0
+    om = oracle_lib.Oracle().from_tensors(L, D, host)
+    st = om.new_state()
+    t0 = time.perf_counter()
+    lg = om.forward([prompt[0]], st)
+    one = time.perf_counter() - t0
+    n = int(max(1, min(31, (budget_s - one) // max(one, 1e-3))))
+    t0 = time.perf_counter()
+    tk = int(np.argmax(lg[0][1:])) + 1
+    for i in range(n):
+        lg = om.forward([tk], st)
+        tk = int(np.argmax(lg[0][1:])) + 1
+    dt = time.perf_counter() - t0
+    om.close()
+    return dict(value=round(n / dt, 4), unit="tokens/s", cores=cores, kind="port",
+                sample=f"{n} greedy tokens of the same synthetic model after a 1-token warm-up "
+                       f"(oracle/rwkv_oracle.c, OpenMP over output columns; weights copied to host in {copy_s:.1f}s)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,248 @@
+// rwkv.h -- C++ drop-in for the reference's host API (reference include/rwkv.h ->
+// include/rwkv/rwkv/rwkv.h: enum MODE, class RWKVState :140-242, class RWKV :245-429),
+// re-implemented as a thin header-only wrapper over the C-ABI of librwkv_mi355x.so
+// (include/rwkv_mi355x.h).  Same public names, argument meaning and error behaviour, so the
+// reference's callers (examples/*/*.cpp, bindings/pybind/c_binding.cpp) compile against it:
+//
+//     g++ -std=c++17 app.cpp -I<repo>/include -L<repo>/rwkv-cpp-accelerated_amd/csrc -lrwkv_mi355x
+//
+// Differences, all documented in INTEGRATION.md:
+//   * `tensors[i]` are not populated (the engine owns re-tiled device memory behind the handle);
+//     getTensorSize()/getTensorTypes() still answer from the format table.
+//   * `residentState = true` keeps the state on the device between calls (the reference re-uploads
+//     and re-downloads 5 x L x D doubles around every forward, rwkv.h:353,372); the default keeps
+//     the reference's host-authoritative semantics.
+//   * the tokenizer (GPT-NeoX BPE) is outside this engine's scope: loadContext() takes token ids;
+//     the std::string overload exists when a `GPT2Tokenizer` with encode() is supplied by the
+//     application (define RWKV_HAVE_TOKENIZER before including this header).
+#ifndef RWKV_H
+#define RWKV_H
+
+#include <cstdint>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rwkv_mi355x.h"
+
+enum MODE { PARRALEL, GPT };   // reference enums/enum.h:2-5
+
+// tensor-slot indices of model.bin, reference enums/enum.h:7-55
+enum {
+    X, EMBED, LAYERNORMS, STATEXY, STATEAA, STATEBB, STATEPP, STATEDD, BUFFER1, BUFFER2, BUFFER3, BUFFER4,
+    MIXK, MIXV, MIXR, KM, VM, RM, KR, VR, RR, O1, O2, O3, ATTOUT, ATTOUTR, ATTOUTO, FFNMIXK, FFNMIXV,
+    FFNK, FFNV, FFNR, FFNKR, FFNVR, FFNRR, FFNKO, FFNVO, FFNRO, FFNKBUFFER, FFNVBUFFER, FFNRBUFFER,
+    DECAY, BONUS, HEAD, HEADR, HEADO
+};
+
+namespace rwkv_detail {
+inline unsigned long long tensor_size(unsigned long long i, unsigned long long a, unsigned long long b)
+{   // reference rwkv.h:124-128
+    const unsigned long long V = RWKV_VOCAB;
+    const unsigned long long s[46] = {b, V * b, 4 * (a + 1) * b, a * b, a * b, a * b, a * b, a * b, b, V, b, b,
+        a * b, a * b, a * b, a * b * b, a * b * b, a * b * b, a * b, a * b, a * b, a * b, a * b, a * b,
+        a * b * b, a * b, a * b, a * b, a * b, a * b * b * 4, a * b * b * 4, a * b * b,
+        a * b, a * b * 4, a * b, a * b, a * b * 4, a * b, b, b, b * 4, a * b, a * b, V * b, b, b};
+    return s[i];
+}
+inline unsigned long long tensor_type(unsigned long long i)
+{   // reference rwkv.h:84
+    const unsigned long long t[46] = {8, 4, 8, 8, 8, 8, 8, 8, 8, 4, 4, 4, 8, 8, 8, 1, 1, 1, 4, 4, 4, 4, 4,
+                                      4, 1, 4, 4, 8, 8, 1, 1, 1, 4, 4, 4, 4, 4, 4, 8, 8, 4, 8, 8, 1, 4, 4};
+    return t[i];
+}
+inline void check(int rc)
+{
+    if (rc != RWKV_OK) throw std::runtime_error(rwkv_last_error());
+}
+} // namespace rwkv_detail
+
+// reference rwkv.h:140-242 -- five host arrays [stateSize][num_layers][num_embed] doubles, value type
+class RWKVState
+{
+public:
+    double *statexy, *stateaa, *statebb, *statepp, *statedd;
+    unsigned long long num_layers, num_embed, stateSize;
+
+    RWKVState(unsigned long long num_layers, unsigned long long num_embed, unsigned long long stateSize)
+        : num_layers(num_layers), num_embed(num_embed), stateSize(stateSize)
+    {
+        alloc();
+        for (unsigned long long i = 0; i < total(); i++) statexy[i] = stateaa[i] = statebb[i] = statepp[i] = statedd[i] = 0;
+    }
+    RWKVState(const RWKVState &o) : num_layers(o.num_layers), num_embed(o.num_embed), stateSize(o.stateSize)
+    {
+        alloc();
+        copy_from(o, 0, 0, total());
+    }
+    // sub-state `offset` of `o` as a 1-slot state (the reference ignores the L*D stride here,
+    // rwkv.h:205-209 -- only offset 0 is ever used by its callers; this one honours it)
+    RWKVState(const RWKVState &o, unsigned long long offset) : num_layers(o.num_layers), num_embed(o.num_embed), stateSize(1)
+    {
+        alloc();
+        copy_from(o, offset * num_layers * num_embed, 0, num_layers * num_embed);
+    }
+    RWKVState &operator=(const RWKVState &o)
+    {
+        if (this != &o) {
+            release();
+            num_layers = o.num_layers; num_embed = o.num_embed; stateSize = o.stateSize;
+            alloc();
+            copy_from(o, 0, 0, total());
+        }
+        return *this;
+    }
+    ~RWKVState() { release(); }
+
+    RWKVState getSubState(unsigned long long offset = 0)
+    {
+        if (offset >= stateSize)
+            throw std::runtime_error("State get offset out of bounds, max offset is " + std::to_string(stateSize));
+        return RWKVState(*this, offset);
+    }
+    void setSubState(RWKVState &other, unsigned long long offset = 0)
+    {
+        const unsigned long long n = num_layers * num_embed;
+        for (unsigned long long i = 0; i < n; i++) {
+            statexy[i + offset * n] = other.statexy[i]; stateaa[i + offset * n] = other.stateaa[i];
+            statebb[i + offset * n] = other.statebb[i]; statepp[i + offset * n] = other.statepp[i];
+            statedd[i + offset * n] = other.statedd[i];
+        }
+    }
+
+private:
+    unsigned long long total() const { return num_layers * num_embed * stateSize; }
+    void alloc()
+    {
+        const unsigned long long n = total();
+        statexy = new double[n]; stateaa = new double[n]; statebb = new double[n]; statepp = new double[n]; statedd = new double[n];
+    }
+    void release() { delete[] statexy; delete[] stateaa; delete[] statebb; delete[] statepp; delete[] statedd; }
+    void copy_from(const RWKVState &o, unsigned long long src, unsigned long long dst, unsigned long long n)
+    {
+        for (unsigned long long i = 0; i < n; i++) {
+            statexy[dst + i] = o.statexy[src + i]; stateaa[dst + i] = o.stateaa[src + i]; statebb[dst + i] = o.statebb[src + i];
+            statepp[dst + i] = o.statepp[src + i]; statedd[dst + i] = o.statedd[src + i];
+        }
+    }
+};
+
+class GPT2Tokenizer;   // supplied by the application (see header comment)
+
+// reference rwkv.h:245-429
+class RWKV
+{
+public:
+    int **tensors = nullptr;            // kept for source compatibility; not populated (see header comment)
+    unsigned long long num_layers = 0;
+    unsigned long long num_embed = 0;
+    float *out = nullptr;               // host logits [maxContext][50277]; forward() returns this
+    unsigned long long maxContext = 1;
+    RWKVState *state = nullptr;         // host state (authoritative unless residentState)
+    GPT2Tokenizer *tokenizer = nullptr;
+    bool ready = false;
+    bool residentState = false;         // engine extension: keep state on the device between forwards
+    // deprecated aliases of state->*, reference rwkv.h:270-274
+    double *statexy = nullptr, *stateaa = nullptr, *statebb = nullptr, *statepp = nullptr, *statedd = nullptr;
+
+    RWKV() {}
+    explicit RWKV(int device) : device_(device) {}
+    RWKV(const RWKV &) = delete;
+    RWKV &operator=(const RWKV &) = delete;
+
+    void loadFile(const std::string &filename, unsigned long long maxGPT = 1)
+    {
+        if (ready) throw std::runtime_error("RWKV already loaded");
+        ensure_ctx();
+        const int rc = rwkv_load_file(ctx_, filename.c_str(), maxGPT);
+        if (rc == RWKV_E_IO) {   // the reference prints and exit(1)s (rwkv.cu:641-645); a library throws instead
+            std::cout << rwkv_last_error() << std::endl;
+            throw std::runtime_error(rwkv_last_error());
+        }
+        rwkv_detail::check(rc);
+        num_layers = rwkv_n_layers(ctx_);
+        num_embed = rwkv_n_embed(ctx_);
+        std::cout << "n_layers: " << num_layers << std::endl << "n_embed: " << num_embed << std::endl;   // rwkv.cu:653-654
+        state = new RWKVState(num_layers, num_embed, maxGPT);
+        statexy = state->statexy; stateaa = state->stateaa; statebb = state->statebb; statepp = state->statepp; statedd = state->statedd;
+        out = new float[(size_t)RWKV_VOCAB * maxGPT]();
+        maxContext = maxGPT;
+        ready = true;
+    }
+
+    unsigned long long getTensorSize(unsigned long long i) { return rwkv_detail::tensor_size(i, num_layers, num_embed); }
+    unsigned long long getTensorTypes(unsigned long long i) { return rwkv_detail::tensor_type(i); }
+
+    float *forward(std::vector<unsigned long long> token, MODE mode)
+    {
+        if (!ready) throw std::runtime_error("RWKV not loaded");
+        if (token.size() > maxContext)
+            throw std::runtime_error("Context too large, max context is " + std::to_string(maxContext));
+        const uint64_t T = token.size();
+        std::vector<uint64_t> t64(token.begin(), token.end());
+        if (!residentState)   // setState, rwkv.h:353
+            rwkv_detail::check(rwkv_set_state(ctx_, state->statexy, state->stateaa, state->statebb, state->statepp, state->statedd, T));
+        rwkv_detail::check(rwkv_forward(ctx_, t64.data(), T, mode == PARRALEL ? RWKV_MODE_PARRALEL : RWKV_MODE_GPT));
+        if (residentState)
+            rwkv_detail::check(rwkv_get_output(ctx_, out, nullptr, nullptr, nullptr, nullptr, nullptr, T));
+        else                  // getOutput, rwkv.h:372
+            rwkv_detail::check(rwkv_get_output(ctx_, out, state->statexy, state->stateaa, state->statebb, state->statepp, state->statedd, T));
+        return out;
+    }
+    float *forward(unsigned long long token) { return forward(std::vector<unsigned long long>{token}, GPT); }
+    float *forward(std::vector<long long> token, MODE mode)
+    {
+        std::vector<unsigned long long> t2(token.begin(), token.end());
+        return forward(t2, mode);
+    }
+
+    RWKVState emptyState() { return RWKVState(num_layers, num_embed, 1); }
+
+    // prompt ingestion in chunks of maxContext tokens, GPT mode (reference rwkv.h:395-413);
+    // returns the last prompt token like the reference does
+    long long loadContext(const std::vector<long long> &initial, bool progress = false)
+    {
+        if (initial.empty()) throw std::runtime_error("empty context");
+        for (size_t i = 0; i < initial.size(); i += maxContext) {
+            const size_t e = std::min(i + (size_t)maxContext, initial.size());
+            forward(std::vector<unsigned long long>(initial.begin() + i, initial.begin() + e), GPT);
+            if (progress) { std::cout << "\r" << int(float(i) / initial.size() * 100) << "%"; std::flush(std::cout); }
+        }
+        return initial.back();
+    }
+#ifdef RWKV_HAVE_TOKENIZER
+    long long loadContext(std::string input, bool progress = false) { return loadContext(tokenizer->encode(input), progress); }
+#endif
+
+    // engine extensions -------------------------------------------------------------------
+    // explicit sync points for residentState mode
+    void pushState() { rwkv_detail::check(rwkv_set_state(ctx_, state->statexy, state->stateaa, state->statebb, state->statepp, state->statedd, maxContext)); }
+    void pullState() { rwkv_detail::check(rwkv_get_output(ctx_, nullptr, state->statexy, state->stateaa, state->statebb, state->statepp, state->statedd, maxContext)); }
+    // device-side greedy continuation (storygen's loop with argmax; token 0 banned as out[0] = -99 does)
+    std::vector<unsigned long long> decodeGreedy(unsigned long long first, unsigned long long n)
+    {
+        if (!ready) throw std::runtime_error("RWKV not loaded");
+        std::vector<uint64_t> ids(n);
+        rwkv_detail::check(rwkv_decode_greedy(ctx_, first, n, ids.data()));
+        return std::vector<unsigned long long>(ids.begin(), ids.end());
+    }
+    rwkv_ctx *handle() { return ctx_; }
+
+    ~RWKV()
+    {
+        delete[] out;
+        if (ctx_) rwkv_free(ctx_);
+        delete state;
+    }
+
+private:
+    rwkv_ctx *ctx_ = nullptr;
+    int device_ = 0;
+    void ensure_ctx()
+    {
+        if (!ctx_) rwkv_detail::check(rwkv_create(&ctx_, device_));
+    }
+};
+
+#endif // RWKV_H

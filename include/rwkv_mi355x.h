@@ -113,6 +113,10 @@ uint64_t rwkv_bytes_per_token(const rwkv_ctx *ctx);
 int rwkv_profile_token(rwkv_ctx *ctx, uint64_t token, int reps, double *ms, uint64_t *bytes,
                        uint32_t *launches);
 
+/* Tuning aid: run one eager token with phase timestamps enabled in the middle layer's ffn r+k
+ * kernel; out receives grid*8*8 stamps of the 100 MHz device wall clock ([workgroup][wave][phase]). */
+int rwkv_debug_timeline(rwkv_ctx *ctx, uint64_t token, unsigned long long *out, uint64_t cap);
+
 /* Standalone launch of the engine's dequant-GEMV on caller-provided device buffers
  * (the kernel behind cudac_mm8_one(), rwkv.cu:297-311): w is FILE layout [N][M] u8 (one layer),
  * x f32[N], r/o f32[N]; y f32[M] is overwritten with x . (w*r + o).  Used by the unit tests. */

@@ -34,6 +34,7 @@
 #define V_SIZE 50277ULL
 #define JSPLIT 16ULL   /* MM8_ONE_JSPLIT, rwkv.cu:21 */
 #define EMBBLOCK 16ULL /* rwkv.cu:24: each device thread owns 16 consecutive elements */
+#define KCHUNK 256ULL  /* output columns per OpenMP work item (host parallelisation only) */
 
 enum { MODE_PARRALEL = 0, MODE_GPT = 1 }; /* enums/enum.h:2-5 */
 
@@ -161,10 +162,10 @@ static void mm8_core(uint64_t N, uint64_t M, const double *xd, const float *xf,
     const float *rl = r + layer * N, *ol = o + layer * N;
 #pragma omp parallel
     {
-        float *part = (float *)malloc(sizeof(float) * 4096);
-#pragma omp for schedule(static)
-        for (uint64_t k0 = 0; k0 < M; k0 += 4096) {
-            const uint64_t kn = (k0 + 4096 <= M) ? 4096 : (M - k0);
+        float *part = (float *)malloc(sizeof(float) * KCHUNK);
+#pragma omp for schedule(dynamic)
+        for (uint64_t k0 = 0; k0 < M; k0 += KCHUNK) {
+            const uint64_t kn = (k0 + KCHUNK <= M) ? KCHUNK : (M - k0);
             for (uint64_t t = 0; t < T; t++) {
                 for (uint64_t s = 0; s < JSPLIT; s++) {
                     uint64_t j0 = s * slab, j1 = (s + 1) * slab;

@@ -106,6 +106,8 @@ struct rwkv_ctx {
     unsigned long long *gen = nullptr;
     unsigned gen_cap = 0;
     hipGraphExec_t g_fwd = nullptr, g_greedy = nullptr;
+    unsigned long long *tl = nullptr;   // phase-timeline buffer (debug), [grid][NW][8]
+    bool tl_on = false;
     std::vector<void *> allocs;
 };
 
@@ -185,6 +187,7 @@ int enqueue_token(rwkv_ctx *c, bool with_argmax, hipEvent_t *ev)
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.sdd = c->state[4] + lo; fa.slot_stride = LD; fa.xx_buf = c->xx2;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.ctl = c->ctl; fa.D = D;
+        fa.tl = (c->tl_on && l == L / 2) ? c->tl : nullptr;
         EV();
         DISPATCH_S(S, k_ffn_rk<S_><<<dim3(grid), dim3(NT), smem_frk(S, gpb), c->stream>>>(fa));
 
@@ -248,7 +251,10 @@ template <typename T> int upload(rwkv_ctx *c, Source &src, int slot, T **dst)
     if (rc) return rc;
     const void *p = src.get(slot, 0, n * sizeof(T));
     if (!p) return fail(RWKV_E_IO, "tensor slot %d: short read / missing", slot);
-    HIPCHK(hipMemcpy(*dst, p, n * sizeof(T), src.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    // stream-ordered with the pack / re-tile kernels that read the copy (a default-stream D2D copy
+    // would race with them: the engine stream is non-blocking)
+    HIPCHK(hipMemcpyAsync(*dst, p, n * sizeof(T), src.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (!src.on_device) HIPCHK(hipStreamSynchronize(c->stream));   // host scratch is reused by the next get()
     return 0;
 }
 
@@ -352,7 +358,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     // state (zero, as `new RWKVState` does: rwkv.h:163-170) and scratch
     for (int s = 0; s < 5; s++) {
         if ((rc = dalloc(c, &c->state[s], max_ctx * L * D))) return rc;
-        HIPCHK(hipMemset(c->state[s], 0, max_ctx * L * D * sizeof(double)));
+        HIPCHK(hipMemsetAsync(c->state[s], 0, max_ctx * L * D * sizeof(double), c->stream));
     }
     if ((rc = dalloc(c, &c->x, D))) return rc;
     if ((rc = dalloc(c, &c->xx1, D))) return rc;
@@ -365,13 +371,14 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if ((rc = dalloc(c, &c->blk_val, (size_t)c->grid))) return rc;
     if ((rc = dalloc(c, &c->blk_idx, (size_t)c->grid))) return rc;
     if ((rc = dalloc(c, &c->logits, max_ctx * V))) return rc;
-    HIPCHK(hipMemset(c->logits, 0, max_ctx * V * sizeof(float)));
+    HIPCHK(hipMemsetAsync(c->logits, 0, max_ctx * V * sizeof(float), c->stream));
     if ((rc = dalloc(c, &c->ctl, 1))) return rc;
-    HIPCHK(hipMemset(c->ctl, 0, sizeof(Ctl)));
+    HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), c->stream));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_ctl), sizeof(Ctl) * max_ctx, hipHostMallocDefault));
     c->gen_cap = 1u << 16;
     if ((rc = dalloc(c, &c->gen, (size_t)c->gen_cap))) return rc;
 
+    HIPCHK(hipStreamSynchronize(c->stream));
     if ((rc = set_smem_limits(c))) return rc;
     const char *nograph = getenv("RWKV_NO_GRAPH");
     if (!(nograph && nograph[0] == '1')) {
@@ -594,6 +601,28 @@ int rwkv_profile_token(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint64
         launches[0] = 1; launches[1] = launches[2] = launches[3] = launches[4] = (uint32_t)L; launches[5] = 1; launches[6] = 1;
     }
     return rc;
+}
+
+// debug: run one eager token with the phase timeline of the middle layer's ffn_rk kernel enabled;
+// out receives grid*NW*8 100-MHz wall-clock stamps (see tl_stamp in kernels.hip.h)
+int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, uint64_t cap)
+{
+    if (!c || !out) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    const size_t n = (size_t)c->grid * NW * 8;
+    if (cap < n) return fail(RWKV_E_ARG, "need room for %zu stamps", n);
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->tl) { int rc = dalloc(c, &c->tl, n); if (rc) return rc; }
+    HIPCHK(hipMemsetAsync(c->tl, 0, n * 8, c->stream));
+    c->h_ctl[0].token = token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
+    HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+    c->tl_on = true;
+    int rc = enqueue_token(c, false, nullptr);
+    c->tl_on = false;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, c->tl, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int rwkv_mm8_one(rwkv_ctx *c, uint64_t N, uint64_t M, const float *x, const uint8_t *w, const float *r,

@@ -106,26 +106,40 @@ template <int PAT, int R> __device__ __forceinline__ constexpr int nvec()
     return PAT == PAT_SHARED ? 1 : (PAT == PAT_PER_ROW ? R : 2);
 }
 
-// issue the R*S 16-byte non-temporal loads of one row group (R rows `stride` bytes apart,
-// `chunks` 16-B pieces per row, piece c handled by lane c%64 at step c/64)
+// Row-group streaming.  A group = R rows `stride` bytes apart, each `chunks` 16-byte pieces long;
+// piece c belongs to lane c%64 at step c/64, so one step of one row is a 1 KiB coalesced
+// non-temporal wave load.  Lanes past the end of a row (rows that are not a multiple of 1 KiB)
+// re-read the row's last piece instead of branching: the staged vector is zero there, and a
+// predicated load would make hipcc drain vmcnt(0) at the branch join.
 template <int R, int S>
+__device__ __forceinline__ void step_load(u32x4 (&w)[R][S], int s, const uint8_t *__restrict__ base,
+                                          size_t stride, int chunks, int lane, unsigned mask = 0xffffffffu)
+{
+    // address = wave-uniform row pointer (SGPR pair) + 32-bit per-lane byte offset (one VGPR per
+    // step): global_load_dwordx4 v, v_off, s[base] -- no 64-bit per-(row,step) address registers.
+    // mask == 0 turns the step into R loads of one 16-byte piece (see group_dot's refill).
+    int c = lane + 64 * s;
+    c = c < chunks ? c : chunks - 1;
+    const unsigned off = ((unsigned)c << 4) & mask;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        w[r][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base + r * stride + off));
+}
+// steps [S0, S1) of a group, in consumption order (step-major)
+template <int R, int S, int S0, int S1>
 __device__ __forceinline__ void group_load(u32x4 (&w)[R][S], const uint8_t *__restrict__ base,
                                            size_t stride, int chunks, int lane)
 {
-    // issue order = consumption order of group_dot (step-major), so its counted vmcnt waits
-    // release the first step while later pieces are still in flight.  Lanes past the end of a
-    // row (rows that are not a multiple of 1 KiB) re-read the row's last piece instead of
-    // branching: the staged vector is zero there, and a predicated load would make hipcc drain
-    // vmcnt(0) at the branch join.
 #pragma unroll
-    for (int s = 0; s < S; s++) {
-        int c = lane + 64 * s;
-        c = c < chunks ? c : chunks - 1;
-#pragma unroll
-        for (int r = 0; r < R; r++)
-            w[r][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base + r * stride) + c);
-    }
+    for (int s = S0; s < S1; s++) step_load<R, S>(w, s, base, stride, chunks, lane);
 }
+// How many steps of the first group are requested BEFORE the prologue runs.  A wave that asks for
+// more than the memory pipe accepts stalls at issue (in-order) and its prologue waits with it; a
+// wave that asks for too little leaves HBM idle while the prologue computes.  Tuned on MI355X.
+#ifndef RWKV_PRE_STEPS
+#define RWKV_PRE_STEPS 2
+#endif
+template <int S> __device__ __forceinline__ constexpr int pre_steps() { return RWKV_PRE_STEPS < S ? RWKV_PRE_STEPS : S; }
 
 __device__ __forceinline__ void dot16(const u32x4 w, const f32x4 (&x)[4], float (&a)[4])
 {
@@ -139,15 +153,25 @@ __device__ __forceinline__ void dot16(const u32x4 w, const f32x4 (&x)[4], float 
     }
 }
 
-// dot products of the loaded group with the staged vector(s); every lane gets all R sums.
-// The LDS reads of the activation pieces are software-pipelined one (step, vector) item ahead
-// and pinned with sched barriers, so at most two 16-float pieces are live (no spills at R*S=20).
+// Dot products of the loaded group with the staged vector(s); every lane gets all R sums.
+//  * The LDS reads of the activation pieces are software-pipelined one (step, vector) item ahead
+//    and pinned with sched barriers, so at most two 16-float pieces are live.
+//  * Refill: as soon as step s of this group has been consumed its registers are re-loaded with
+//    step s of the NEXT group (`next`), so the wave keeps R*S loads in flight across groups
+//    instead of draining and restarting the memory pipe at every group boundary.  The refill is
+//    unconditional and branch-free (a branch would make hipcc's waitcnt pass merge the two paths
+//    and wait for the refill itself; two template copies in sibling branches get their common
+//    byte->float converts hoisted and spilled): after a wave's LAST group, `next_valid` = false
+//    degrades the refill to R*S loads of one and the same 16-byte piece (one L1-resident line),
+//    which nobody waits for.
 template <int R, int S, int PAT>
-__device__ __forceinline__ void group_dot(const u32x4 (&w)[R][S], const float *xv, int xvlen, int lane,
-                                          float (&out)[R])
+__device__ __forceinline__ void group_dot(u32x4 (&w)[R][S], const float *xv, int xvlen, int lane, float (&out)[R],
+                                          const uint8_t *__restrict__ next, size_t stride, int chunks, bool next_valid)
 {
     constexpr int NV = nvec<PAT, R>();
     constexpr int NI = S * NV;
+    const unsigned mask = next_valid ? 0xffffffffu : 0u;
+    const size_t nstride = next_valid ? stride : 0;
     float acc[R][4];
 #pragma unroll
     for (int r = 0; r < R; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
@@ -169,13 +193,31 @@ __device__ __forceinline__ void group_dot(const u32x4 (&w)[R][S], const float *x
             if (xsel<PAT>(r) == v) {
                 dot16(w[r][s], x[it & 1], acc[r]);
                 // pin the partial sums here: without it LLVM sinks all FMAs below all LDS reads and
-                // the whole staged vector becomes live at once (spills)
+                // the whole staged vector becomes live at once (spills); the sched barrier keeps the
+                // next row's 16 byte->float converts from being hoisted above this row's FMAs
                 asm volatile("" : "+v"(acc[r][0]), "+v"(acc[r][1]), "+v"(acc[r][2]), "+v"(acc[r][3]));
+                __builtin_amdgcn_sched_barrier(0);
             }
         __builtin_amdgcn_sched_barrier(0);
+        if (v == NV - 1) {
+            step_load<R, S>(w, s, next, nstride, chunks, lane, mask);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; r++) out[r] = wave_sum((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]));
+}
+
+// optional phase timeline (debug / tuning): lane 0 of every wave stamps the 100 MHz wall clock
+// into tl[((block * NW) + wave) * 8 + phase].  tl == nullptr in production.
+__device__ __forceinline__ void tl_stamp(unsigned long long *tl, int phase)
+{
+    if (tl) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = wall_clock64();
+        if ((threadIdx.x & 63) == 0) tl[((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 8 + phase] = t;
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -191,21 +233,21 @@ __device__ __forceinline__ void group_dot(const u32x4 (&w)[R][S], const float *x
 // LayerNorm statistics of a D-vector held E elements per thread (reference semantics: mean =
 // sum/D, variance over D-1, no epsilon -- rwkv.cu:40-57,412-450), in f64.
 template <int E>
-__device__ __forceinline__ void ln_stats(const double (&xl)[E], int D, double &mean, double &stdv, double *red)
+__device__ __forceinline__ void ln_stats(const double (&xl)[E], int D, double &mean, double &rstd, double *red)
 {
-    double s[1] = {0.0};
-#pragma unroll
-    for (int e = 0; e < E; e++) s[0] += (threadIdx.x + e * NT < D) ? xl[e] : 0.0;
-    block_sum<1>(s, red);
-    mean = s[0] / (double)D;
-    double q[1] = {0.0};
+    // one workgroup reduction of (sum, sum of squares) in f64; var = (sumsq - sum^2/D)/(D-1).
+    // (f64 leaves ~1e-13 relative after the cancellation for |mean| up to 1e2 sigma.)
+    double s[2] = {0.0, 0.0};
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const double d = xl[e] - mean;
-        q[0] += (threadIdx.x + e * NT < D) ? d * d : 0.0;
+        const double v = (threadIdx.x + e * NT < D) ? xl[e] : 0.0;
+        s[0] += v;
+        s[1] += v * v;
     }
-    block_sum<1>(q, red);
-    stdv = sqrt(q[0] / (double)(D - 1));
+    block_sum<2>(s, red);
+    mean = s[0] / (double)D;
+    const double var = (s[1] - s[0] * mean) / (double)(D - 1);
+    rstd = 1.0 / sqrt(var);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -277,23 +319,25 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
 #pragma unroll
         for (int q = 0; q < 3; q++) P[e][q] = a.pk[jj * 3 + q];
     }
-    // (2) weights of the first group
+    // (2) step 0 of the first group's weights.  Only one step: a wave that asks for more than the
+    // memory pipe accepts stalls AT ISSUE (in-order), and the prologue below would wait with it.
+    // Unconditional (a wave without a group re-reads a neighbour's rows): a branch around the loads
+    // would make hipcc's waitcnt pass assume the no-load path and drain the weights early.
     u32x4 w[3][S];
     int g = g0 + wave;
-    // unconditional (a wave without a group re-reads a neighbour's rows): a branch around the loads
-    // would make hipcc's waitcnt pass assume the no-load path and drain the weights early
-    group_load<3, S>(w, a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 3 * D, (size_t)D, chunks, lane);
+    const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 3 * D;
+    group_load<3, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
 
     // (3) LayerNorm, token-shift mix, pre-scale by the per-row quantisation scale, stage in LDS
-    double mean, stdv;
-    ln_stats<E>(xl, D, mean, stdv, red);
+    double mean, rstd;
+    ln_stats<E>(xl, D, mean, rstd, red);
     double Ssum[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int j = threadIdx.x + e * NT;
         float xk = 0.f, xvv = 0.f, xr = 0.f;
         if (j < D) {
-            const double xx = (double)P[e][0][0] * ((xl[e] - mean) / stdv) + (double)P[e][0][1];
+            const double xx = (double)P[e][0][0] * ((xl[e] - mean) * rstd) + (double)P[e][0][1];
             const double prev = pv[e];
             const double mk = (double)P[e][0][2], mv = (double)P[e][0][3], mr = (double)P[e][1][0];
             const float fk = (float)(mk * xx + (1.0 - mk) * prev);   // rwkv.cu:382-384: rounded to f32
@@ -306,27 +350,23 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
         const int p = xperm(j);
         xv[p] = xk; xv[XV + p] = xvv; xv[2 * XV + p] = xr;
     }
-    block_sum<3>(Ssum, red);
+    group_load<3, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // remaining steps of the first group
+    __syncthreads();                                                       // staged vectors visible
 
-    while (g < g1) {
+    for (; g < g1; g += NW) {
         float out[3];
-        group_dot<3, S, PAT_PER_ROW>(w, xv, XV, lane, out);
-        if (lane == 0) {
-            stash[(g - g0) * 3 + 0] = out[0] + (float)Ssum[0];
-            stash[(g - g0) * 3 + 1] = out[1] + (float)Ssum[1];
-            stash[(g - g0) * 3 + 2] = out[2] + (float)Ssum[2];
-        }
-        g += NW;
-        if (g >= g1) break;
-        group_load<3, S>(w, a.w + (size_t)g * 3 * D, (size_t)D, chunks, lane);
+        const bool nv = g + NW < g1;
+        group_dot<3, S, PAT_PER_ROW>(w, xv, XV, lane, out, a.w + (size_t)(nv ? g + NW : 0) * 3 * D, (size_t)D, chunks, nv);
+        if (lane == 0) { stash[(g - g0) * 3 + 0] = out[0]; stash[(g - g0) * 3 + 1] = out[1]; stash[(g - g0) * 3 + 2] = out[2]; }
     }
-    __syncthreads();
+    block_sum<3>(Ssum, red);   // offset terms: only needed by the epilogue (also the barrier before it)
 
     // WKV recurrence + receptance gate, one lane per channel (rwkv.cu:242-255)
     double part[1] = {0.0};
     if ((int)threadIdx.x < g1 - g0) {
         const int i = g0 + threadIdx.x;
-        const float k = stash[threadIdx.x * 3 + 0], v = stash[threadIdx.x * 3 + 1], r = stash[threadIdx.x * 3 + 2];
+        const float k = stash[threadIdx.x * 3 + 0] + (float)Ssum[0], v = stash[threadIdx.x * 3 + 1] + (float)Ssum[1],
+                    r = stash[threadIdx.x * 3 + 2] + (float)Ssum[2];
         const double aa = a.saa[so + i], bb = a.sbb[so + i];
         const double vv = (double)v;
         const double e1 = exp(a.uw[i] + (double)k);
@@ -380,20 +420,24 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
 
     u32x4 w[R][S];
     int g = g0 + wave;
-    {
-        int row = (g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * R;
+    auto rowbase = [&](int gg) {
+        int row = gg * R;
         if (row > D - R) row = D - R;
-        group_load<R, S>(w, a.w + (size_t)row * D, (size_t)D, chunks, lane);
-    }
+        return a.w + (size_t)row * D;
+    };
+    const uint8_t *wb = rowbase(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0));
+    group_load<R, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
 #pragma unroll
     for (int e = 0; e < E; e++) { const int j = threadIdx.x + e * NT; xv[xperm(j)] = (j < D) ? yl[e] : 0.f; }
     if ((int)threadIdx.x >= a.n_part) Ssum[0] = 0.0;
+    group_load<R, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);
     block_sum<1>(Ssum, red);
     const float Sf = (float)Ssum[0];
 
-    while (g < g1) {
+    for (; g < g1; g += NW) {
         float out[R];
-        group_dot<R, S, PAT_SHARED>(w, xv, XV, lane, out);
+        const bool nv = g + NW < g1;
+        group_dot<R, S, PAT_SHARED>(w, xv, XV, lane, out, rowbase(nv ? g + NW : 0), (size_t)D, chunks, nv);
         int row0 = g * R;
         const int shift = (row0 > D - R) ? row0 - (D - R) : 0;   // last group may overlap the previous one
         row0 -= shift;
@@ -406,11 +450,6 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
                 a.sxy[so + i] = a.xx_buf[i];                         // mixatt's state write (:385), deferred
             }
         }
-        g += NW;
-        if (g >= g1) break;
-        int row = g * R;
-        if (row > D - R) row = D - R;
-        group_load<R, S>(w, a.w + (size_t)row * D, (size_t)D, chunks, lane);
     }
 }
 
@@ -428,6 +467,7 @@ struct FfnRKArgs {
     double *partS;                    // [gridDim.x]
     const Ctl *ctl;
     int D;
+    unsigned long long *tl;           // optional phase timeline (see tl_stamp)
 };
 
 // ln2 -> mix -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573)
@@ -445,9 +485,14 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
+    tl_stamp(a.tl, 0);
 
     double xl[E], pv[E];
     f32x4 P[E][2];
+#ifdef RWKV_EXP_NOPROLOGUE   // timing experiment only: no prologue traffic, constant staged vectors
+#pragma unroll
+    for (int e = 0; e < E; e++) { xl[e] = 1.0 + e; pv[e] = 0.5; P[e][0] = f32x4{1.f, 0.f, 0.5f, 0.5f}; P[e][1] = f32x4{0.01f, 0.f, 0.01f, 0.f}; }
+#else
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int j = threadIdx.x + e * NT, jj = j < D ? j : D - 1;
@@ -456,19 +501,32 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
         P[e][0] = a.pk[jj * 2];
         P[e][1] = a.pk[jj * 2 + 1];
     }
+#endif
     u32x4 w[5][S];
     int g = g0 + wave;
-    group_load<5, S>(w, a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 5 * D, (size_t)D, chunks, lane);
+#ifdef RWKV_EXP_SAMEROWS   // timing experiment only: every wave streams group 0 (cache resident) -> compute-only time
+#define RWKV_EXP_G(gg) 0
+#else
+#define RWKV_EXP_G(gg) (gg)
+#endif
+    const uint8_t *wb = a.w + (size_t)RWKV_EXP_G(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 5 * D;
+    group_load<5, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
+    tl_stamp(a.tl, 1);
 
-    double mean, stdv;
-    ln_stats<E>(xl, D, mean, stdv, red);
+    double mean, rstd;
+#ifdef RWKV_EXP_NOPROLOGUE
+    mean = 0.25; rstd = 0.9;
+#else
+    ln_stats<E>(xl, D, mean, rstd, red);
+#endif
+    tl_stamp(a.tl, 2);
     double Ssum[2] = {0.0, 0.0};
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int j = threadIdx.x + e * NT;
         float xk = 0.f, xr = 0.f;
         if (j < D) {
-            const double xx = (double)P[e][0][0] * ((xl[e] - mean) / stdv) + (double)P[e][0][1];
+            const double xx = (double)P[e][0][0] * ((xl[e] - mean) * rstd) + (double)P[e][0][1];
             const double prev = pv[e];
             const double mk = (double)P[e][0][2], mr = (double)P[e][0][3];
             const float fk = (float)(mk * xx + (1.0 - mk) * prev);   // f64 mix (:341-342), f32 cast in the GEMV (:290)
@@ -480,24 +538,27 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
         const int p = xperm(j);
         xv[p] = xk; xv[XV + p] = xr;
     }
-    block_sum<2>(Ssum, red);
+    group_load<5, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);
+    __syncthreads();
+    tl_stamp(a.tl, 3);
+    bool first_ = true;
 
-    while (g < g1) {
+    for (; g < g1; g += NW) {
         float out[5];
-        group_dot<5, S, PAT_FFN_RK>(w, xv, XV, lane, out);
+        const bool nv = g + NW < g1;
+        group_dot<5, S, PAT_FFN_RK>(w, xv, XV, lane, out, a.w + (size_t)RWKV_EXP_G(nv ? g + NW : 0) * 5 * D, (size_t)D, chunks, nv);
 #pragma unroll
         for (int r = 0; r < 5; r++)
-            if (lane == r) stash[(g - g0) * 5 + r] = out[r] + (float)Ssum[r < 4 ? 0 : 1];
-        g += NW;
-        if (g >= g1) break;
-        group_load<5, S>(w, a.w + (size_t)g * 5 * D, (size_t)D, chunks, lane);
+            if (lane == r) stash[(g - g0) * 5 + r] = out[r];
+        if (first_) { tl_stamp(a.tl, 4); first_ = false; }
     }
-    __syncthreads();
+    block_sum<2>(Ssum, red);   // offset terms: only needed by the epilogue (also the barrier before it)
+    tl_stamp(a.tl, 5);
 
     double part[1] = {0.0};
     for (int t = threadIdx.x; t < 5 * (g1 - g0); t += NT) {
         const int q = t % 5, i = g0 + t / 5;
-        const float val = stash[t];
+        const float val = stash[t] + (float)Ssum[q < 4 ? 0 : 1];
         if (q < 4) {
             float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
             h = h * h;
@@ -510,6 +571,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     }
     block_sum<1>(part, red);
     if (threadIdx.x == 0) a.partS[blockIdx.x] = part[0];
+    tl_stamp(a.tl, 6);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -551,27 +613,27 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
 
     u32x4 w[4][S];
     int g = g0 + wave;
-    group_load<4, S>(w, a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 4 * D, (size_t)D, chunks, lane);
+    const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 4 * D;
+    group_load<4, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
 
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int e = 0; e < E; e++) { const int j = threadIdx.x + e * NT; xv[q * XV + xperm(j)] = (j < D) ? hl[q][e] : 0.f; }
     if ((int)threadIdx.x >= a.n_part) Ssum[0] = 0.0;
+    group_load<4, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);
     block_sum<1>(Ssum, red);
     const float Sf = (float)Ssum[0];
 
-    while (g < g1) {
+    for (; g < g1; g += NW) {
         float out[4];
-        group_dot<4, S, PAT_PER_ROW>(w, xv, XV, lane, out);
+        const bool nv = g + NW < g1;
+        group_dot<4, S, PAT_PER_ROW>(w, xv, XV, lane, out, a.w + (size_t)(nv ? g + NW : 0) * 4 * D, (size_t)D, chunks, nv);
         if (lane == 0) {
             const float v = ((out[0] + out[1]) + (out[2] + out[3])) + Sf;
             a.x[g] = a.x[g] + (double)(v * a.rgate[g]);   // blockout, rwkv.cu:407 (f32 product)
             a.sdd[so + g] = a.xx_buf[g];                   // mixffn's state write (:344), deferred
         }
-        g += NW;
-        if (g >= g1) break;
-        group_load<4, S>(w, a.w + (size_t)g * 4 * D, (size_t)D, chunks, lane);
     }
 }
 
@@ -616,34 +678,38 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
     }
     u32x4 w[R][S];
     int g = g0 + wave;
-    {
-        int row = (g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * R;
+    auto rowbase = [&](int gg) {
+        int row = gg * R;
         if (row > V - R) row = V - R;
-        group_load<R, S>(w, a.w + (size_t)row * D, (size_t)D, chunks, lane);
-    }
-    double mean, stdv;
-    ln_stats<E>(xl, D, mean, stdv, red);
+        return a.w + (size_t)row * D;
+    };
+    const uint8_t *wb = rowbase(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0));
+    group_load<R, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
+    double mean, rstd;
+    ln_stats<E>(xl, D, mean, rstd, red);
     double Ssum[1] = {0.0};
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int j = threadIdx.x + e * NT;
         float xs = 0.f;
         if (j < D) {
-            const float f = (float)((double)P[e][0] * ((xl[e] - mean) / stdv) + (double)P[e][1]);
+            const float f = (float)((double)P[e][0] * ((xl[e] - mean) * rstd) + (double)P[e][1]);
             xs = f * P[e][2];
             Ssum[0] += (double)(f * P[e][3]);
         }
         xv[xperm(j)] = xs;
     }
+    group_load<R, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);
     block_sum<1>(Ssum, red);
     const float Sf = (float)Ssum[0];
     float *lg = a.logits + (size_t)a.ctl->out_row * V;
 
     float best = -INFINITY;
     unsigned besti = 0xffffffffu;
-    while (g < g1) {
+    for (; g < g1; g += NW) {
         float out[R];
-        group_dot<R, S, PAT_SHARED>(w, xv, XV, lane, out);
+        const bool nv = g + NW < g1;
+        group_dot<R, S, PAT_SHARED>(w, xv, XV, lane, out, rowbase(nv ? g + NW : 0), (size_t)D, chunks, nv);
         int row0 = g * R;
         const int shift = (row0 > V - R) ? row0 - (V - R) : 0;
         row0 -= shift;
@@ -654,11 +720,6 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
             if (lane == r && r >= shift) lg[i] = val;
             if (i != 0 && (val > best || (val == best && (unsigned)i < besti))) { best = val; besti = (unsigned)i; }
         }
-        g += NW;
-        if (g >= g1) break;
-        int row = g * R;
-        if (row > V - R) row = V - R;
-        group_load<R, S>(w, a.w + (size_t)row * D, (size_t)D, chunks, lane);
     }
     if (lane == 0) { bval[wave] = best; bidx[wave] = besti; }
     __syncthreads();
@@ -740,15 +801,15 @@ __global__ __launch_bounds__(NT) void k_mm8(Mm8Args a)
         u32x4 w[R][S];
         float out[R];
         if (QUARTERS) {
-            group_load<R, S>(w, a.w_t + (size_t)g * a.N, (size_t)Dq, chunks, lane);
-            group_dot<R, S, PAT_PER_ROW>(w, xv, XV, lane, out);
+            group_load<R, S, 0, S>(w, a.w_t + (size_t)g * a.N, (size_t)Dq, chunks, lane);
+            group_dot<R, S, PAT_PER_ROW>(w, xv, XV, lane, out, a.w_t, 0, chunks, false);
             if (lane == 0) a.y[g] = ((out[0] + out[1]) + (out[2] + out[3])) + Sf;
         } else {
             int row0 = g * R;
             const int shift = (row0 > M - R) ? row0 - (M - R) : 0;
             row0 -= shift;
-            group_load<R, S>(w, a.w_t + (size_t)row0 * a.N, (size_t)a.N, chunks, lane);
-            group_dot<R, S, PAT_SHARED>(w, xv, XV, lane, out);
+            group_load<R, S, 0, S>(w, a.w_t + (size_t)row0 * a.N, (size_t)a.N, chunks, lane);
+            group_dot<R, S, PAT_SHARED>(w, xv, XV, lane, out, a.w_t, 0, chunks, false);
 #pragma unroll
             for (int r = 0; r < R; r++)
                 if (lane == r && r >= shift) a.y[row0 + r] = out[r] + Sf;
