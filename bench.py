@@ -99,15 +99,35 @@ def main():
     tok_s = args.steps * world / dt
     B_tok = m.bytes_per_token()
 
-    # ---- per-kernel HIP-event timing on the engine's stream (same stream, same token chain) ----
+    # ---- drop-in mode: host-authoritative state, uploaded/downloaded every token (rwkv.h:353,372) ----
+    drop_in = None
+    if rank == 0:
+        m.resident = False
+        m.pull_state(1)
+        n_di = min(64, args.steps)
+        t0 = time.perf_counter()
+        tk = int(ids[-1])
+        for _ in range(n_di):
+            lg = m.forward(tk)
+            tk = int(np.argmax(lg[1:mf.VOCAB])) + 1
+        drop_in = dict(tokens_per_s=round(n_di / (time.perf_counter() - t0), 2),
+                                    note="host state authoritative: 5xLxD f64 up + down and logits down per token (PCIe-inclusive)")
+        m.resident = True
+
+    # ---- per-kernel HIP-event timing on the engine's stream (the stream the kernels are launched on) ----
+    # (a) one event pair per launch of an eager replay of the token chain (includes ~2.5 us of event
+    #     bracketing per launch); (b) ONE event pair around a batch of all L x reps launches of a class:
+    #     the per-launch duration quoted in `roofline`, comparable with rocprofv3's kernel durations.
     prof = m.profile_token(token=int(ids[-1]), reps=args.profile_reps)
     per_launch = {}
     for p in prof:
         n = p["reps"] * p["launches_per_token"]
         us = 1e3 * p["ms_total"] / n if n else 0.0
-        per_launch[p["name"]] = dict(us=us, bytes=p["bytes_per_launch"],
-                                     gbps=(p["bytes_per_launch"] / (us * 1e-6) / 1e9) if us > 0 else 0.0,
-                                     launches_per_token=p["launches_per_token"])
+        per_launch[p["name"]] = dict(us_event_pair=us, bytes=p["bytes_per_launch"], launches_per_token=p["launches_per_token"])
+    for p in m.profile_batched(token=int(ids[-1]), reps=max(1, args.profile_reps // 4)):
+        d = per_launch[p["name"]]
+        d["us"] = p["us"]
+        d["gbps"] = (d["bytes"] / (p["us"] * 1e-6) / 1e9) if p["us"] > 0 else 0.0
     # dominant kernel = the class with the most device time per token
     dom = max((k for k in per_launch if per_launch[k]["bytes"] > 0 and k != "embed_ln0"),
               key=lambda k: per_launch[k]["us"] * per_launch[k]["launches_per_token"])
@@ -115,8 +135,9 @@ def main():
                 unit="GB/s", frac=round(per_launch[dom]["gbps"] / HBM_PEAK_GBPS, 4),
                 launch_us=round(per_launch[dom]["us"], 3), bytes_per_launch=per_launch[dom]["bytes"],
                 traffic=None,
-                method="hipEvent pairs around every launch of an eager replay of the token chain on the engine stream, "
-                       f"{args.profile_reps} tokens, right after the timed region")
+                method="algorithmic uint8 weight bytes of one launch / average launch duration; duration = one hipEvent pair "
+                       "around a batch of back-to-back launches of the kernel (all layers x reps) on the engine stream, "
+                       "right after the timed region")
     traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # filled from rocprofv3 --pmc passes (see profiles/)
     if os.path.exists(traffic_file):
         try:
@@ -128,7 +149,7 @@ def main():
         metric="tokens/sec single-stream RWKV-4 uint8 greedy decode",
         value=round(tok_s, 2), unit="tokens/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
         ms_per_step=round(1e3 * dt / args.steps, 5), higher_is_better=True, scaling="weak",
-        vs_baseline=None, dtype="u8 weights x f32 activations, f32 accumulate, f64 state", data="synthetic",
+        vs_baseline=None, dtype="u8 weights x 24-bit fixed-point activations, exact u32 accumulate (v_dot4_u32_u8); f32/f64 epilogues, f64 state", data="synthetic",
         config=dict(workload=f"RWKV-4-Raven-{args.model} uint8 single-stream greedy decode "
                              f"(L={L}, D={D}, V={mf.VOCAB}), 32-token prompt then {args.steps}-token continuation, "
                              "device-resident state",
@@ -137,23 +158,13 @@ def main():
         roofline=roof,
         end_to_end=dict(achieved_GBps=round(B_tok * tok_s / world / 1e9, 1),
                         frac_of_8TBps=round(B_tok * tok_s / world / 1e9 / HBM_PEAK_GBPS, 4)),
-        kernels={k: dict(us=round(v["us"], 3), GBps=round(v["gbps"], 1)) for k, v in per_launch.items()},
+        kernels={k: dict(us=round(v["us"], 3), GBps=round(v["gbps"], 1), us_event_pair=round(v["us_event_pair"], 3))
+                 for k, v in per_launch.items()},
         load_s=round(load_s, 2),
     )
 
-    # ---- drop-in mode: host-authoritative state, uploaded/downloaded every token (rwkv.h:353,372) ----
-    if rank == 0:
-        m.resident = False
-        m.pull_state(1)
-        n_di = min(64, args.steps)
-        t0 = time.perf_counter()
-        tk = int(ids[-1])
-        for _ in range(n_di):
-            lg = m.forward(tk)
-            tk = int(np.argmax(lg[1:mf.VOCAB])) + 1
-        line["drop_in_mode"] = dict(tokens_per_s=round(n_di / (time.perf_counter() - t0), 2),
-                                    note="host state authoritative: 5xLxD f64 up + down and logits down per token (PCIe-inclusive)")
-        m.resident = True
+    if drop_in is not None:
+        line["drop_in_mode"] = drop_in
 
     # ---- CPU baseline: the oracle (CPU restatement of rwkv.cu:493-593) on this box's host cores ----
     if rank == 0 and not args.no_cpu_baseline:

@@ -113,6 +113,12 @@ uint64_t rwkv_bytes_per_token(const rwkv_ctx *ctx);
 int rwkv_profile_token(rwkv_ctx *ctx, uint64_t token, int reps, double *ms, uint64_t *bytes,
                        uint32_t *launches);
 
+/* Like rwkv_profile_token, but ONE event pair brackets a batch of `reps` x (launches per token) back-to-back
+ * launches of each class, so the per-launch figure is not inflated by per-bracket event overhead and is
+ * comparable with rocprofv3 kernel durations.  ms[c] = total ms of the batch, n[c] = launches in it.
+ * Leaves the recurrent state zeroed (the batches run the kernels out of token order). */
+int rwkv_profile_batched(rwkv_ctx *ctx, uint64_t token, int reps, double *ms, uint32_t *n);
+
 /* Tuning aid: run one eager token with phase timestamps enabled in the middle layer's ffn r+k
  * kernel; out receives grid*8*8 stamps of the 100 MHz device wall clock ([workgroup][wave][phase]). */
 int rwkv_debug_timeline(rwkv_ctx *ctx, uint64_t token, unsigned long long *out, uint64_t cap);

@@ -96,6 +96,7 @@ struct rwkv_ctx {
     double *uw = nullptr, *ew = nullptr;
     f32x4 *pk_att = nullptr, *pk_ffn = nullptr, *pk_head = nullptr;   // packed prologue parameter tables
     uint8_t *w_kvr = nullptr, *w_att = nullptr, *w_frk = nullptr, *w_fv = nullptr, *w_head = nullptr;
+    unsigned *rs_kvr = nullptr, *rs_att = nullptr, *rs_frk = nullptr, *rs_fv = nullptr, *rs_head = nullptr;   // row sums
     // state + scratch (device)
     double *state[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double *x = nullptr, *xx1 = nullptr, *xx2 = nullptr, *partA = nullptr, *partF = nullptr;
@@ -122,11 +123,12 @@ template <typename T> int dalloc(rwkv_ctx *c, T **p, size_t count)
     return 0;
 }
 
-size_t smem_att(int S, int gpb) { return RED_BYTES + 3 * (size_t)S * 4096 + (size_t)gpb * 3 * 4; }
-size_t smem_attout(int S) { return RED_BYTES + (size_t)S * 4096; }
-size_t smem_frk(int S, int gpb) { return RED_BYTES + 2 * (size_t)S * 4096 + (size_t)gpb * 5 * 4; }
-size_t smem_fv(int S) { return RED_BYTES + 4 * (size_t)S * 4096; }
-size_t smem_head(int S) { return RED_BYTES + (size_t)S * 4096 + NW * 8; }
+// one staged vector = 3 limb planes of S x 1 KiB
+size_t smem_att(int S, int gpb) { return RED_BYTES + 3 * (size_t)S * 3072 + (size_t)gpb * 3 * 4; }
+size_t smem_attout(int S) { return RED_BYTES + (size_t)S * 3072; }
+size_t smem_frk(int S, int gpb) { return RED_BYTES + 2 * (size_t)S * 3072 + (size_t)gpb * 5 * 4; }
+size_t smem_fv(int S) { return RED_BYTES + 4 * (size_t)S * 3072; }
+size_t smem_head(int S) { return RED_BYTES + (size_t)S * 3072 + NW * 8; }
 
 constexpr int ATTOUT_R = 2;
 
@@ -147,67 +149,78 @@ template <typename K> int allow_smem(K kernel, size_t bytes)
 
 int gpb_of(const rwkv_ctx *c) { return (int)((c->D + c->grid - 1) / c->grid) + 1; }
 
-// enqueue the kernels of one token on the context's stream.  ev: optional array of
-// (4L + 4) events recorded before each launch and after the last (profiling).
-int enqueue_token(rwkv_ctx *c, bool with_argmax, hipEvent_t *ev)
+// ---- one launch helper per kernel class (0 embed, 1 att, 2 att_out, 3 ffn_rk, 4 ffn_v, 5 head, 6 argmax) ----
+void launch_class(rwkv_ctx *c, int cls, uint64_t l)
 {
     const int D = (int)c->D, S = c->S, grid = c->grid;
     const uint64_t L = c->L;
-    const size_t LD = (size_t)L * D;
+    const size_t LD = (size_t)L * D, lo = (size_t)l * D;
     const int gpb = gpb_of(c);
-    int evi = 0;
-#define EV() do { if (ev) HIPCHK(hipEventRecord(ev[evi++], c->stream)); } while (0)
-
-    EV();
-    EmbedArgs ea{c->embed, c->ln, c->x, c->ctl, D};
-    hipLaunchKernelGGL(k_embed_ln0, dim3(1), dim3(NT), 0, c->stream, ea);
-
-    for (uint64_t l = 0; l < L; l++) {
-        const size_t lo = (size_t)l * D;
+    switch (cls) {
+    case 0: {
+        EmbedArgs ea{c->embed, c->ln, c->x, c->ctl, D};
+        k_embed_ln0<<<dim3(1), dim3(NT), 0, c->stream>>>(ea);
+    } break;
+    case 1: {
         AttArgs aa;
         aa.x = c->x; aa.pk = c->pk_att + lo * 3;
-        aa.w = c->w_kvr + (size_t)l * 3 * D * D;
+        aa.w = c->w_kvr + (size_t)l * 3 * D * D; aa.rs = c->rs_kvr + lo * 3;
         aa.uw = c->uw + lo; aa.ew = c->ew + lo;
         aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
         aa.sxy = c->state[0] + lo; aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
         aa.slot_stride = LD; aa.xx_buf = c->xx1; aa.ybuf = c->ybuf; aa.partS = c->partA;
         aa.ctl = c->ctl; aa.D = D;
-        EV();
         DISPATCH_S(S, k_att<S_><<<dim3(grid), dim3(NT), smem_att(S, gpb), c->stream>>>(aa));
-
+    } break;
+    case 2: {
         AttOutArgs ao;
-        ao.w = c->w_att + (size_t)l * D * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.n_part = grid;
+        ao.w = c->w_att + (size_t)l * D * D; ao.rs = c->rs_att + lo; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.n_part = grid;
         ao.x = c->x; ao.xx_buf = c->xx1; ao.sxy = c->state[0] + lo; ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D;
-        EV();
         DISPATCH_S(S, k_attout<S_, ATTOUT_R><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
-
+    } break;
+    case 3: {
         FfnRKArgs fa;
         fa.x = c->x; fa.pk = c->pk_ffn + lo * 2;
-        fa.w = c->w_frk + (size_t)l * 5 * D * D;
+        fa.w = c->w_frk + (size_t)l * 5 * D * D; fa.rs = c->rs_frk + lo * 5;
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.sdd = c->state[4] + lo; fa.slot_stride = LD; fa.xx_buf = c->xx2;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.ctl = c->ctl; fa.D = D;
         fa.tl = (c->tl_on && l == L / 2) ? c->tl : nullptr;
-        EV();
         DISPATCH_S(S, k_ffn_rk<S_><<<dim3(grid), dim3(NT), smem_frk(S, gpb), c->stream>>>(fa));
-
+    } break;
+    case 4: {
         FfnVArgs fv;
-        fv.w = c->w_fv + (size_t)l * 4 * D * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.n_part = grid;
+        fv.w = c->w_fv + (size_t)l * 4 * D * D; fv.rs = c->rs_fv + lo; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.n_part = grid;
         fv.rgate = c->rgate; fv.x = c->x; fv.xx_buf = c->xx2; fv.sdd = c->state[4] + lo;
         fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D;
-        EV();
         DISPATCH_S(S, k_ffnv<S_><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
+    } break;
+    case 5: {
+        HeadArgs ha;
+        ha.x = c->x; ha.pk = c->pk_head; ha.w = c->w_head; ha.rs = c->rs_head; ha.logits = c->logits;
+        ha.blk_val = c->blk_val; ha.blk_idx = c->blk_idx; ha.ctl = c->ctl; ha.D = D;
+        DISPATCH_S(S, k_head<S_><<<dim3(grid), dim3(NT), smem_head(S), c->stream>>>(ha));
+    } break;
+    default:
+        k_argmax_finish<<<dim3(1), dim3(64), 0, c->stream>>>(c->blk_val, c->blk_idx, grid, c->ctl, c->gen, c->gen_cap);
     }
+}
 
-    HeadArgs ha;
-    ha.x = c->x; ha.pk = c->pk_head; ha.w = c->w_head; ha.logits = c->logits;
-    ha.blk_val = c->blk_val; ha.blk_idx = c->blk_idx; ha.ctl = c->ctl; ha.D = D;
+// enqueue the kernels of one token on the context's stream.  ev: optional array of
+// (4L + 4) events recorded before each launch and after the last (profiling).
+int enqueue_token(rwkv_ctx *c, bool with_argmax, hipEvent_t *ev)
+{
+    const uint64_t L = c->L;
+    int evi = 0;
+#define EV() do { if (ev) HIPCHK(hipEventRecord(ev[evi++], c->stream)); } while (0)
     EV();
-    DISPATCH_S(S, k_head<S_><<<dim3(grid), dim3(NT), smem_head(S), c->stream>>>(ha));
+    launch_class(c, 0, 0);
+    for (uint64_t l = 0; l < L; l++)
+        for (int cls = 1; cls <= 4; cls++) { EV(); launch_class(c, cls, l); }
     EV();
-    if (with_argmax)
-        hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(64), 0, c->stream, c->blk_val, c->blk_idx, grid,
-                           c->ctl, c->gen, c->gen_cap);
+    launch_class(c, 5, 0);
+    EV();
+    if (with_argmax) launch_class(c, 6, 0);
     EV();
 #undef EV
     HIPCHK(hipGetLastError());
@@ -350,10 +363,27 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         if (!rc) rc = retile(c, src, FFNV, l, 4 * D, D, c->w_fv + l * 4 * D * D, 1, 1, 0, staging);
     }
     if (!rc) rc = retile(c, src, HEAD, 0, D, V, c->w_head, 1, 1, 0, staging);
+    // row sums of the re-tiled matrices (the 2^23 offset of the activation limbs is removed with them)
+    if (!rc) rc = dalloc(c, &c->rs_kvr, L * 3 * D);
+    if (!rc) rc = dalloc(c, &c->rs_att, L * D);
+    if (!rc) rc = dalloc(c, &c->rs_frk, L * 5 * D);
+    if (!rc) rc = dalloc(c, &c->rs_fv, L * D);
+    if (!rc) rc = dalloc(c, &c->rs_head, V);
+    if (!rc) {
+        auto rowsum = [&](const uint8_t *w, unsigned *rs, uint64_t rows, uint64_t N) {
+            k_rowsum<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream>>>(w, rs, (size_t)rows, (int)N);
+        };
+        rowsum(c->w_kvr, c->rs_kvr, L * 3 * D, D);
+        rowsum(c->w_att, c->rs_att, L * D, D);
+        rowsum(c->w_frk, c->rs_frk, L * 5 * D, D);
+        rowsum(c->w_fv, c->rs_fv, L * D, 4 * D);
+        rowsum(c->w_head, c->rs_head, V, D);
+    }
     hipError_t se = hipStreamSynchronize(c->stream);
     if (staging) (void)hipFree(staging);
     if (rc) return rc;
     HIPCHK(se);
+    HIPCHK(hipGetLastError());
 
     // state (zero, as `new RWKVState` does: rwkv.h:163-170) and scratch
     for (int s = 0; s < 5; s++) {
@@ -603,6 +633,43 @@ int rwkv_profile_token(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint64
     return rc;
 }
 
+// Per-class launch duration from ONE event pair around a batch of back-to-back launches of that
+// class (all L layers x reps): amortises the ~2.5 us a hipEvent pair adds per bracket, so the
+// figure is comparable with rocprofv3's kernel durations.  ms[c] = total ms, n[c] = launches.
+int rwkv_profile_batched(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint32_t *n)
+{
+    if (!c || !ms || !n) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (token >= RWKV_VOCAB || reps <= 0) return fail(RWKV_E_ARG, "bad token / reps");
+    HIPCHK(hipSetDevice(c->device));
+    c->h_ctl[0].token = token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
+    HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+    int rc = enqueue_token(c, true, nullptr);   // valid inputs for every class
+    if (rc) return rc;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    for (int cls = 0; cls < RWKV_N_KCLASS; cls++) {
+        const bool per_layer = cls >= 1 && cls <= 4;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipEventRecord(a, c->stream));
+        uint32_t cnt = 0;
+        for (int r = 0; r < reps; r++)
+            for (uint64_t l = 0; l < (per_layer ? c->L : 1); l++) { launch_class(c, cls, l); cnt++; }
+        HIPCHK(hipEventRecord(b, c->stream));
+        HIPCHK(hipEventSynchronize(b));
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, a, b));
+        ms[cls] = (double)t; n[cls] = cnt;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    HIPCHK(hipGetLastError());
+    // the batches above advanced the recurrent state with a scrambled schedule: reset it
+    for (int st = 0; st < 5; st++)
+        HIPCHK(hipMemsetAsync(c->state[st], 0, c->maxT * c->L * c->D * sizeof(double), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // debug: run one eager token with the phase timeline of the middle layer's ffn_rk kernel enabled;
 // out receives grid*NW*8 100-MHz wall-clock stamps (see tl_stamp in kernels.hip.h)
 int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, uint64_t cap)
@@ -637,9 +704,12 @@ int rwkv_mm8_one(rwkv_ctx *c, uint64_t N, uint64_t M, const float *x, const uint
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&wt), N * M));
     dim3 rg((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
     hipLaunchKernelGGL(k_retile, rg, dim3(256), 0, c->stream, w, wt, (int)N, (int)M, 1, 1, 0);
-    Mm8Args a{wt, x, r, o, y, (int)N, (int)M};
+    unsigned *rsum = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&rsum), M * sizeof(unsigned)) != hipSuccess) { (void)hipFree(wt); return fail(RWKV_E_DEVICE, "hipMalloc failed"); }
+    k_rowsum<<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, c->stream>>>(wt, rsum, (size_t)M, (int)N);
+    Mm8Args a{wt, rsum, x, r, o, y, (int)N, (int)M};
     const int S = (int)(((quarters ? N / 4 : N) + 1023) / 1024);
-    const size_t smem = RED_BYTES + (size_t)(quarters ? 4 : 1) * S * 4096;
+    const size_t smem = RED_BYTES + (size_t)(quarters ? 4 : 1) * S * 3072;
     int rc = 0;
     if (quarters) {
         DISPATCH_S(S, rc = allow_smem(k_mm8<S_, true>, smem));
@@ -651,6 +721,7 @@ int rwkv_mm8_one(rwkv_ctx *c, uint64_t N, uint64_t M, const float *x, const uint
     hipError_t e1 = hipGetLastError();
     hipError_t e2 = hipStreamSynchronize(c->stream);
     (void)hipFree(wt);
+    (void)hipFree(rsum);
     if (rc) return rc;
     HIPCHK(e1);
     HIPCHK(e2);

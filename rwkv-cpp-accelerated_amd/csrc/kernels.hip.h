@@ -10,21 +10,27 @@
 //   k_ffnv        rwkv.cu:574-577   ffn_v dequant-GEMV, x += v * sigmoid(r) (+ commits state dd)
 //   k_head        rwkv.cu:585-589   ln_out + head dequant-GEMV -> logits (+ per-block argmax)
 //
-// Design (DESIGN.md has the long form):
+// Design (DESIGN.md has the long form and the measurements behind each choice):
 //  * The uint8 matrices are re-tiled at load into ROW-PER-OUTPUT order (w_t[k][j], j contiguous),
 //    so one wavefront owns whole output rows: each lane streams 16-byte pieces of the row with
-//    non-temporal global_load_dwordx4 (1 KiB per wave-instruction, every 128-B line used once),
-//    accumulates 4 independent f32 FMA chains and the row is finished by a 64-lane shuffle
-//    reduction.  No float atomics, no pre-zeroed accumulators, no cross-workgroup reduction:
-//    results are deterministic and every epilogue (WKV, sigmoid, relu^2, residual) fuses into
-//    the kernel that finished the row.
-//  * sum_j x_j (u_jk r_j + o_j) = sum_j (x_j r_j) u_jk + sum_j x_j o_j : the activation vector is
-//    pre-multiplied by the per-row scale once per workgroup and staged in LDS (chunk-interleaved
-//    so every ds_read_b128 is conflict-free); the offset term is one scalar per vector.
+//    non-temporal global_load_dwordx4 (1 KiB per wave-instruction, every 128-B line used once)
+//    and the row is finished by a 64-lane shuffle reduction.  No float atomics, no pre-zeroed
+//    accumulators, no cross-workgroup reduction: results are deterministic and every epilogue
+//    (WKV, sigmoid, relu^2, residual) fuses into the kernel that finished the row.
+//  * sum_j x_j (u_jk r_j + o_j) = sum_j (x_j r_j) u_jk + sum_j x_j o_j.  The first term is an
+//    integer contraction: the pre-scaled activation vector is quantised ONCE per workgroup to
+//    24-bit fixed point (3 unsigned byte limbs, scale = max|.|/8388000) and staged in LDS, and
+//    the u8 x u8 products run on v_dot4_u32_u8 (4 MACs per lane-instruction, exact u32
+//    accumulation, no byte->float converts).  Measured on MI355X the f32 formulation
+//    (v_cvt_f32_ubyteN + v_fma_f32 per weight byte) cost as much VALU time as the HBM stream
+//    itself; the limb form needs 12 instructions per 16 weight bytes instead of 32 and its
+//    rounding error (<= 1.2e-7 max|x|) is below that of an f32 FMA chain.  The offset term is
+//    one scalar per vector.
 //  * Every GEMV needs its complete input vector, so LayerNorm / token-shift prologues are
-//    recomputed per workgroup from the D-vector (L2 resident) while the first weight loads --
-//    issued before the prologue, they do not depend on it -- are already in flight.
-//  * Grid = one 512-thread workgroup per CU (8 waves, up to 20 x 16 B loads in flight per lane).
+//    recomputed per workgroup from the D-vector (L2 resident).  Prologue inputs are requested
+//    first, then the first steps of the weight stream, so the prologue runs under the stream.
+//  * Grid = one 512-thread workgroup per CU (8 waves); each wave keeps R*S x 16 B loads in flight
+//    and refills a step's registers with the next row group as soon as the step is consumed.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,9 +41,12 @@ constexpr int NT = 512;          // threads per workgroup
 constexpr int NW = NT / 64;      // wavefronts per workgroup
 constexpr int RED_BYTES = 1024;  // LDS scratch for workgroup reductions
 constexpr unsigned VOCAB = 50277u;
+constexpr float QLIM = 8388000.0f;       // |quantised activation| <= QLIM < 2^23
+constexpr double QOFF = 8388608.0;       // 2^23: limbs hold q + 2^23 as an unsigned 24-bit number
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 // per-token control block, lives in device memory so a captured hipGraph can be replayed for
 // any token / state slot / logits row (and so the device-side argmax can feed the next step)
@@ -49,16 +58,35 @@ struct Ctl {
     unsigned int pad;
 };
 
-__device__ __forceinline__ float wave_sum(float v)
+__device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
-__device__ __forceinline__ double wave_sum(double v)
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+// 64-lane sum on the DPP network (VALU-latency steps instead of six dependent ds_bpermute round
+// trips through the LDS crossbar): xor-1/xor-2 inside quads, rotate by 4 and 8 inside each row of
+// 16, then row_bcast:15 / row_bcast:31 fold the four rows into lane 63; readlane makes it uniform.
+__device__ __forceinline__ unsigned wave_sum_dpp(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, true);   // row_ror:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);   // row_ror:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
     return v;
 }
 
@@ -83,14 +111,64 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *red)
     }
     __syncthreads();
 }
-
-// LDS position of element j of an activation vector: 16-element chunk c = j/16 belongs to lane
-// c%64 at step c/64; the four float4 pieces of a chunk are spread so that piece q of all 64
-// lanes is contiguous (ds_read_b128 with lane-consecutive 16-B addresses: conflict-free).
-__device__ __forceinline__ int xperm(int j)
+// workgroup-wide max of K floats
+template <int K>
+__device__ __forceinline__ void block_max(float (&v)[K], double *redd)
 {
-    const int c = j >> 4, q = (j >> 2) & 3, e = j & 3;
-    return ((((c >> 6) * 4 + q) * 64 + (c & 63)) << 2) + e;
+    float *red = reinterpret_cast<float *>(redd);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = wave_max(v[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[w * K + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; i++) s = fmaxf(s, red[i * K + k]);
+        v[k] = s;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// Staged activation vectors.  Element j of a vector belongs to the 16-element piece c = j/16,
+// which lane c%64 consumes at step c/64 together with weight bytes [16c, 16c+16) of a row.
+// LDS image per vector: [step][limb 0..2][lane][4 dwords]; dword q of a lane holds limb b of
+// elements 16c+4q .. 16c+4q+3 (byte e = element 4q+e), i.e. exactly the operand v_dot4_u32_u8
+// needs against dword q of the lane's 16 weight bytes.  A lane's ds_read_b128 of one limb plane is
+// lane-consecutive (conflict-free).  S*768 dwords (3 KiB per step) per vector.
+template <int S> __device__ __forceinline__ constexpr int xvd() { return S * 768; }
+template <int S> __device__ __forceinline__ constexpr int nquads() { return (S * 256 + NT - 1) / NT; }   // per thread
+
+// quantise 4 consecutive elements (quad qd = j/4) with 1/scale `inv_s` and store their 3 limb dwords.
+// real == false writes zero limbs: padding must contribute nothing to the integer sums (it is
+// outside the row sums used for the 2^23 offset correction).
+__device__ __forceinline__ void stage_quad(unsigned *xq, int qd, const float (&xr)[4], float inv_s, bool real)
+{
+    unsigned d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const unsigned qi = (unsigned)(__float2int_rn(xr[e] * inv_s) + 8388608);
+        d0 |= (qi & 255u) << (8 * e);
+        d1 |= ((qi >> 8) & 255u) << (8 * e);
+        d2 |= ((qi >> 16) & 255u) << (8 * e);
+    }
+    const int c = qd >> 2, q = qd & 3;
+    unsigned *p = xq + ((((c >> 6) * 3) * 64 + (c & 63)) << 2) + q;
+    p[0] = real ? d0 : 0u;
+    p[256] = real ? d1 : 0u;
+    p[512] = real ? d2 : 0u;
+}
+__device__ __forceinline__ float inv_scale(float amax) { return QLIM / fmaxf(amax, 1e-30f); }
+__device__ __forceinline__ double scale_of(float amax) { return (double)fmaxf(amax, 1e-30f) / (double)QLIM; }
+// integer sums of one row -> real value of sum_j u_j * x_j
+__device__ __forceinline__ float row_value(unsigned long long T, unsigned rowsum, double scale)
+{
+    return (float)(scale * ((double)(long long)T - QOFF * (double)rowsum));
 }
 
 // which staged vector row r of a group multiplies with
@@ -106,10 +184,11 @@ template <int PAT, int R> __device__ __forceinline__ constexpr int nvec()
     return PAT == PAT_SHARED ? 1 : (PAT == PAT_PER_ROW ? R : 2);
 }
 
+// ------------------------------------------------------------------------------------------
 // Row-group streaming.  A group = R rows `stride` bytes apart, each `chunks` 16-byte pieces long;
 // piece c belongs to lane c%64 at step c/64, so one step of one row is a 1 KiB coalesced
 // non-temporal wave load.  Lanes past the end of a row (rows that are not a multiple of 1 KiB)
-// re-read the row's last piece instead of branching: the staged vector is zero there, and a
+// re-read the row's last piece instead of branching: the staged limbs are zero there, and a
 // predicated load would make hipcc drain vmcnt(0) at the branch join.
 template <int R, int S>
 __device__ __forceinline__ void step_load(u32x4 (&w)[R][S], int s, const uint8_t *__restrict__ base,
@@ -141,62 +220,52 @@ __device__ __forceinline__ void group_load(u32x4 (&w)[R][S], const uint8_t *__re
 #endif
 template <int S> __device__ __forceinline__ constexpr int pre_steps() { return RWKV_PRE_STEPS < S ? RWKV_PRE_STEPS : S; }
 
-__device__ __forceinline__ void dot16(const u32x4 w, const f32x4 (&x)[4], float (&a)[4])
-{
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const unsigned u = w[q];
-        a[0] = fmaf((float)(u & 0xffu), x[q][0], a[0]);
-        a[1] = fmaf((float)((u >> 8) & 0xffu), x[q][1], a[1]);
-        a[2] = fmaf((float)((u >> 16) & 0xffu), x[q][2], a[2]);
-        a[3] = fmaf((float)(u >> 24), x[q][3], a[3]);
-    }
-}
-
-// Dot products of the loaded group with the staged vector(s); every lane gets all R sums.
-//  * The LDS reads of the activation pieces are software-pipelined one (step, vector) item ahead
-//    and pinned with sched barriers, so at most two 16-float pieces are live.
+// Integer dot products of the loaded group with the staged vector(s): T[r] = sum_j u_rj * q'_j
+// (q' = 24-bit unsigned limb value), every lane gets all R sums.
+//  * The LDS reads of the limb pieces are software-pipelined one (step, vector) item ahead and
+//    pinned with sched barriers, so at most two 12-dword pieces are live.
 //  * Refill: as soon as step s of this group has been consumed its registers are re-loaded with
 //    step s of the NEXT group (`next`), so the wave keeps R*S loads in flight across groups
 //    instead of draining and restarting the memory pipe at every group boundary.  The refill is
 //    unconditional and branch-free (a branch would make hipcc's waitcnt pass merge the two paths
 //    and wait for the refill itself; two template copies in sibling branches get their common
-//    byte->float converts hoisted and spilled): after a wave's LAST group, `next_valid` = false
-//    degrades the refill to R*S loads of one and the same 16-byte piece (one L1-resident line),
-//    which nobody waits for.
+//    code hoisted and spilled): after a wave's LAST group, `next_valid` = false degrades the refill
+//    to R*S loads of one and the same 16-byte piece (one L1-resident line), which nobody waits for.
 template <int R, int S, int PAT>
-__device__ __forceinline__ void group_dot(u32x4 (&w)[R][S], const float *xv, int xvlen, int lane, float (&out)[R],
+__device__ __forceinline__ void group_dot(u32x4 (&w)[R][S], const unsigned *xq, int lane, unsigned long long (&T)[R],
                                           const uint8_t *__restrict__ next, size_t stride, int chunks, bool next_valid)
 {
     constexpr int NV = nvec<PAT, R>();
     constexpr int NI = S * NV;
+    constexpr int XVD = xvd<S>();
     const unsigned mask = next_valid ? 0xffffffffu : 0u;
     const size_t nstride = next_valid ? stride : 0;
-    float acc[R][4];
+    unsigned acc[R][3];
 #pragma unroll
-    for (int r = 0; r < R; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
-    f32x4 x[2][4];
-    const f32x4 *xb = reinterpret_cast<const f32x4 *>(xv) + lane;
+    for (int r = 0; r < R; r++) { acc[r][0] = acc[r][1] = acc[r][2] = 0u; }
+    u32x4 x[2][3];
+    const u32x4 *xb = reinterpret_cast<const u32x4 *>(xq) + lane;
 #pragma unroll
-    for (int q = 0; q < 4; q++) x[0][q] = xb[q * 64];
+    for (int b = 0; b < 3; b++) x[0][b] = xb[b * 64];
 #pragma unroll
     for (int it = 0; it < NI; it++) {
         const int s = it / NV, v = it % NV;
         if (it + 1 < NI) {
             const int s1 = (it + 1) / NV, v1 = (it + 1) % NV;
-            const f32x4 *p = xb + (v1 * (xvlen >> 2)) + (s1 * 4) * 64;
+            const u32x4 *p = xb + (v1 * (XVD >> 2)) + (s1 * 3) * 64;
 #pragma unroll
-            for (int q = 0; q < 4; q++) x[(it + 1) & 1][q] = p[q * 64];
+            for (int b = 0; b < 3; b++) x[(it + 1) & 1][b] = p[b * 64];
         }
 #pragma unroll
         for (int r = 0; r < R; r++)
             if (xsel<PAT>(r) == v) {
-                dot16(w[r][s], x[it & 1], acc[r]);
-                // pin the partial sums here: without it LLVM sinks all FMAs below all LDS reads and
-                // the whole staged vector becomes live at once (spills); the sched barrier keeps the
-                // next row's 16 byte->float converts from being hoisted above this row's FMAs
-                asm volatile("" : "+v"(acc[r][0]), "+v"(acc[r][1]), "+v"(acc[r][2]), "+v"(acc[r][3]));
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < 3; b++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        acc[r][b] = __builtin_amdgcn_udot4(w[r][s][q], x[it & 1][b][q], acc[r][b], false);
+                // pin the partial sums here so the dot products stay between their LDS reads
+                asm volatile("" : "+v"(acc[r][0]), "+v"(acc[r][1]), "+v"(acc[r][2]));
             }
         __builtin_amdgcn_sched_barrier(0);
         if (v == NV - 1) {
@@ -204,8 +273,13 @@ __device__ __forceinline__ void group_dot(u32x4 (&w)[R][S], const float *xv, int
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // each limb total fits 32 bits (N * 255 * 255 < 2^32 for N <= 66051), so the three planes are
+    // reduced as u32 and combined afterwards on wave-uniform values
 #pragma unroll
-    for (int r = 0; r < R; r++) out[r] = wave_sum((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]));
+    for (int r = 0; r < R; r++) {
+        const unsigned t0 = wave_sum_dpp(acc[r][0]), t1 = wave_sum_dpp(acc[r][1]), t2 = wave_sum_dpp(acc[r][2]);
+        T[r] = (unsigned long long)t0 + ((unsigned long long)t1 << 8) + ((unsigned long long)t2 << 16);
+    }
 }
 
 // optional phase timeline (debug / tuning): lane 0 of every wave stamps the 100 MHz wall clock
@@ -224,30 +298,38 @@ __device__ __forceinline__ void tl_stamp(unsigned long long *tl, int phase)
 // Prologue discipline.  vmcnt retires loads IN ORDER, so a prologue load issued after the weight
 // loads would not return before every weight byte of the wave has landed.  Each kernel therefore
 // issues, in program order: (1) ALL of its prologue inputs, straight-line and branch-free
-// (out-of-range elements clamp their index), (2) the first row group's weight loads, and only
+// (out-of-range elements clamp their index), (2) the first steps of the first row group, and only
 // then (3) consumes the prologue inputs -- hipcc's counted s_waitcnt vmcnt(N) lets the LayerNorm /
-// mix / LDS staging run while the weight loads are still in flight.  The static per-channel
-// parameters are packed at load time into float4 tables (k_pack_*), so a prologue element costs
-// 1-3 16-byte loads instead of up to 13 scalar ones.
+// mix / quantise / LDS staging run while the weight loads are in flight.  The static per-channel
+// parameters are packed at load time into float4 tables (k_pack_*).  A thread owns QUADS of 4
+// consecutive elements (quad qd = tid + i*NT), which is what one limb dword holds.
 
-// LayerNorm statistics of a D-vector held E elements per thread (reference semantics: mean =
-// sum/D, variance over D-1, no epsilon -- rwkv.cu:40-57,412-450), in f64.
-template <int E>
-__device__ __forceinline__ void ln_stats(const double (&xl)[E], int D, double &mean, double &rstd, double *red)
+// LayerNorm statistics of a D-vector held as NQ quads per thread (reference semantics: mean =
+// sum/D, variance over D-1, no epsilon -- rwkv.cu:40-57,412-450), in f64: one workgroup reduction
+// of (sum, sum of squares); var = (sumsq - sum*mean)/(D-1).
+template <int NQ>
+__device__ __forceinline__ void ln_stats(const double (&xl)[NQ][4], int D, double &mean, double &rstd, double *red)
 {
-    // one workgroup reduction of (sum, sum of squares) in f64; var = (sumsq - sum^2/D)/(D-1).
-    // (f64 leaves ~1e-13 relative after the cancellation for |mean| up to 1e2 sigma.)
     double s[2] = {0.0, 0.0};
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const double v = (threadIdx.x + e * NT < D) ? xl[e] : 0.0;
-        s[0] += v;
-        s[1] += v * v;
+    for (int i = 0; i < NQ; i++) {
+        const bool real = (int)(threadIdx.x + i * NT) * 4 < D;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const double v = real ? xl[i][e] : 0.0;
+            s[0] += v;
+            s[1] += v * v;
+        }
     }
     block_sum<2>(s, red);
     mean = s[0] / (double)D;
     const double var = (s[1] - s[0] * mean) / (double)(D - 1);
     rstd = 1.0 / sqrt(var);
+}
+__device__ __forceinline__ void load_quad_f64(const double *p, int qd, double (&out)[4])
+{
+    const f64x2 a = reinterpret_cast<const f64x2 *>(p)[qd * 2], b = reinterpret_cast<const f64x2 *>(p)[qd * 2 + 1];
+    out[0] = a[0]; out[1] = a[1]; out[2] = b[0]; out[3] = b[1];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -264,23 +346,21 @@ __global__ __launch_bounds__(NT) void k_embed_ln0(EmbedArgs a)
     __shared__ double red[NW * 2];
     const int D = a.D;
     const float *row = a.embed + (size_t)a.ctl->token * D;
-    double s[1] = {0.0};
-    for (int j = threadIdx.x; j < D; j += NT) s[0] += (double)row[j];
-    block_sum<1>(s, red);
+    double s[2] = {0.0, 0.0};
+    for (int j = threadIdx.x; j < D; j += NT) { const double v = (double)row[j]; s[0] += v; s[1] += v * v; }
+    block_sum<2>(s, red);
     const double mean = s[0] / (double)D;
-    double q[1] = {0.0};
-    for (int j = threadIdx.x; j < D; j += NT) { const double d = (double)row[j] - mean; q[0] += d * d; }
-    block_sum<1>(q, red);
-    const double stdv = sqrt(q[0] / (double)(D - 1));
+    const double rstd = 1.0 / sqrt((s[1] - s[0] * mean) / (double)(D - 1));
     for (int j = threadIdx.x; j < D; j += NT)
-        a.x[j] = a.ln[j] * (((double)row[j] - mean) / stdv) + a.ln[D + j];
+        a.x[j] = a.ln[j] * (((double)row[j] - mean) * rstd) + a.ln[D + j];
 }
 
 // ------------------------------------------------------------------------------------------
 struct AttArgs {
     const double *x;                      // residual stream [D]
-    const f32x4 *pk;                      // [D][3] packed {lnw,lnb,mixk,mixv | mixr,rk,rv,rr | ok,ov,or,0}
+    const f32x4 *pk;                      // [3][4][D/4] packed {lnw,lnb,mixk,mixv | mixr,rk,rv,rr | ok,ov,or,0}, see k_pack_att
     const uint8_t *w;                     // [D][3][D] u8: rows K_i, V_i, R_i of channel i
+    const unsigned *rs;                   // [D][3] row sums of w (for the 2^23 limb offset)
     const double *uw, *ew;                // precomputed bonus+decay and exp(decay), [D]
     const float *r_att, *o_att;           // att_out scale / offset (to pre-scale the gated wkv)
     double *sxy, *saa, *sbb;              // state arrays [slots][L][D], already offset to this layer
@@ -297,67 +377,90 @@ template <int S>
 __global__ __launch_bounds__(NT) void k_att(AttArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XV = S * 1024;
-    constexpr int E = XV / NT;
+    constexpr int XVD = xvd<S>();
+    constexpr int NQ = nquads<S>();
     double *red = reinterpret_cast<double *>(smem);
-    float *xv = reinterpret_cast<float *>(smem + RED_BYTES);
-    float *stash = xv + 3 * XV;
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
+    float *stash = reinterpret_cast<float *>(xq + 3 * XVD);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4;
+    const int chunks = D >> 4, nqd = D >> 2;
     const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
 
     // (1) prologue inputs
-    double xl[E], pv[E];
-    f32x4 P[E][3];
+    double xl[NQ][4], pv[NQ][4];
+    f32x4 P[NQ][4][3];
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int j = threadIdx.x + e * NT, jj = j < D ? j : D - 1;
-        xl[e] = a.x[jj];
-        pv[e] = a.sxy[so + jj];
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
+        load_quad_f64(a.x, qc, xl[i]);
+        load_quad_f64(a.sxy + so, qc, pv[i]);
 #pragma unroll
-        for (int q = 0; q < 3; q++) P[e][q] = a.pk[jj * 3 + q];
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) P[i][e][q] = a.pk[(q * 4 + e) * nqd + qc];   // [piece][elem-in-quad][quad]: lane-contiguous
     }
-    // (2) step 0 of the first group's weights.  Only one step: a wave that asks for more than the
-    // memory pipe accepts stalls AT ISSUE (in-order), and the prologue below would wait with it.
-    // Unconditional (a wave without a group re-reads a neighbour's rows): a branch around the loads
-    // would make hipcc's waitcnt pass assume the no-load path and drain the weights early.
+    // (2) first steps of the first group's weights.  Unconditional (a wave without a group re-reads
+    // a neighbour's rows): a branch around the loads would make hipcc's waitcnt pass assume the
+    // no-load path and drain the weights early.
     u32x4 w[3][S];
     int g = g0 + wave;
     const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 3 * D;
     group_load<3, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
 
-    // (3) LayerNorm, token-shift mix, pre-scale by the per-row quantisation scale, stage in LDS
+    // (3) LayerNorm, token-shift mix, pre-scale by the per-row quantisation scale
     double mean, rstd;
-    ln_stats<E>(xl, D, mean, rstd, red);
+    ln_stats<NQ>(xl, D, mean, rstd, red);
     double Ssum[3] = {0.0, 0.0, 0.0};
+    float amax[3] = {0.f, 0.f, 0.f};
+    float xr[NQ][3][4];
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int j = threadIdx.x + e * NT;
-        float xk = 0.f, xvv = 0.f, xr = 0.f;
-        if (j < D) {
-            const double xx = (double)P[e][0][0] * ((xl[e] - mean) * rstd) + (double)P[e][0][1];
-            const double prev = pv[e];
-            const double mk = (double)P[e][0][2], mv = (double)P[e][0][3], mr = (double)P[e][1][0];
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NT;
+        const bool real = qd < nqd;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const double xx = (double)P[i][e][0][0] * ((xl[i][e] - mean) * rstd) + (double)P[i][e][0][1];
+            const double prev = pv[i][e];
+            const double mk = (double)P[i][e][0][2], mv = (double)P[i][e][0][3], mr = (double)P[i][e][1][0];
             const float fk = (float)(mk * xx + (1.0 - mk) * prev);   // rwkv.cu:382-384: rounded to f32
             const float fv = (float)(mv * xx + (1.0 - mv) * prev);
             const float fr = (float)(mr * xx + (1.0 - mr) * prev);
-            xk = fk * P[e][1][1]; xvv = fv * P[e][1][2]; xr = fr * P[e][1][3];
-            Ssum[0] += (double)(fk * P[e][2][0]); Ssum[1] += (double)(fv * P[e][2][1]); Ssum[2] += (double)(fr * P[e][2][2]);
-            if (blockIdx.x == 0) a.xx_buf[j] = xx;
+            xr[i][0][e] = fk * P[i][e][1][1]; xr[i][1][e] = fv * P[i][e][1][2]; xr[i][2][e] = fr * P[i][e][1][3];
+            if (real) {
+                Ssum[0] += (double)(fk * P[i][e][2][0]); Ssum[1] += (double)(fv * P[i][e][2][1]); Ssum[2] += (double)(fr * P[i][e][2][2]);
+#pragma unroll
+                for (int m = 0; m < 3; m++) amax[m] = fmaxf(amax[m], fabsf(xr[i][m][e]));
+                if (blockIdx.x == 0) a.xx_buf[qd * 4 + e] = xx;
+            }
         }
-        const int p = xperm(j);
-        xv[p] = xk; xv[XV + p] = xvv; xv[2 * XV + p] = xr;
     }
-    group_load<3, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // remaining steps of the first group
+    block_max<3>(amax, red);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NT;
+        if (qd < S * 256) {
+#pragma unroll
+            for (int m = 0; m < 3; m++) stage_quad(xq + m * XVD, qd, xr[i][m], inv_scale(amax[m]), qd < nqd);
+        }
+    }
     __syncthreads();                                                       // staged vectors visible
+    // the bulk of the first group is requested only now: its issue stalls on the full memory pipe,
+    // and a stall in front of a workgroup barrier would make every wave wait for the slowest one
+    group_load<3, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);
+    const double sc[3] = {scale_of(amax[0]), scale_of(amax[1]), scale_of(amax[2])};
 
     for (; g < g1; g += NW) {
-        float out[3];
+        unsigned long long T[3];
         const bool nv = g + NW < g1;
-        group_dot<3, S, PAT_PER_ROW>(w, xv, XV, lane, out, a.w + (size_t)(nv ? g + NW : 0) * 3 * D, (size_t)D, chunks, nv);
-        if (lane == 0) { stash[(g - g0) * 3 + 0] = out[0]; stash[(g - g0) * 3 + 1] = out[1]; stash[(g - g0) * 3 + 2] = out[2]; }
+        // per-group epilogue inputs are requested BEFORE the dot issues the refill loads: a load
+        // placed after them would, by in-order vmcnt, wait for the whole next group to land
+        const unsigned rsum = a.rs[g * 3 + (lane < 3 ? lane : 0)];
+        group_dot<3, S, PAT_PER_ROW>(w, xq, lane, T, a.w + (size_t)(nv ? g + NW : 0) * 3 * D, (size_t)D, chunks, nv);
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+            if (lane == m) stash[(g - g0) * 3 + m] = row_value(T[m], rsum, sc[m]);
     }
     block_sum<3>(Ssum, red);   // offset terms: only needed by the epilogue (also the barrier before it)
 
@@ -386,6 +489,7 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
 // ------------------------------------------------------------------------------------------
 struct AttOutArgs {
     const uint8_t *w;      // [D][D] u8 rows = output channels
+    const unsigned *rs;    // [D] row sums
     const float *ybuf;     // [D] pre-scaled input vector
     const double *partS;   // [n_part] partial offset sums (n_part <= NT)
     int n_part;
@@ -402,19 +506,22 @@ template <int S, int R>
 __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XV = S * 1024;
-    constexpr int E = XV / NT;
+    constexpr int NQ = nquads<S>();
     double *red = reinterpret_cast<double *>(smem);
-    float *xv = reinterpret_cast<float *>(smem + RED_BYTES);
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4;
+    const int chunks = D >> 4, nqd = D >> 2;
     const int G = (D + R - 1) / R;
     const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
 
-    float yl[E];
+    float yl[NQ][4];
 #pragma unroll
-    for (int e = 0; e < E; e++) { const int j = threadIdx.x + e * NT; yl[e] = a.ybuf[j < D ? j : D - 1]; }
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
+        const f32x4 t = reinterpret_cast<const f32x4 *>(a.ybuf)[qc];
+        yl[i][0] = t[0]; yl[i][1] = t[1]; yl[i][2] = t[2]; yl[i][3] = t[3];
+    }
     double Ssum[1] = {a.partS[(int)threadIdx.x < a.n_part ? threadIdx.x : 0]};
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
 
@@ -427,27 +534,42 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
     };
     const uint8_t *wb = rowbase(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0));
     group_load<R, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
+
+    float amax[1] = {0.f};
 #pragma unroll
-    for (int e = 0; e < E; e++) { const int j = threadIdx.x + e * NT; xv[xperm(j)] = (j < D) ? yl[e] : 0.f; }
+    for (int i = 0; i < NQ; i++)
+        if ((int)(threadIdx.x + i * NT) < nqd)
+#pragma unroll
+            for (int e = 0; e < 4; e++) amax[0] = fmaxf(amax[0], fabsf(yl[i][e]));
+    block_max<1>(amax, red);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NT;
+        if (qd < S * 256) stage_quad(xq, qd, yl[i], inv_scale(amax[0]), qd < nqd);
+    }
     if ((int)threadIdx.x >= a.n_part) Ssum[0] = 0.0;
-    group_load<R, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);
-    block_sum<1>(Ssum, red);
+    block_sum<1>(Ssum, red);   // also the barrier that publishes the staged vector
+    group_load<R, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
     const float Sf = (float)Ssum[0];
+    const double sc = scale_of(amax[0]);
 
     for (; g < g1; g += NW) {
-        float out[R];
+        unsigned long long T[R];
         const bool nv = g + NW < g1;
-        group_dot<R, S, PAT_SHARED>(w, xv, XV, lane, out, rowbase(nv ? g + NW : 0), (size_t)D, chunks, nv);
         int row0 = g * R;
         const int shift = (row0 > D - R) ? row0 - (D - R) : 0;   // last group may overlap the previous one
         row0 -= shift;
+        // epilogue inputs first (see k_att): lane r owns row row0 + r
+        const int mi = row0 + (lane < R ? lane : 0);
+        const unsigned rsum = a.rs[mi];
+        const double xold = a.x[mi], xxn = a.xx_buf[mi];
+        group_dot<R, S, PAT_SHARED>(w, xq, lane, T, rowbase(nv ? g + NW : 0), (size_t)D, chunks, nv);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (lane == r && r >= shift) {
-                const int i = row0 + r;
-                const float acc = (float)a.x[i] + (out[r] + Sf);   // f32 accumulator pre-loaded with x (:548)
-                a.x[i] = (double)acc;                                // :553
-                a.sxy[so + i] = a.xx_buf[i];                         // mixatt's state write (:385), deferred
+                const float acc = (float)xold + (row_value(T[r], rsum, sc) + Sf);   // f32 accumulator pre-loaded with x (:548)
+                a.x[mi] = (double)acc;                                              // :553
+                a.sxy[so + mi] = xxn;                                               // mixatt's state write (:385), deferred
             }
         }
     }
@@ -456,8 +578,9 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
 // ------------------------------------------------------------------------------------------
 struct FfnRKArgs {
     const double *x;
-    const f32x4 *pk;                  // [D][2] packed {lnw,lnb,mixk,mixr | rk,ok,rr,or}
+    const f32x4 *pk;                  // [2][4][D/4] packed {lnw,lnb,mixk,mixr | rk,ok,rr,or}, see k_pack_ffn
     const uint8_t *w;                 // [D][5][D]: rows ffn_k out 4i..4i+3, then ffn_r out i
+    const unsigned *rs;               // [D][5] row sums
     const float *r_fv, *o_fv;         // ffn_v scale / offset [4D]
     const double *sdd;                // state dd of this layer (read only here)
     size_t slot_stride;
@@ -475,37 +598,32 @@ template <int S>
 __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XV = S * 1024;
-    constexpr int E = XV / NT;
+    constexpr int XVD = xvd<S>();
+    constexpr int NQ = nquads<S>();
     double *red = reinterpret_cast<double *>(smem);
-    float *xv = reinterpret_cast<float *>(smem + RED_BYTES);
-    float *stash = xv + 2 * XV;
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
+    float *stash = reinterpret_cast<float *>(xq + 2 * XVD);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4;
+    const int chunks = D >> 4, nqd = D >> 2;
     const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
     tl_stamp(a.tl, 0);
 
-    double xl[E], pv[E];
-    f32x4 P[E][2];
-#ifdef RWKV_EXP_NOPROLOGUE   // timing experiment only: no prologue traffic, constant staged vectors
+    double xl[NQ][4], pv[NQ][4];
+    f32x4 P[NQ][4][2];
 #pragma unroll
-    for (int e = 0; e < E; e++) { xl[e] = 1.0 + e; pv[e] = 0.5; P[e][0] = f32x4{1.f, 0.f, 0.5f, 0.5f}; P[e][1] = f32x4{0.01f, 0.f, 0.01f, 0.f}; }
-#else
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
+        load_quad_f64(a.x, qc, xl[i]);
+        load_quad_f64(a.sdd + so, qc, pv[i]);
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int j = threadIdx.x + e * NT, jj = j < D ? j : D - 1;
-        xl[e] = a.x[jj];
-        pv[e] = a.sdd[so + jj];
-        P[e][0] = a.pk[jj * 2];
-        P[e][1] = a.pk[jj * 2 + 1];
+        for (int e = 0; e < 4; e++) { P[i][e][0] = a.pk[e * nqd + qc]; P[i][e][1] = a.pk[(4 + e) * nqd + qc]; }   // lane-contiguous
     }
-#endif
     u32x4 w[5][S];
     int g = g0 + wave;
-#ifdef RWKV_EXP_SAMEROWS   // timing experiment only: every wave streams group 0 (cache resident) -> compute-only time
-#define RWKV_EXP_G(gg) 0
+#ifdef RWKV_EXP_SAMEROWS   // timing experiment only: waves stream 64 cache-resident groups -> compute-only time
+#define RWKV_EXP_G(gg) ((gg) % 64)
 #else
 #define RWKV_EXP_G(gg) (gg)
 #endif
@@ -514,42 +632,53 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     tl_stamp(a.tl, 1);
 
     double mean, rstd;
-#ifdef RWKV_EXP_NOPROLOGUE
-    mean = 0.25; rstd = 0.9;
-#else
-    ln_stats<E>(xl, D, mean, rstd, red);
-#endif
+    ln_stats<NQ>(xl, D, mean, rstd, red);
     tl_stamp(a.tl, 2);
     double Ssum[2] = {0.0, 0.0};
+    float amax[2] = {0.f, 0.f};
+    float xr[NQ][2][4];
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int j = threadIdx.x + e * NT;
-        float xk = 0.f, xr = 0.f;
-        if (j < D) {
-            const double xx = (double)P[e][0][0] * ((xl[e] - mean) * rstd) + (double)P[e][0][1];
-            const double prev = pv[e];
-            const double mk = (double)P[e][0][2], mr = (double)P[e][0][3];
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NT;
+        const bool real = qd < nqd;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const double xx = (double)P[i][e][0][0] * ((xl[i][e] - mean) * rstd) + (double)P[i][e][0][1];
+            const double prev = pv[i][e];
+            const double mk = (double)P[i][e][0][2], mr = (double)P[i][e][0][3];
             const float fk = (float)(mk * xx + (1.0 - mk) * prev);   // f64 mix (:341-342), f32 cast in the GEMV (:290)
             const float fr = (float)(mr * xx + (1.0 - mr) * prev);
-            xk = fk * P[e][1][0]; xr = fr * P[e][1][2];
-            Ssum[0] += (double)(fk * P[e][1][1]); Ssum[1] += (double)(fr * P[e][1][3]);
-            if (blockIdx.x == 0) a.xx_buf[j] = xx;
+            xr[i][0][e] = fk * P[i][e][1][0]; xr[i][1][e] = fr * P[i][e][1][2];
+            if (real) {
+                Ssum[0] += (double)(fk * P[i][e][1][1]); Ssum[1] += (double)(fr * P[i][e][1][3]);
+                amax[0] = fmaxf(amax[0], fabsf(xr[i][0][e])); amax[1] = fmaxf(amax[1], fabsf(xr[i][1][e]));
+                if (blockIdx.x == 0) a.xx_buf[qd * 4 + e] = xx;
+            }
         }
-        const int p = xperm(j);
-        xv[p] = xk; xv[XV + p] = xr;
     }
-    group_load<5, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);
+    block_max<2>(amax, red);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NT;
+        if (qd < S * 256) {
+            stage_quad(xq, qd, xr[i][0], inv_scale(amax[0]), qd < nqd);
+            stage_quad(xq + XVD, qd, xr[i][1], inv_scale(amax[1]), qd < nqd);
+        }
+    }
     __syncthreads();
     tl_stamp(a.tl, 3);
+    group_load<5, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
+    const double sc[2] = {scale_of(amax[0]), scale_of(amax[1])};
     bool first_ = true;
 
     for (; g < g1; g += NW) {
-        float out[5];
+        unsigned long long T[5];
         const bool nv = g + NW < g1;
-        group_dot<5, S, PAT_FFN_RK>(w, xv, XV, lane, out, a.w + (size_t)RWKV_EXP_G(nv ? g + NW : 0) * 5 * D, (size_t)D, chunks, nv);
+        const unsigned rsum = a.rs[g * 5 + (lane < 5 ? lane : 0)];   // before the refills (see k_att)
+        group_dot<5, S, PAT_FFN_RK>(w, xq, lane, T, a.w + (size_t)RWKV_EXP_G(nv ? g + NW : 0) * 5 * D, (size_t)D, chunks, nv);
 #pragma unroll
         for (int r = 0; r < 5; r++)
-            if (lane == r) stash[(g - g0) * 5 + r] = out[r];
+            if (lane == r) stash[(g - g0) * 5 + r] = row_value(T[r], rsum, sc[r < 4 ? 0 : 1]);
         if (first_) { tl_stamp(a.tl, 4); first_ = false; }
     }
     block_sum<2>(Ssum, red);   // offset terms: only needed by the epilogue (also the barrier before it)
@@ -577,6 +706,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
 // ------------------------------------------------------------------------------------------
 struct FfnVArgs {
     const uint8_t *w;      // [D][4D] u8: row i = output channel i, as 4 quarter-rows of D bytes
+    const unsigned *rs;    // [D] row sums (whole 4D row)
     const float *hbuf;     // [4D] pre-scaled hidden vector
     const double *partS;
     int n_part;
@@ -594,20 +724,24 @@ template <int S>
 __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XV = S * 1024;
-    constexpr int E = XV / NT;
+    constexpr int XVD = xvd<S>();
+    constexpr int NQ = nquads<S>();
     double *red = reinterpret_cast<double *>(smem);
-    float *xv = reinterpret_cast<float *>(smem + RED_BYTES);
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4;
+    const int chunks = D >> 4, nqd = D >> 2;
     const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
 
-    float hl[4][E];
+    float hl[4][NQ][4];
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int e = 0; e < E; e++) { const int j = threadIdx.x + e * NT; hl[q][e] = a.hbuf[q * D + (j < D ? j : D - 1)]; }
+        for (int i = 0; i < NQ; i++) {
+            const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
+            const f32x4 t = reinterpret_cast<const f32x4 *>(a.hbuf + (size_t)q * D)[qc];
+            hl[q][i][0] = t[0]; hl[q][i][1] = t[1]; hl[q][i][2] = t[2]; hl[q][i][3] = t[3];
+        }
     double Ssum[1] = {a.partS[(int)threadIdx.x < a.n_part ? threadIdx.x : 0]};
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
 
@@ -616,23 +750,39 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
     const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 4 * D;
     group_load<4, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
 
+    float amax[1] = {0.f};   // one scale for the whole 4D vector (its quarters are summed per row)
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int e = 0; e < E; e++) { const int j = threadIdx.x + e * NT; xv[q * XV + xperm(j)] = (j < D) ? hl[q][e] : 0.f; }
+        for (int i = 0; i < NQ; i++)
+            if ((int)(threadIdx.x + i * NT) < nqd)
+#pragma unroll
+                for (int e = 0; e < 4; e++) amax[0] = fmaxf(amax[0], fabsf(hl[q][i][e]));
+    block_max<1>(amax, red);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const int qd = threadIdx.x + i * NT;
+            if (qd < S * 256) stage_quad(xq + q * XVD, qd, hl[q][i], inv_scale(amax[0]), qd < nqd);
+        }
     if ((int)threadIdx.x >= a.n_part) Ssum[0] = 0.0;
-    group_load<4, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);
     block_sum<1>(Ssum, red);
+    group_load<4, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
     const float Sf = (float)Ssum[0];
+    const double sc = scale_of(amax[0]);
 
     for (; g < g1; g += NW) {
-        float out[4];
+        unsigned long long T[4];
         const bool nv = g + NW < g1;
-        group_dot<4, S, PAT_PER_ROW>(w, xv, XV, lane, out, a.w + (size_t)(nv ? g + NW : 0) * 4 * D, (size_t)D, chunks, nv);
+        const unsigned rsum = a.rs[g];   // epilogue inputs before the refills (see k_att)
+        const double xold = a.x[g], xxn = a.xx_buf[g];
+        const float rg = a.rgate[g];
+        group_dot<4, S, PAT_PER_ROW>(w, xq, lane, T, a.w + (size_t)(nv ? g + NW : 0) * 4 * D, (size_t)D, chunks, nv);
         if (lane == 0) {
-            const float v = ((out[0] + out[1]) + (out[2] + out[3])) + Sf;
-            a.x[g] = a.x[g] + (double)(v * a.rgate[g]);   // blockout, rwkv.cu:407 (f32 product)
-            a.sdd[so + g] = a.xx_buf[g];                   // mixffn's state write (:344), deferred
+            const float v = row_value((T[0] + T[1]) + (T[2] + T[3]), rsum, sc) + Sf;
+            a.x[g] = xold + (double)(v * rg);   // blockout, rwkv.cu:407 (f32 product)
+            a.sdd[so + g] = xxn;                 // mixffn's state write (:344), deferred
         }
     }
 }
@@ -640,8 +790,9 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
 // ------------------------------------------------------------------------------------------
 struct HeadArgs {
     const double *x;
-    const f32x4 *pk;           // [D] packed {lnw, lnb, r, o} of ln_out / head
+    const f32x4 *pk;           // [4][D/4] packed {lnw, lnb, r, o} of ln_out / head, see k_pack_head
     const uint8_t *w;          // [V][D] u8
+    const unsigned *rs;        // [V] row sums
     float *logits;             // [max_ctx][V]
     float *blk_val;            // [gridDim.x] per-workgroup max logit (index 0 banned)
     unsigned *blk_idx;         // [gridDim.x]
@@ -654,27 +805,28 @@ template <int S>
 __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XV = S * 1024;
-    constexpr int E = XV / NT;
+    constexpr int XVD = xvd<S>();
+    constexpr int NQ = nquads<S>();
     constexpr int R = 4;
     double *red = reinterpret_cast<double *>(smem);
-    float *xv = reinterpret_cast<float *>(smem + RED_BYTES);
-    float *bval = xv + XV;
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
+    float *bval = reinterpret_cast<float *>(xq + XVD);
     unsigned *bidx = reinterpret_cast<unsigned *>(bval + NW);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4;
+    const int chunks = D >> 4, nqd = D >> 2;
     const int V = (int)VOCAB;
     const int G = (V + R - 1) / R;
     const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
 
-    double xl[E];
-    f32x4 P[E];
+    double xl[NQ][4];
+    f32x4 P[NQ][4];
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int j = threadIdx.x + e * NT, jj = j < D ? j : D - 1;
-        xl[e] = a.x[jj];
-        P[e] = a.pk[jj];
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
+        load_quad_f64(a.x, qc, xl[i]);
+#pragma unroll
+        for (int e = 0; e < 4; e++) P[i][e] = a.pk[e * nqd + qc];   // lane-contiguous
     }
     u32x4 w[R][S];
     int g = g0 + wave;
@@ -686,37 +838,46 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
     const uint8_t *wb = rowbase(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0));
     group_load<R, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
     double mean, rstd;
-    ln_stats<E>(xl, D, mean, rstd, red);
+    ln_stats<NQ>(xl, D, mean, rstd, red);
     double Ssum[1] = {0.0};
+    float amax[1] = {0.f};
+    float xr[NQ][4];
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int j = threadIdx.x + e * NT;
-        float xs = 0.f;
-        if (j < D) {
-            const float f = (float)((double)P[e][0] * ((xl[e] - mean) * rstd) + (double)P[e][1]);
-            xs = f * P[e][2];
-            Ssum[0] += (double)(f * P[e][3]);
+    for (int i = 0; i < NQ; i++) {
+        const bool real = (int)(threadIdx.x + i * NT) < nqd;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float f = (float)((double)P[i][e][0] * ((xl[i][e] - mean) * rstd) + (double)P[i][e][1]);
+            xr[i][e] = f * P[i][e][2];
+            if (real) { Ssum[0] += (double)(f * P[i][e][3]); amax[0] = fmaxf(amax[0], fabsf(xr[i][e])); }
         }
-        xv[xperm(j)] = xs;
     }
-    group_load<R, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);
+    block_max<1>(amax, red);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NT;
+        if (qd < S * 256) stage_quad(xq, qd, xr[i], inv_scale(amax[0]), qd < nqd);
+    }
     block_sum<1>(Ssum, red);
+    group_load<R, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
     const float Sf = (float)Ssum[0];
+    const double sc = scale_of(amax[0]);
     float *lg = a.logits + (size_t)a.ctl->out_row * V;
 
     float best = -INFINITY;
     unsigned besti = 0xffffffffu;
     for (; g < g1; g += NW) {
-        float out[R];
+        unsigned long long T[R];
         const bool nv = g + NW < g1;
-        group_dot<R, S, PAT_SHARED>(w, xv, XV, lane, out, rowbase(nv ? g + NW : 0), (size_t)D, chunks, nv);
         int row0 = g * R;
         const int shift = (row0 > V - R) ? row0 - (V - R) : 0;
         row0 -= shift;
+        const u32x4 rs4 = {a.rs[row0], a.rs[row0 + 1], a.rs[row0 + 2], a.rs[row0 + 3]};   // before the refills (see k_att)
+        group_dot<R, S, PAT_SHARED>(w, xq, lane, T, rowbase(nv ? g + NW : 0), (size_t)D, chunks, nv);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const float val = out[r] + Sf;
             const int i = row0 + r;
+            const float val = row_value(T[r], rs4[r], sc) + Sf;
             if (lane == r && r >= shift) lg[i] = val;
             if (i != 0 && (val > best || (val == best && (unsigned)i < besti))) { best = val; besti = (unsigned)i; }
         }
@@ -759,10 +920,11 @@ __global__ void k_argmax_finish(const float *blk_val, const unsigned *blk_idx, i
 
 // ------------------------------------------------------------------------------------------
 // Stand-alone dequant-GEMV on the same row engine (unit tests; the kernel behind
-// cudac_mm8_one, rwkv.cu:267-311).  w_t is the re-tiled [M][N] matrix.  N <= 5120: rows whole;
-// otherwise N = 4*Dq and rows are processed as 4 quarter-rows (the ffn_v shape).
+// cudac_mm8_one, rwkv.cu:267-311).  w_t is the re-tiled [M][N] matrix, rs its row sums.
+// N <= 5120: rows whole; otherwise N = 4*Dq and rows are processed as 4 quarter-rows (ffn_v shape).
 struct Mm8Args {
     const uint8_t *w_t;
+    const unsigned *rs;
     const float *x, *r, *o;
     float *y;
     int N, M;
@@ -771,48 +933,65 @@ template <int S, bool QUARTERS>
 __global__ __launch_bounds__(NT) void k_mm8(Mm8Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XV = S * 1024;
+    constexpr int XVD = xvd<S>();
+    constexpr int NQ = nquads<S>();
     constexpr int R = 4;
+    constexpr int NVQ = QUARTERS ? 4 : 1;
     double *red = reinterpret_cast<double *>(smem);
-    float *xv = reinterpret_cast<float *>(smem + RED_BYTES);
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Dq = QUARTERS ? a.N / 4 : a.N;
-    const int chunks = Dq >> 4;
+    const int chunks = Dq >> 4, nqd = Dq >> 2;
     const int M = a.M;
     const int G = QUARTERS ? M : (M + R - 1) / R;
     const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
 
     double Ssum[1] = {0.0};
-    for (int q = 0; q < (QUARTERS ? 4 : 1); q++)
-        for (int j = threadIdx.x; j < XV; j += NT) {
-            float xs = 0.f;
-            if (j < Dq) {
-                const float f = a.x[q * Dq + j];
-                xs = f * a.r[q * Dq + j];
-                Ssum[0] += (double)(f * a.o[q * Dq + j]);
+    float amax[1] = {0.f};
+    float xr[NVQ][NQ][4];
+#pragma unroll
+    for (int q = 0; q < NVQ; q++)
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const int qd = threadIdx.x + i * NT;
+            const bool real = qd < nqd;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int j = q * Dq + (real ? qd : 0) * 4 + e;
+                const float f = a.x[j];
+                xr[q][i][e] = f * a.r[j];
+                if (real) { Ssum[0] += (double)(f * a.o[j]); amax[0] = fmaxf(amax[0], fabsf(xr[q][i][e])); }
             }
-            xv[q * XV + xperm(j)] = xs;
+        }
+    block_max<1>(amax, red);
+#pragma unroll
+    for (int q = 0; q < NVQ; q++)
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const int qd = threadIdx.x + i * NT;
+            if (qd < S * 256) stage_quad(xq + q * XVD, qd, xr[q][i], inv_scale(amax[0]), qd < nqd);
         }
     block_sum<1>(Ssum, red);
     const float Sf = (float)Ssum[0];
+    const double sc = scale_of(amax[0]);
 
     for (int g = g0 + wave; g < g1; g += NW) {
         u32x4 w[R][S];
-        float out[R];
+        unsigned long long T[R];
         if (QUARTERS) {
             group_load<R, S, 0, S>(w, a.w_t + (size_t)g * a.N, (size_t)Dq, chunks, lane);
-            group_dot<R, S, PAT_PER_ROW>(w, xv, XV, lane, out, a.w_t, 0, chunks, false);
-            if (lane == 0) a.y[g] = ((out[0] + out[1]) + (out[2] + out[3])) + Sf;
+            group_dot<R, S, PAT_PER_ROW>(w, xq, lane, T, a.w_t, 0, chunks, false);
+            if (lane == 0) a.y[g] = row_value((T[0] + T[1]) + (T[2] + T[3]), a.rs[g], sc) + Sf;
         } else {
             int row0 = g * R;
             const int shift = (row0 > M - R) ? row0 - (M - R) : 0;
             row0 -= shift;
             group_load<R, S, 0, S>(w, a.w_t + (size_t)row0 * a.N, (size_t)a.N, chunks, lane);
-            group_dot<R, S, PAT_SHARED>(w, xv, XV, lane, out, a.w_t, 0, chunks, false);
+            group_dot<R, S, PAT_SHARED>(w, xq, lane, T, a.w_t, 0, chunks, false);
 #pragma unroll
             for (int r = 0; r < R; r++)
-                if (lane == r && r >= shift) a.y[row0 + r] = out[r] + Sf;
+                if (lane == r && r >= shift) a.y[row0 + r] = row_value(T[r], a.rs[row0 + r], sc) + Sf;
         }
     }
 }
@@ -840,6 +1019,24 @@ __global__ void k_retile(const uint8_t *__restrict__ src, uint8_t *__restrict__ 
     }
 }
 
+// row sums of a re-tiled matrix: rs[row] = sum_j w_t[row][j]; one wave per row (load time)
+__global__ void k_rowsum(const uint8_t *__restrict__ w_t, unsigned *__restrict__ rs, size_t rows, int N)
+{
+    const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(w_t + row * (size_t)N);
+    unsigned acc = 0;
+    for (int c = lane; c < (N >> 4); c += 64) {
+        const u32x4 v = p[c];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_udot4(v[q], 0x01010101u, acc, false);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) rs[row] = acc;
+}
+
 // uw = bonus + decay, ew = exp(decay)   (constants of rwkv.cu:247-252, hoisted out of the token loop)
 __global__ void k_prep_wkv(const double *decay, const double *bonus, double *uw, double *ew, size_t n)
 {
@@ -847,33 +1044,38 @@ __global__ void k_prep_wkv(const double *decay, const double *bonus, double *uw,
     if (i < n) { uw[i] = bonus[i] + decay[i]; ew[i] = exp(decay[i]); }
 }
 
-// Load-time packing of the static per-channel parameters into float4 tables (the prologues read
-// 1-3 16-byte pieces per element instead of up to 13 scalars).  The f64 tensors involved
-// (layernorm rows, time-mix vectors) hold f32-representable values in converted checkpoints
-// (converter: .double() of f32 tensors, convert_model.py:44-56), so the narrowing is exact there.
+// Load-time packing of the static per-channel parameters into float4 tables.  A prologue thread
+// owns quads of 4 consecutive channels (quad qd = j/4, e = j%4), so the tables are laid out
+// [piece q][e][qd]: for a given (q, e) the 64 lanes of a wave read 64 consecutive float4 = one
+// fully coalesced 1 KiB load.  The f64 tensors involved (layernorm rows, time-mix vectors) hold
+// f32-representable values in converted checkpoints (converter: .double() of f32 tensors,
+// convert_model.py:44-56), so the narrowing is exact there.
 __global__ void k_pack_att(f32x4 *pk, const double *lnw, const double *lnb, const double *mk, const double *mv,
                            const double *mr, const float *rk, const float *rv, const float *rr,
                            const float *ok, const float *ov, const float *orr, int D)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D) return;
-    pk[j * 3 + 0] = f32x4{(float)lnw[j], (float)lnb[j], (float)mk[j], (float)mv[j]};
-    pk[j * 3 + 1] = f32x4{(float)mr[j], rk[j], rv[j], rr[j]};
-    pk[j * 3 + 2] = f32x4{ok[j], ov[j], orr[j], 0.f};
+    const int nqd = D >> 2, qd = j >> 2, e = j & 3;
+    pk[(0 * 4 + e) * nqd + qd] = f32x4{(float)lnw[j], (float)lnb[j], (float)mk[j], (float)mv[j]};
+    pk[(1 * 4 + e) * nqd + qd] = f32x4{(float)mr[j], rk[j], rv[j], rr[j]};
+    pk[(2 * 4 + e) * nqd + qd] = f32x4{ok[j], ov[j], orr[j], 0.f};
 }
 __global__ void k_pack_ffn(f32x4 *pk, const double *lnw, const double *lnb, const double *mk, const double *mr,
                            const float *rk, const float *ok, const float *rr, const float *orr, int D)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D) return;
-    pk[j * 2 + 0] = f32x4{(float)lnw[j], (float)lnb[j], (float)mk[j], (float)mr[j]};
-    pk[j * 2 + 1] = f32x4{rk[j], ok[j], rr[j], orr[j]};
+    const int nqd = D >> 2, qd = j >> 2, e = j & 3;
+    pk[(0 * 4 + e) * nqd + qd] = f32x4{(float)lnw[j], (float)lnb[j], (float)mk[j], (float)mr[j]};
+    pk[(1 * 4 + e) * nqd + qd] = f32x4{rk[j], ok[j], rr[j], orr[j]};
 }
 __global__ void k_pack_head(f32x4 *pk, const double *lnw, const double *lnb, const float *r, const float *o, int D)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D) return;
-    pk[j] = f32x4{(float)lnw[j], (float)lnb[j], r[j], o[j]};
+    const int nqd = D >> 2, qd = j >> 2, e = j & 3;
+    pk[e * nqd + qd] = f32x4{(float)lnw[j], (float)lnb[j], r[j], o[j]};
 }
 
 } // namespace rwkvk

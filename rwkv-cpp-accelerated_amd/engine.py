@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "rwkv_create", "rwkv_load_file", "rwkv_load_tensors", "rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx",
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
-    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline",
+    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched",
 ]
 
 _lib = None
@@ -62,6 +62,7 @@ def lib():
     L.rwkv_profile_token.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(C.c_uint32)]
     L.rwkv_profile_token.restype = i32
     L.rwkv_mm8_one.argtypes = [vp, u64, u64, vp, vp, vp, vp, vp]; L.rwkv_mm8_one.restype = i32
+    L.rwkv_profile_batched.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]; L.rwkv_profile_batched.restype = i32
     L.rwkv_debug_timeline.argtypes = [vp, u64, vp, u64]; L.rwkv_debug_timeline.restype = i32
     _lib = L
     return L
@@ -237,6 +238,13 @@ class RWKV:
         _chk(lib().rwkv_profile_token(self._h, token, reps, ms, by, ln))
         return [dict(name=KCLASS_NAMES[k], ms_total=ms[k], reps=reps, launches_per_token=int(ln[k]),
                      bytes_per_launch=int(by[k])) for k in range(N_KCLASS)]
+
+    def profile_batched(self, token: int = 1, reps: int = 4):
+        """per-class launch duration from one event pair around reps x L back-to-back launches (resets the state)"""
+        ms = (C.c_double * N_KCLASS)(); n = (C.c_uint32 * N_KCLASS)()
+        _chk(lib().rwkv_profile_batched(self._h, token, reps, ms, n))
+        by = [p["bytes_per_launch"] for p in self.profile_token(token, 1)]
+        return [dict(name=KCLASS_NAMES[k], us=1e3 * ms[k] / max(1, n[k]), launches=int(n[k]), bytes_per_launch=by[k]) for k in range(N_KCLASS)]
 
     def debug_timeline(self, token: int = 1, grid: int = 256):
         buf = np.zeros(512 * 8 * 8, dtype=np.uint64)
