@@ -43,6 +43,7 @@ def test_oracle_matches_reference_fixture(oracle, path):
     st = m.new_state(slots=slots)
     _replay(lambda toks: m.forward(toks, st, mode=mode), g)
     for i in range(5):
-        r = g[f"state{i}"]
-        assert np.abs(st[i][: r.size] - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), f"state {i}"
+        n = min(st[i].size, g[f"state{i}"].size)      # GPT mode: only slot 0 is live (the reference sizes its host state by maxGPT)
+        r = g[f"state{i}"][:n]
+        assert np.abs(st[i][:n] - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), f"state {i}"
     m.close()
