@@ -88,6 +88,17 @@ int rwkv_reset_state(rwkv_ctx *ctx);
  * the LAST step remain in the device logits buffer (row 0). */
 int rwkv_decode_greedy(rwkv_ctx *ctx, uint64_t first_token, uint64_t n_tokens, uint64_t *out_tokens);
 
+/* ---- layer pipeline (no reference counterpart: the reference is single-device) ----
+ * A context may own a contiguous layer range [l0, l1) of the model: call rwkv_set_layer_range()
+ * before loading.  The first stage (l0 == 0) also owns the embedding table + ln0, the last stage
+ * (l1 == n_layers) ln_out + head.  rwkv_stage_forward() runs this stage's share of ONE token on
+ * state slot `slot`: stage 0 starts from `token`; later stages start from the residual vector the
+ * caller has placed in rwkv_x_device() (f64[n_embed], e.g. by an RCCL recv) and leave their output
+ * there for the next hop.  On the last stage `pick` (may be NULL) receives the greedy id. */
+int rwkv_set_layer_range(rwkv_ctx *ctx, uint64_t l0, uint64_t l1);
+int rwkv_stage_forward(rwkv_ctx *ctx, uint64_t token, uint32_t slot, uint64_t *pick);
+double *rwkv_x_device(rwkv_ctx *ctx);
+
 /* Replaces freeTensors(), rwkv.cu:719-730, plus destruction of the handle. */
 void rwkv_free(rwkv_ctx *ctx);
 

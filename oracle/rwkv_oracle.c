@@ -386,3 +386,62 @@ uint64_t oracle_argmax_ban0(const float *logits)
     for (uint64_t i = 2; i < V_SIZE; i++) if (logits[i] > logits[best]) best = i;
     return best;
 }
+
+/* ---- one pipeline stage of one token: layers [l0, l1) of rwkv.cu:528-581 on state slot `slot`
+ * (state arrays are [slots][L][D]); embedding + ln0 (rwkv.cu:513-524) when l0 == 0, ln_out + head
+ * (rwkv.cu:585-589) when l1 == L.  x is the residual vector handed between stages (f64[D], in/out).
+ * Same arithmetic as oracle_forward with T = 1; used to check the layer-pipeline host logic. ---- */
+int oracle_stage_forward(const oracle_model *m, uint64_t token, double *x, uint64_t l0, uint64_t l1,
+                         double **state, uint64_t slot, float *logits)
+{
+    const uint64_t L = m->L, D = m->D;
+    const double *ln = (const double *)m->t[LAYERNORMS];
+    if (l0 >= l1 || l1 > L) return -3;
+    const uint64_t so = slot * L * D;
+    double *sxy = state[0] + so, *saa = state[1] + so, *sbb = state[2] + so, *spp = state[3] + so, *sdd = state[4] + so;
+    double *buffer1 = (double *)malloc(8 * D), *ffnk_in = (double *)malloc(8 * D), *ffnr_in = (double *)malloc(8 * D);
+    float *buffer2 = (float *)malloc(4 * (D > V_SIZE ? D : V_SIZE)), *buffer3 = (float *)malloc(4 * D), *buffer4 = (float *)malloc(4 * D);
+    float *ffnrbuffer = (float *)malloc(4 * 4 * D), mean, var;
+    if (l0 == 0) {
+        if (token >= V_SIZE) return -2;
+        const float *embed = (const float *)m->t[EMBED];
+        for (uint64_t i = 0; i < D; i++) buffer1[i] = (double)embed[token * D + i];
+        oracle_meanvar(D, buffer1, 1, &mean, &var);
+        oracle_layernorm(D, buffer1, ln, 0, &mean, &var, x, 1);
+    }
+    for (uint64_t l = l0; l < l1; l++) {
+        oracle_meanvar(D, x, 1, &mean, &var);
+        oracle_layernorm(D, x, ln, 4 * l + 2, &mean, &var, buffer1, 1);
+        oracle_mixatt(D, buffer1, sxy, (const double *)m->t[MIXK], (const double *)m->t[MIXV], (const double *)m->t[MIXR],
+                      ffnrbuffer, l, L, 1, MODE_GPT);
+        memset(buffer2, 0, 4 * D); memset(buffer3, 0, 4 * D); memset(buffer4, 0, 4 * D);
+        oracle_mm8_three(D, ffnrbuffer, (const uint8_t *)m->t[KM], (const uint8_t *)m->t[VM], (const uint8_t *)m->t[RM],
+                         (const float *)m->t[KR], (const float *)m->t[VR], (const float *)m->t[RR],
+                         (const float *)m->t[O1], (const float *)m->t[O2], (const float *)m->t[O3], buffer2, buffer3, buffer4, l, 1);
+        oracle_wkv(D, (const double *)m->t[DECAY], (const double *)m->t[BONUS], buffer2, buffer3, buffer4, buffer1, saa, sbb, spp, l, L, 1, MODE_GPT);
+        for (uint64_t i = 0; i < D; i++) buffer2[i] = (float)x[i];
+        oracle_mm8_one_f64(D, D, buffer1, (const uint8_t *)m->t[ATTOUT], buffer2, (const float *)m->t[ATTOUTR], (const float *)m->t[ATTOUTO], l, 1);
+        for (uint64_t i = 0; i < D; i++) x[i] = (double)buffer2[i];
+        oracle_meanvar(D, x, 1, &mean, &var);
+        oracle_layernorm(D, x, ln, 4 * (l + 1), &mean, &var, buffer1, 1);
+        oracle_mixffn(D, buffer1, sdd, (const double *)m->t[FFNMIXK], (const double *)m->t[FFNMIXV], ffnk_in, ffnr_in, l, L, 1, MODE_GPT);
+        memset(buffer2, 0, 4 * D);
+        oracle_mm8_one_f64(D, D, ffnr_in, (const uint8_t *)m->t[FFNR], buffer2, (const float *)m->t[FFNRR], (const float *)m->t[FFNRO], l, 1);
+        for (uint64_t i = 0; i < D; i++) buffer4[i] = (float)(1.0 / (1.0 + exp(-(double)buffer2[i])));
+        memset(ffnrbuffer, 0, 4 * 4 * D);
+        oracle_mm8_one_f64(D, 4 * D, ffnk_in, (const uint8_t *)m->t[FFNK], ffnrbuffer, (const float *)m->t[FFNKR], (const float *)m->t[FFNKO], l, 1);
+        for (uint64_t i = 0; i < 4 * D; i++) { float a = ffnrbuffer[i]; a = a * (float)(a > 0); ffnrbuffer[i] = a * a; }
+        memset(buffer3, 0, 4 * D);
+        oracle_mm8_one_f32(4 * D, D, ffnrbuffer, (const uint8_t *)m->t[FFNV], buffer3, (const float *)m->t[FFNVR], (const float *)m->t[FFNVO], l, 1);
+        for (uint64_t i = 0; i < D; i++) x[i] = x[i] + (double)(buffer3[i] * buffer4[i]);
+    }
+    if (l1 == L && logits) {
+        oracle_meanvar(D, x, 1, &mean, &var);
+        oracle_layernorm(D, x, ln, 4 * L + 2, &mean, &var, buffer1, 1);
+        memset(buffer2, 0, 4 * V_SIZE);
+        oracle_mm8_one_f64(D, V_SIZE, buffer1, (const uint8_t *)m->t[HEAD], buffer2, (const float *)m->t[HEADR], (const float *)m->t[HEADO], 0, 1);
+        memcpy(logits, buffer2, 4 * V_SIZE);
+    }
+    free(buffer1); free(ffnk_in); free(ffnr_in); free(buffer2); free(buffer3); free(buffer4); free(ffnrbuffer);
+    return 0;
+}

@@ -85,6 +85,7 @@ struct rwkv_ctx {
     int grid = 256;          // workgroups per launch = compute units
     bool loaded = false;
     uint64_t L = 0, D = 0, maxT = 1;
+    uint64_t l0 = 0, l1 = UINT64_MAX;   // pipeline stage: this context owns layers [l0, l1) (whole model by default)
     int S = 0;               // ceil(D / 1024): 1 KiB row pieces per lane
 
     // weights (device)
@@ -164,7 +165,7 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
     case 1: {
         AttArgs aa;
         aa.x = c->x; aa.pk = c->pk_att + lo * 3;
-        aa.w = c->w_kvr + (size_t)l * 3 * D * D; aa.rs = c->rs_kvr + lo * 3;
+        aa.w = c->w_kvr + (size_t)(l - c->l0) * 3 * D * D; aa.rs = c->rs_kvr + (size_t)(l - c->l0) * D * 3;
         aa.uw = c->uw + lo; aa.ew = c->ew + lo;
         aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
         aa.sxy = c->state[0] + lo; aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
@@ -174,23 +175,23 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
     } break;
     case 2: {
         AttOutArgs ao;
-        ao.w = c->w_att + (size_t)l * D * D; ao.rs = c->rs_att + lo; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.n_part = grid;
+        ao.w = c->w_att + (size_t)(l - c->l0) * D * D; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.n_part = grid;
         ao.x = c->x; ao.xx_buf = c->xx1; ao.sxy = c->state[0] + lo; ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D;
         DISPATCH_S(S, k_attout<S_, ATTOUT_R><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
     } break;
     case 3: {
         FfnRKArgs fa;
         fa.x = c->x; fa.pk = c->pk_ffn + lo * 2;
-        fa.w = c->w_frk + (size_t)l * 5 * D * D; fa.rs = c->rs_frk + lo * 5;
+        fa.w = c->w_frk + (size_t)(l - c->l0) * 5 * D * D; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5;
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.sdd = c->state[4] + lo; fa.slot_stride = LD; fa.xx_buf = c->xx2;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.ctl = c->ctl; fa.D = D;
-        fa.tl = (c->tl_on && l == L / 2) ? c->tl : nullptr;
+        fa.tl = (c->tl_on && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr;
         DISPATCH_S(S, k_ffn_rk<S_><<<dim3(grid), dim3(NT), smem_frk(S, gpb), c->stream>>>(fa));
     } break;
     case 4: {
         FfnVArgs fv;
-        fv.w = c->w_fv + (size_t)l * 4 * D * D; fv.rs = c->rs_fv + lo; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.n_part = grid;
+        fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.n_part = grid;
         fv.rgate = c->rgate; fv.x = c->x; fv.xx_buf = c->xx2; fv.sdd = c->state[4] + lo;
         fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D;
         DISPATCH_S(S, k_ffnv<S_><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
@@ -210,17 +211,17 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
 // (4L + 4) events recorded before each launch and after the last (profiling).
 int enqueue_token(rwkv_ctx *c, bool with_argmax, hipEvent_t *ev)
 {
-    const uint64_t L = c->L;
+    const bool first = c->l0 == 0, last = c->l1 == c->L;
     int evi = 0;
 #define EV() do { if (ev) HIPCHK(hipEventRecord(ev[evi++], c->stream)); } while (0)
     EV();
-    launch_class(c, 0, 0);
-    for (uint64_t l = 0; l < L; l++)
+    if (first) launch_class(c, 0, 0);
+    for (uint64_t l = c->l0; l < c->l1; l++)
         for (int cls = 1; cls <= 4; cls++) { EV(); launch_class(c, cls, l); }
     EV();
-    launch_class(c, 5, 0);
+    if (last) launch_class(c, 5, 0);
     EV();
-    if (with_argmax) launch_class(c, 6, 0);
+    if (last && with_argmax) launch_class(c, 6, 0);
     EV();
 #undef EV
     HIPCHK(hipGetLastError());
@@ -292,11 +293,15 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if (max_ctx == 0) max_ctx = 1;
     HIPCHK(hipSetDevice(c->device));
     c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
+    if (c->l1 == UINT64_MAX) c->l1 = L;
+    if (c->l0 >= c->l1 || c->l1 > L) return fail(RWKV_E_ARG, "layer range [%llu, %llu) does not fit a %llu-layer model", (unsigned long long)c->l0, (unsigned long long)c->l1, (unsigned long long)L);
+    const uint64_t l0 = c->l0, l1 = c->l1, nl = l1 - l0;
+    const bool first = l0 == 0, last = l1 == L;
     const uint64_t V = RWKV_VOCAB;
     int rc;
 
     // vectors: as-is
-    if ((rc = upload(c, src, EMBED, &c->embed))) return rc;
+    if (first && (rc = upload(c, src, EMBED, &c->embed))) return rc;   // the table lives on the first stage only
     if ((rc = upload(c, src, LAYERNORMS, &c->ln))) return rc;
     if ((rc = upload(c, src, MIXK, &c->mixk))) return rc;
     if ((rc = upload(c, src, MIXV, &c->mixv))) return rc;
@@ -345,39 +350,39 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     }
 
     // uint8 matrices: re-tile to row-per-output
-    if ((rc = dalloc(c, &c->w_kvr, L * 3 * D * D))) return rc;
-    if ((rc = dalloc(c, &c->w_att, L * D * D))) return rc;
-    if ((rc = dalloc(c, &c->w_frk, L * 5 * D * D))) return rc;
-    if ((rc = dalloc(c, &c->w_fv, L * 4 * D * D))) return rc;
-    if ((rc = dalloc(c, &c->w_head, V * D))) return rc;
+    if ((rc = dalloc(c, &c->w_kvr, nl * 3 * D * D))) return rc;
+    if ((rc = dalloc(c, &c->w_att, nl * D * D))) return rc;
+    if ((rc = dalloc(c, &c->w_frk, nl * 5 * D * D))) return rc;
+    if ((rc = dalloc(c, &c->w_fv, nl * 4 * D * D))) return rc;
+    if (last && (rc = dalloc(c, &c->w_head, V * D))) return rc;
     uint8_t *staging = nullptr;
     if (!src.on_device) HIPCHK(hipMalloc(reinterpret_cast<void **>(&staging), std::max<uint64_t>(4 * D * D, V * D)));
-    for (uint64_t l = 0; l < L && !rc; l++) {
-        uint8_t *kvr = c->w_kvr + l * 3 * D * D, *frk = c->w_frk + l * 5 * D * D;
+    for (uint64_t l = l0; l < l1 && !rc; l++) {
+        uint8_t *kvr = c->w_kvr + (l - l0) * 3 * D * D, *frk = c->w_frk + (l - l0) * 5 * D * D;
         if (!rc) rc = retile(c, src, KM, l, D, D, kvr, 1, 3, 0, staging);
         if (!rc) rc = retile(c, src, VM, l, D, D, kvr, 1, 3, 1, staging);
         if (!rc) rc = retile(c, src, RM, l, D, D, kvr, 1, 3, 2, staging);
-        if (!rc) rc = retile(c, src, ATTOUT, l, D, D, c->w_att + l * D * D, 1, 1, 0, staging);
+        if (!rc) rc = retile(c, src, ATTOUT, l, D, D, c->w_att + (l - l0) * D * D, 1, 1, 0, staging);
         if (!rc) rc = retile(c, src, FFNK, l, D, 4 * D, frk, 4, 5, 0, staging);
         if (!rc) rc = retile(c, src, FFNR, l, D, D, frk, 1, 5, 4, staging);
-        if (!rc) rc = retile(c, src, FFNV, l, 4 * D, D, c->w_fv + l * 4 * D * D, 1, 1, 0, staging);
+        if (!rc) rc = retile(c, src, FFNV, l, 4 * D, D, c->w_fv + (l - l0) * 4 * D * D, 1, 1, 0, staging);
     }
-    if (!rc) rc = retile(c, src, HEAD, 0, D, V, c->w_head, 1, 1, 0, staging);
+    if (!rc && last) rc = retile(c, src, HEAD, 0, D, V, c->w_head, 1, 1, 0, staging);
     // row sums of the re-tiled matrices (the 2^23 offset of the activation limbs is removed with them)
-    if (!rc) rc = dalloc(c, &c->rs_kvr, L * 3 * D);
-    if (!rc) rc = dalloc(c, &c->rs_att, L * D);
-    if (!rc) rc = dalloc(c, &c->rs_frk, L * 5 * D);
-    if (!rc) rc = dalloc(c, &c->rs_fv, L * D);
+    if (!rc) rc = dalloc(c, &c->rs_kvr, nl * 3 * D);
+    if (!rc) rc = dalloc(c, &c->rs_att, nl * D);
+    if (!rc) rc = dalloc(c, &c->rs_frk, nl * 5 * D);
+    if (!rc) rc = dalloc(c, &c->rs_fv, nl * D);
     if (!rc) rc = dalloc(c, &c->rs_head, V);
     if (!rc) {
         auto rowsum = [&](const uint8_t *w, unsigned *rs, uint64_t rows, uint64_t N) {
             k_rowsum<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream>>>(w, rs, (size_t)rows, (int)N);
         };
-        rowsum(c->w_kvr, c->rs_kvr, L * 3 * D, D);
-        rowsum(c->w_att, c->rs_att, L * D, D);
-        rowsum(c->w_frk, c->rs_frk, L * 5 * D, D);
-        rowsum(c->w_fv, c->rs_fv, L * D, 4 * D);
-        rowsum(c->w_head, c->rs_head, V, D);
+        rowsum(c->w_kvr, c->rs_kvr, nl * 3 * D, D);
+        rowsum(c->w_att, c->rs_att, nl * D, D);
+        rowsum(c->w_frk, c->rs_frk, nl * 5 * D, D);
+        rowsum(c->w_fv, c->rs_fv, nl * D, 4 * D);
+        if (last) rowsum(c->w_head, c->rs_head, V, D);
     }
     hipError_t se = hipStreamSynchronize(c->stream);
     if (staging) (void)hipFree(staging);
@@ -454,6 +459,15 @@ int rwkv_create(rwkv_ctx **out, int device)
     return 0;
 }
 
+int rwkv_set_layer_range(rwkv_ctx *c, uint64_t l0, uint64_t l1)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    if (c->loaded) return fail(RWKV_E_STATE, "RWKV already loaded");
+    if (l0 >= l1) return fail(RWKV_E_ARG, "empty layer range");
+    c->l0 = l0; c->l1 = l1;
+    return 0;
+}
+
 int rwkv_load_file(rwkv_ctx *c, const char *path, uint64_t max_ctx)
 {
     if (!c || !path) return fail(RWKV_E_ARG, "NULL argument");
@@ -508,6 +522,25 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
+
+int rwkv_stage_forward(rwkv_ctx *c, uint64_t token, uint32_t slot, uint64_t *pick)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (slot >= c->maxT) return fail(RWKV_E_ARG, "state slot %u out of range (max context %llu)", slot, (unsigned long long)c->maxT);
+    if (c->l0 == 0 && token >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
+    HIPCHK(hipSetDevice(c->device));
+    c->h_ctl[0].token = token; c->h_ctl[0].slot = slot; c->h_ctl[0].out_row = slot; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
+    HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+    const bool last = c->l1 == c->L;
+    int rc = run_token(c, last && pick != nullptr);
+    if (rc) return rc;
+    if (last && pick) HIPCHK(hipMemcpyAsync(pick, c->gen, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+double *rwkv_x_device(rwkv_ctx *c) { return c ? c->x : nullptr; }
 
 int rwkv_set_state(rwkv_ctx *c, const double *xy, const double *aa, const double *bb, const double *pp,
                    const double *dd, uint64_t n_slots)
@@ -589,8 +622,8 @@ void *rwkv_stream(rwkv_ctx *c) { return c ? (void *)c->stream : nullptr; }
 uint64_t rwkv_bytes_per_token(const rwkv_ctx *c)
 {
     if (!c) return 0;
-    const uint64_t L = c->L, D = c->D, V = RWKV_VOCAB;
-    return 13 * L * D * D + V * D + 168 * L * D + 40 * D;
+    const uint64_t nl = (c->l1 == UINT64_MAX ? c->L : c->l1) - c->l0, D = c->D, V = RWKV_VOCAB;
+    return 13 * nl * D * D + (c->l1 == c->L || c->l1 == UINT64_MAX ? V * D : 0) + 168 * nl * D + 40 * D;   // SURVEY.md section 8(d), this stage's share
 }
 
 int rwkv_profile_token(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint64_t *bytes, uint32_t *launches)
@@ -600,7 +633,7 @@ int rwkv_profile_token(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint64
     if (token >= RWKV_VOCAB || reps <= 0) return fail(RWKV_E_ARG, "bad token / reps");
     HIPCHK(hipSetDevice(c->device));
     const uint64_t L = c->L, D = c->D, V = RWKV_VOCAB;
-    const int nev = (int)(4 * L + 4);
+    const int nev = (int)(4 * (c->l1 - c->l0) + 4);
     std::vector<hipEvent_t> ev(nev);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     for (int k = 0; k < RWKV_N_KCLASS; k++) ms[k] = 0.0;
@@ -614,10 +647,11 @@ int rwkv_profile_token(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint64
         for (int i = 0; i + 1 < nev; i++) {
             float t = 0.f;
             if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) != hipSuccess) { rc = fail(RWKV_E_DEVICE, "hipEventElapsedTime failed"); break; }
+            const int nlay = (int)(c->l1 - c->l0);
             int cls;
             if (i == 0) cls = 0;
-            else if (i <= (int)(4 * L)) cls = 1 + (i - 1) % 4;
-            else if (i == (int)(4 * L + 1)) cls = 5;
+            else if (i <= 4 * nlay) cls = 1 + (i - 1) % 4;
+            else if (i == 4 * nlay + 1) cls = 5;
             else cls = 6;
             ms[cls] += (double)t;
         }
@@ -628,7 +662,7 @@ int rwkv_profile_token(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint64
         bytes[5] = V * D; bytes[6] = 0;
     }
     if (launches) {
-        launches[0] = 1; launches[1] = launches[2] = launches[3] = launches[4] = (uint32_t)L; launches[5] = 1; launches[6] = 1;
+        launches[0] = 1; launches[1] = launches[2] = launches[3] = launches[4] = (uint32_t)(c->l1 - c->l0); launches[5] = 1; launches[6] = 1;
     }
     return rc;
 }
@@ -654,7 +688,7 @@ int rwkv_profile_batched(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint
         HIPCHK(hipEventRecord(a, c->stream));
         uint32_t cnt = 0;
         for (int r = 0; r < reps; r++)
-            for (uint64_t l = 0; l < (per_layer ? c->L : 1); l++) { launch_class(c, cls, l); cnt++; }
+            for (uint64_t l = (per_layer ? c->l0 : 0); l < (per_layer ? c->l1 : 1); l++) { launch_class(c, cls, l); cnt++; }
         HIPCHK(hipEventRecord(b, c->stream));
         HIPCHK(hipEventSynchronize(b));
         float t = 0.f;

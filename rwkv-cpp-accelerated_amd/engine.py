@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "rwkv_create", "rwkv_load_file", "rwkv_load_tensors", "rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx",
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
-    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched",
+    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device",
 ]
 
 _lib = None
@@ -62,6 +62,9 @@ def lib():
     L.rwkv_profile_token.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(C.c_uint32)]
     L.rwkv_profile_token.restype = i32
     L.rwkv_mm8_one.argtypes = [vp, u64, u64, vp, vp, vp, vp, vp]; L.rwkv_mm8_one.restype = i32
+    L.rwkv_set_layer_range.argtypes = [vp, u64, u64]; L.rwkv_set_layer_range.restype = i32
+    L.rwkv_stage_forward.argtypes = [vp, u64, C.c_uint32, C.POINTER(u64)]; L.rwkv_stage_forward.restype = i32
+    L.rwkv_x_device.argtypes = [vp]; L.rwkv_x_device.restype = vp
     L.rwkv_profile_batched.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]; L.rwkv_profile_batched.restype = i32
     L.rwkv_debug_timeline.argtypes = [vp, u64, vp, u64]; L.rwkv_debug_timeline.restype = i32
     _lib = L
@@ -175,6 +178,18 @@ class RWKV:
             torch.cuda.synchronize()
         _chk(lib().rwkv_load_tensors(self._h, n_layers, n_embed, ptrs, 1 if on_device else 0, maxGPT))
         self._after_load()
+
+    # -- layer pipeline ---------------------------------------------------------------------
+    def set_layer_range(self, l0: int, l1: int):
+        _chk(lib().rwkv_set_layer_range(self._h, l0, l1))
+
+    def stage_forward(self, token: int, slot: int = 0, want_pick: bool = False):
+        pick = C.c_uint64(0)
+        _chk(lib().rwkv_stage_forward(self._h, int(token), slot, C.byref(pick) if want_pick else None))
+        return int(pick.value) if want_pick else None
+
+    def x_device_ptr(self) -> int:
+        return int(lib().rwkv_x_device(self._h) or 0)
 
     # -- state sync --------------------------------------------------------------------------
     def push_state(self, n_slots: int | None = None):

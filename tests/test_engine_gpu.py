@@ -185,3 +185,35 @@ def test_full_size_properties_7b_layer(eng_mod):
     err = (ys[2] - ys[0] - ys[1]).abs().max().item()
     assert err <= 1e-4 * ys[2].abs().max().item()
     m.close()
+
+
+def test_pipeline_virtual_stages_equal_full_model(eng_mod):
+    """layer pipeline with all stages co-located on one GPU (same code path as the multi-GPU run minus
+    the RCCL hop): chaining the stage contexts reproduces the full model's greedy ids and logits"""
+    import torch
+    from rwkv_cpp_accelerated_amd import pipeline
+    L, D, n = 6, 768, 6
+    t = mf.synthetic_tensors(L, D, seed=55)
+    full = eng_mod.RWKV(resident=True); full.loadTensors(L, D, t, maxGPT=2)
+    parts = pipeline.partition_layers(L, 3, D)
+    stages = [pipeline.EngineStage(t, L, D, l0, l1, n_slots=2) for l0, l1 in parts]
+    assert stages[0].first and stages[-1].last and not stages[1].first and not stages[1].last
+    for slot, tk0 in ((0, 17), (1, 4242)):          # two independent streams on two state slots
+        tk_p = tk_f = tk0
+        for step in range(n):
+            lg = full.forward([0] * slot + [tk_f], eng_mod.MODE_PARRALEL) if False else None
+            # full model on the same slot: PARRALEL call with `slot+1` tokens would touch other slots, so use stage API
+            tk_f = full.stage_forward(tk_f, slot, want_pick=True)
+            for i, st in enumerate(stages):
+                if i > 0:
+                    st.x.copy_(stages[i - 1].x); torch.cuda.synchronize()
+                tk_p_next = st.forward(tk_p, slot, want_pick=st.last)
+            tk_p = tk_p_next
+            assert tk_p == tk_f, (slot, step)
+            a = full.logits(2)[slot * mf.VOCAB:(slot + 1) * mf.VOCAB].copy()
+            b = stages[-1].m.logits(2)[slot * mf.VOCAB:(slot + 1) * mf.VOCAB].copy()
+            assert np.array_equal(a, b)            # bit-identical: same kernels, same data
+    assert stages[1].m.bytes_per_token() == 13 * (parts[1][1] - parts[1][0]) * D * D + 168 * (parts[1][1] - parts[1][0]) * D + 40 * D
+    for s in stages:
+        s.m.close()
+    full.close()
