@@ -101,7 +101,7 @@ struct rwkv_ctx {
     // state + scratch (device)
     double *state[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double *x = nullptr, *xx1 = nullptr, *xx2 = nullptr, *partA = nullptr, *partF = nullptr;
-    float *ybuf = nullptr, *hbuf = nullptr, *rgate = nullptr, *logits = nullptr, *blk_val = nullptr;
+    float *ybuf = nullptr, *hbuf = nullptr, *rgate = nullptr, *logits = nullptr, *blk_val = nullptr, *partMA = nullptr, *partMF = nullptr;
     unsigned *blk_idx = nullptr;
     Ctl *ctl = nullptr;
     Ctl *h_ctl = nullptr;    // pinned staging, maxT entries
@@ -110,6 +110,7 @@ struct rwkv_ctx {
     hipGraphExec_t g_fwd = nullptr, g_greedy = nullptr;
     unsigned long long *tl = nullptr;   // phase-timeline buffer (debug), [grid][NW][8]
     bool tl_on = false;
+    bool ring = false;                  // loader/consumer (LDS ring) variant of the dominant kernel
     std::vector<void *> allocs;
 };
 
@@ -128,6 +129,8 @@ template <typename T> int dalloc(rwkv_ctx *c, T **p, size_t count)
 size_t smem_att(int S, int gpb) { return RED_BYTES + 3 * (size_t)S * 3072 + (size_t)gpb * 3 * 4; }
 size_t smem_attout(int S) { return RED_BYTES + (size_t)S * 3072; }
 size_t smem_frk(int S, int gpb) { return RED_BYTES + 2 * (size_t)S * 3072 + (size_t)gpb * 5 * 4; }
+constexpr int RING_SLOTS_FRK = 5;
+size_t smem_frk_ring(int S, int gpb, int D) { return 128 + RED_BYTES + 2 * (size_t)S * 3072 + (size_t)((gpb * 5 + 3) & ~3) * 4 + (size_t)RING_SLOTS_FRK * 5 * D; }
 size_t smem_fv(int S) { return RED_BYTES + 4 * (size_t)S * 3072; }
 size_t smem_head(int S) { return RED_BYTES + (size_t)S * 3072 + NW * 8; }
 
@@ -169,13 +172,13 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         aa.uw = c->uw + lo; aa.ew = c->ew + lo;
         aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
         aa.sxy = c->state[0] + lo; aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
-        aa.slot_stride = LD; aa.xx_buf = c->xx1; aa.ybuf = c->ybuf; aa.partS = c->partA;
+        aa.slot_stride = LD; aa.xx_buf = c->xx1; aa.ybuf = c->ybuf; aa.partS = c->partA; aa.partM = c->partMA;
         aa.ctl = c->ctl; aa.D = D;
         DISPATCH_S(S, k_att<S_><<<dim3(grid), dim3(NT), smem_att(S, gpb), c->stream>>>(aa));
     } break;
     case 2: {
         AttOutArgs ao;
-        ao.w = c->w_att + (size_t)(l - c->l0) * D * D; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.n_part = grid;
+        ao.w = c->w_att + (size_t)(l - c->l0) * D * D; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
         ao.x = c->x; ao.xx_buf = c->xx1; ao.sxy = c->state[0] + lo; ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D;
         DISPATCH_S(S, k_attout<S_, ATTOUT_R><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
     } break;
@@ -185,13 +188,14 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         fa.w = c->w_frk + (size_t)(l - c->l0) * 5 * D * D; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5;
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.sdd = c->state[4] + lo; fa.slot_stride = LD; fa.xx_buf = c->xx2;
-        fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.ctl = c->ctl; fa.D = D;
+        fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.partM = c->partMF; fa.ctl = c->ctl; fa.D = D;
         fa.tl = (c->tl_on && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr;
-        DISPATCH_S(S, k_ffn_rk<S_><<<dim3(grid), dim3(NT), smem_frk(S, gpb), c->stream>>>(fa));
+        if (c->ring) { DISPATCH_S(S, k_ffn_rk_ring<S_, RING_SLOTS_FRK><<<dim3(grid), dim3(NT), smem_frk_ring(S, gpb, D), c->stream>>>(fa)); }
+        else { DISPATCH_S(S, k_ffn_rk<S_><<<dim3(grid), dim3(NT), smem_frk(S, gpb), c->stream>>>(fa)); }
     } break;
     case 4: {
         FfnVArgs fv;
-        fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.n_part = grid;
+        fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
         fv.rgate = c->rgate; fv.x = c->x; fv.xx_buf = c->xx2; fv.sdd = c->state[4] + lo;
         fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D;
         DISPATCH_S(S, k_ffnv<S_><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
@@ -279,6 +283,7 @@ int set_smem_limits(rwkv_ctx *c)
     DISPATCH_S(S, rc = allow_smem(k_att<S_>, smem_att(S, gpb))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R>, smem_attout(S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_>, smem_frk(S, gpb))); if (rc) return rc;
+    if (c->ring) { DISPATCH_S(S, rc = allow_smem(k_ffn_rk_ring<S_, RING_SLOTS_FRK>, smem_frk_ring(S, gpb, (int)c->D))); if (rc) return rc; }
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_>, smem_fv(S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_head<S_>, smem_head(S))); if (rc) return rc;
     return 0;
@@ -403,6 +408,8 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if ((rc = dalloc(c, &c->rgate, D))) return rc;
     if ((rc = dalloc(c, &c->partA, (size_t)c->grid))) return rc;
     if ((rc = dalloc(c, &c->partF, (size_t)c->grid))) return rc;
+    if ((rc = dalloc(c, &c->partMA, (size_t)c->grid))) return rc;
+    if ((rc = dalloc(c, &c->partMF, (size_t)c->grid))) return rc;
     if ((rc = dalloc(c, &c->blk_val, (size_t)c->grid))) return rc;
     if ((rc = dalloc(c, &c->blk_idx, (size_t)c->grid))) return rc;
     if ((rc = dalloc(c, &c->logits, max_ctx * V))) return rc;
@@ -453,6 +460,8 @@ int rwkv_create(rwkv_ctx **out, int device)
     const char *g = getenv("RWKV_GRID");
     if (g && atoi(g) > 0) c->grid = atoi(g);
     if (c->grid > NT) c->grid = NT;   // consumers sum one partial per thread
+    const char *rg = getenv("RWKV_RING");
+    c->ring = rg && rg[0] == '1';
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(RWKV_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = c;

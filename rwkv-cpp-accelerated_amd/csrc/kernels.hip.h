@@ -58,21 +58,46 @@ struct Ctl {
     unsigned int pad;
 };
 
+// 64-lane reductions run on the DPP network (VALU-latency steps) instead of six dependent
+// ds_bpermute round trips through the LDS crossbar per reduction: xor-1 / xor-2 inside quads,
+// rotate by 4 and 8 inside each row of 16, then row_bcast:15 / row_bcast:31 fold the four rows into
+// lane 63; readlane makes the result wave-uniform.  Lanes disabled by a row mask read 0 (`old`).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, BOUND);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, BOUND);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_f64<0xB1, 0xf, true>(v);
+    v += dpp_f64<0x4E, 0xf, true>(v);
+    v += dpp_f64<0x124, 0xf, true>(v);
+    v += dpp_f64<0x128, 0xf, true>(v);
+    v += dpp_f64<0x142, 0xa, false>(v);
+    v += dpp_f64<0x143, 0xc, false>(v);
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_f32(float v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
 }
-// 64-lane sum on the DPP network (VALU-latency steps instead of six dependent ds_bpermute round
-// trips through the LDS crossbar): xor-1/xor-2 inside quads, rotate by 4 and 8 inside each row of
-// 16, then row_bcast:15 / row_bcast:31 fold the four rows into lane 63; readlane makes it uniform.
+// max of NON-NEGATIVE values (disabled lanes contribute 0)
+__device__ __forceinline__ float wave_max(float v)
+{
+    v = fmaxf(v, dpp_f32<0xB1, 0xf, true>(v));
+    v = fmaxf(v, dpp_f32<0x4E, 0xf, true>(v));
+    v = fmaxf(v, dpp_f32<0x124, 0xf, true>(v));
+    v = fmaxf(v, dpp_f32<0x128, 0xf, true>(v));
+    v = fmaxf(v, dpp_f32<0x142, 0xa, false>(v));
+    v = fmaxf(v, dpp_f32<0x143, 0xc, false>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ unsigned wave_sum_dpp(unsigned v)
 {
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
@@ -83,14 +108,10 @@ __device__ __forceinline__ unsigned wave_sum_dpp(unsigned v)
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
-}
 
-// workgroup-wide sum of K doubles; every thread gets the totals.  `red` = NW*K doubles of LDS.
+// workgroup-wide sum of K doubles; every thread gets the totals.  `red` = NW*K doubles of LDS that no
+// later reduction of the same kernel reuses before all waves have read them (callers hand out
+// distinct regions of the 1 KiB scratch), so ONE barrier per reduction.
 template <int K>
 __device__ __forceinline__ void block_sum(double (&v)[K], double *red)
 {
@@ -109,9 +130,8 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *red)
         for (int i = 0; i < NW; i++) s += red[i * K + k];
         v[k] = s;
     }
-    __syncthreads();
 }
-// workgroup-wide max of K floats
+// workgroup-wide max of K floats (same scratch discipline)
 template <int K>
 __device__ __forceinline__ void block_max(float (&v)[K], double *redd)
 {
@@ -131,8 +151,9 @@ __device__ __forceinline__ void block_max(float (&v)[K], double *redd)
         for (int i = 0; i < NW; i++) s = fmaxf(s, red[i * K + k]);
         v[k] = s;
     }
-    __syncthreads();
 }
+// scratch regions (in doubles) of the RED_BYTES block: NW*K <= 24 doubles each
+constexpr int RED_STATS = 0, RED_MAX = 24, RED_OFFS = 48, RED_PART = 72, RED_AUX = 96;
 
 // ------------------------------------------------------------------------------------------
 // Staged activation vectors.  Element j of a vector belongs to the 16-element piece c = j/16,
@@ -231,7 +252,7 @@ template <int S> __device__ __forceinline__ constexpr int pre_steps() { return R
 //    and wait for the refill itself; two template copies in sibling branches get their common
 //    code hoisted and spilled): after a wave's LAST group, `next_valid` = false degrades the refill
 //    to R*S loads of one and the same 16-byte piece (one L1-resident line), which nobody waits for.
-template <int R, int S, int PAT>
+template <int R, int S, int PAT, bool REFILL = true>
 __device__ __forceinline__ void group_dot(u32x4 (&w)[R][S], const unsigned *xq, int lane, unsigned long long (&T)[R],
                                           const uint8_t *__restrict__ next, size_t stride, int chunks, bool next_valid)
 {
@@ -268,7 +289,7 @@ __device__ __forceinline__ void group_dot(u32x4 (&w)[R][S], const unsigned *xq, 
                 asm volatile("" : "+v"(acc[r][0]), "+v"(acc[r][1]), "+v"(acc[r][2]));
             }
         __builtin_amdgcn_sched_barrier(0);
-        if (v == NV - 1) {
+        if (REFILL && v == NV - 1) {
             step_load<R, S>(w, s, next, nstride, chunks, lane, mask);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -321,7 +342,7 @@ __device__ __forceinline__ void ln_stats(const double (&xl)[NQ][4], int D, doubl
             s[1] += v * v;
         }
     }
-    block_sum<2>(s, red);
+    block_sum<2>(s, red + RED_STATS);
     mean = s[0] / (double)D;
     const double var = (s[1] - s[0] * mean) / (double)(D - 1);
     rstd = 1.0 / sqrt(var);
@@ -368,6 +389,7 @@ struct AttArgs {
     double *xx_buf;                       // [D] ln1 output, committed to sxy by k_attout
     float *ybuf;                          // [D] gated wkv * r_att (input vector of k_attout)
     double *partS;                        // [gridDim.x] partial sums of gated wkv * o_att
+    float *partM;                         // [gridDim.x] partial max |ybuf| (k_attout's quantisation scale)
     const Ctl *ctl;
     int D;
 };
@@ -432,11 +454,11 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
                 Ssum[0] += (double)(fk * P[i][e][2][0]); Ssum[1] += (double)(fv * P[i][e][2][1]); Ssum[2] += (double)(fr * P[i][e][2][2]);
 #pragma unroll
                 for (int m = 0; m < 3; m++) amax[m] = fmaxf(amax[m], fabsf(xr[i][m][e]));
-                if (blockIdx.x == 0) a.xx_buf[qd * 4 + e] = xx;
+                if (qd * 4 + e >= g0 && qd * 4 + e < g1) a.xx_buf[qd * 4 + e] = xx;   // every workgroup publishes the channels it owns (not one straggler all of them)
             }
         }
     }
-    block_max<3>(amax, red);
+    block_max<3>(amax, red + RED_MAX);
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
         const int qd = threadIdx.x + i * NT;
@@ -462,10 +484,11 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
         for (int m = 0; m < 3; m++)
             if (lane == m) stash[(g - g0) * 3 + m] = row_value(T[m], rsum, sc[m]);
     }
-    block_sum<3>(Ssum, red);   // offset terms: only needed by the epilogue (also the barrier before it)
+    block_sum<3>(Ssum, red + RED_OFFS);   // offset terms: only needed by the epilogue (also the barrier before it)
 
     // WKV recurrence + receptance gate, one lane per channel (rwkv.cu:242-255)
     double part[1] = {0.0};
+    float pmax[1] = {0.f};
     if ((int)threadIdx.x < g1 - g0) {
         const int i = g0 + threadIdx.x;
         const float k = stash[threadIdx.x * 3 + 0] + (float)Ssum[0], v = stash[threadIdx.x * 3 + 1] + (float)Ssum[1],
@@ -479,11 +502,14 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
         a.saa[so + i] = (aa + ek * vv) * ew;
         a.sbb[so + i] = (bb + ek) * ew;
         const float yf = (float)y;                       // att_out GEMV casts its input to f32 (rwkv.cu:290)
-        a.ybuf[i] = yf * a.r_att[i];
+        const float ys = yf * a.r_att[i];
+        a.ybuf[i] = ys;
         part[0] = (double)(yf * a.o_att[i]);
+        pmax[0] = fabsf(ys);
     }
-    block_sum<1>(part, red);
-    if (threadIdx.x == 0) a.partS[blockIdx.x] = part[0];
+    block_sum<1>(part, red + RED_PART);
+    block_max<1>(pmax, red + RED_AUX);
+    if (threadIdx.x == 0) { a.partS[blockIdx.x] = part[0]; a.partM[blockIdx.x] = pmax[0]; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,6 +518,7 @@ struct AttOutArgs {
     const unsigned *rs;    // [D] row sums
     const float *ybuf;     // [D] pre-scaled input vector
     const double *partS;   // [n_part] partial offset sums (n_part <= NT)
+    const float *partM;    // [n_part] partial max |ybuf|
     int n_part;
     double *x;             // residual stream, updated in place (row-owned)
     const double *xx_buf;  // ln1 output of this token -> new state xy
@@ -523,6 +550,7 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
         yl[i][0] = t[0]; yl[i][1] = t[1]; yl[i][2] = t[2]; yl[i][3] = t[3];
     }
     double Ssum[1] = {a.partS[(int)threadIdx.x < a.n_part ? threadIdx.x : 0]};
+    float amax[1] = {a.partM[(int)threadIdx.x < a.n_part ? threadIdx.x : 0]};
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
 
     u32x4 w[R][S];
@@ -535,20 +563,25 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
     const uint8_t *wb = rowbase(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0));
     group_load<R, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
 
-    float amax[1] = {0.f};
+    // scale and offset come from the producer's per-workgroup partials: one reduction round
+    if ((int)threadIdx.x >= a.n_part) { Ssum[0] = 0.0; amax[0] = 0.f; }
+    {
+        float *redf = reinterpret_cast<float *>(red + RED_MAX);
+        const double ws = wave_sum(Ssum[0]);
+        const float wm = wave_max(amax[0]);
+        if (lane == 0) { red[RED_OFFS + wave] = ws; redf[wave] = wm; }
+        __syncthreads();
+        double ts = 0.0; float tm = 0.f;
 #pragma unroll
-    for (int i = 0; i < NQ; i++)
-        if ((int)(threadIdx.x + i * NT) < nqd)
-#pragma unroll
-            for (int e = 0; e < 4; e++) amax[0] = fmaxf(amax[0], fabsf(yl[i][e]));
-    block_max<1>(amax, red);
+        for (int i = 0; i < NW; i++) { ts += red[RED_OFFS + i]; tm = fmaxf(tm, redf[i]); }
+        Ssum[0] = ts; amax[0] = tm;
+    }
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
         const int qd = threadIdx.x + i * NT;
         if (qd < S * 256) stage_quad(xq, qd, yl[i], inv_scale(amax[0]), qd < nqd);
     }
-    if ((int)threadIdx.x >= a.n_part) Ssum[0] = 0.0;
-    block_sum<1>(Ssum, red);   // also the barrier that publishes the staged vector
+    __syncthreads();   // staged vector visible
     group_load<R, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
     const float Sf = (float)Ssum[0];
     const double sc = scale_of(amax[0]);
@@ -588,6 +621,7 @@ struct FfnRKArgs {
     float *hbuf;                      // [4D] relu^2(k) * r_fv
     float *rgate;                     // [D] sigmoid(r)
     double *partS;                    // [gridDim.x]
+    float *partM;                     // [gridDim.x] partial max |hbuf| (k_ffnv's quantisation scale)
     const Ctl *ctl;
     int D;
     unsigned long long *tl;           // optional phase timeline (see tl_stamp)
@@ -652,11 +686,11 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
             if (real) {
                 Ssum[0] += (double)(fk * P[i][e][1][1]); Ssum[1] += (double)(fr * P[i][e][1][3]);
                 amax[0] = fmaxf(amax[0], fabsf(xr[i][0][e])); amax[1] = fmaxf(amax[1], fabsf(xr[i][1][e]));
-                if (blockIdx.x == 0) a.xx_buf[qd * 4 + e] = xx;
+                if (qd * 4 + e >= g0 && qd * 4 + e < g1) a.xx_buf[qd * 4 + e] = xx;   // every workgroup publishes the channels it owns (not one straggler all of them)
             }
         }
     }
-    block_max<2>(amax, red);
+    block_max<2>(amax, red + RED_MAX);
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
         const int qd = threadIdx.x + i * NT;
@@ -681,10 +715,11 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
             if (lane == r) stash[(g - g0) * 5 + r] = row_value(T[r], rsum, sc[r < 4 ? 0 : 1]);
         if (first_) { tl_stamp(a.tl, 4); first_ = false; }
     }
-    block_sum<2>(Ssum, red);   // offset terms: only needed by the epilogue (also the barrier before it)
+    block_sum<2>(Ssum, red + RED_OFFS);   // offset terms: only needed by the epilogue (also the barrier before it)
     tl_stamp(a.tl, 5);
 
     double part[1] = {0.0};
+    float pmax[1] = {0.f};
     for (int t = threadIdx.x; t < 5 * (g1 - g0); t += NT) {
         const int q = t % 5, i = g0 + t / 5;
         const float val = stash[t] + (float)Ssum[q < 4 ? 0 : 1];
@@ -692,14 +727,299 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
             float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
             h = h * h;
             const int kk = 4 * i + q;
-            a.hbuf[kk] = h * a.r_fv[kk];
+            const float hs = h * a.r_fv[kk];
+            a.hbuf[kk] = hs;
             part[0] += (double)(h * a.o_fv[kk]);
+            pmax[0] = fmaxf(pmax[0], fabsf(hs));
         } else {
             a.rgate[i] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
         }
     }
-    block_sum<1>(part, red);
-    if (threadIdx.x == 0) a.partS[blockIdx.x] = part[0];
+    block_sum<1>(part, red + RED_PART);
+    block_max<1>(pmax, red + RED_AUX);
+    if (threadIdx.x == 0) { a.partS[blockIdx.x] = part[0]; a.partM[blockIdx.x] = pmax[0]; }
+    tl_stamp(a.tl, 6);
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-specialised variant: loader waves + LDS ring.
+//
+// Measured on MI355X (tools/timeline.py): in the all-waves-do-everything kernels above the weight
+// stream and the prologue fight for the same in-order waves -- a wave that has asked for more loads
+// than the memory pipe accepts stalls AT ISSUE and cannot run its share of the prologue, and a
+// wave that asks for little leaves HBM idle for the ~6 us the prologue takes.  Here the roles are
+// split inside the workgroup: NL loader waves do nothing but copy the workgroup's (contiguous)
+// weight region HBM -> registers -> LDS ring, one row group per ring slot, two groups in flight per
+// loader; the other NC waves run the prologue and then drain the ring with the same dot4 code.
+// The ring fills while the prologue runs, so the stream never waits for it.
+// No s_barrier after the role split (it would need the loaders): the consumers synchronise among
+// themselves through LDS counters; every spin is bounded.
+constexpr int NL = 2;           // loader waves
+constexpr int NC = NW - NL;     // consumer waves
+constexpr int NCT = NC * 64;    // consumer threads
+struct RingCtl {
+    unsigned ready[8];          // ready[slot] = generation whose data is complete in the slot
+    unsigned done[8];           // done[slot]  = generation the consumers have finished reading
+    unsigned bar;               // consumer barrier arrivals
+    unsigned err;               // a bounded spin gave up
+    unsigned go;                // consumer waves whose prologue loads have landed (loaders start at NC)
+    unsigned pad[13];
+};
+__device__ __forceinline__ bool spin_ge(unsigned *p, unsigned want, unsigned *err)
+{
+    for (int i = 0; i < (1 << 22); i++) {
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return false;
+}
+// barrier among the NC consumer waves only (phase counts the barriers executed so far)
+__device__ __forceinline__ void cbar(RingCtl *rc, unsigned &phase)
+{
+    phase++;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&rc->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    spin_ge(&rc->bar, phase * NC, &rc->err);
+}
+// reductions among the consumer waves; `red` must be a scratch region that is not reused by a
+// later reduction before every wave has read it (callers pass distinct regions), so one barrier each
+template <int K>
+__device__ __forceinline__ void csum(double (&v)[K], double *red, RingCtl *rc, unsigned &phase, int cw)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[cw * K + k] = v[k];
+    }
+    cbar(rc, phase);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < NC; i++) t += red[i * K + k];
+        v[k] = t;
+    }
+}
+template <int K>
+__device__ __forceinline__ void cmax(float (&v)[K], double *redd, RingCtl *rc, unsigned &phase, int cw)
+{
+    float *red = reinterpret_cast<float *>(redd);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = wave_max(v[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[cw * K + k] = v[k];
+    }
+    cbar(rc, phase);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; i++) t = fmaxf(t, red[i * K + k]);
+        v[k] = t;
+    }
+}
+
+// loader wave `lw`: copies groups lw, lw+NL, ... (gbytes each, contiguous from `base`) into the ring.
+// NLD = 1 KiB wave-loads per group.  Two register sets: the next group's loads are in flight while
+// the current one is written to LDS.  The issue is branch-free (see group_dot's refill).
+template <int NLD, int NSLOT>
+__device__ __forceinline__ void ring_loader(const uint8_t *__restrict__ base, unsigned gbytes, int ng, unsigned char *ring,
+                                            RingCtl *rc, int lw, int lane)
+{
+    u32x4 A[NLD], B[NLD];
+    auto issue = [&](u32x4 (&buf)[NLD], int gi) {
+        const bool valid = gi < ng;
+        const uint8_t *gb = base + (size_t)(valid ? gi : 0) * gbytes;
+        const unsigned mask = valid ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            unsigned off = (unsigned)(i * 1024 + lane * 16);
+            off = off < gbytes ? off : gbytes - 16;
+            buf[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(gb + (off & mask)));
+        }
+    };
+    auto drain = [&](u32x4 (&buf)[NLD], int gi) {
+        const int slot = gi % NSLOT;
+        const unsigned gen = (unsigned)(gi / NSLOT) + 1u;
+        if (gen > 1u) spin_ge(&rc->done[slot], gen - 1u, &rc->err);   // previous tenant fully consumed
+        unsigned char *dst = ring + (size_t)slot * gbytes;
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const unsigned off = (unsigned)(i * 1024 + lane * 16);
+            if (off < gbytes) *reinterpret_cast<u32x4 *>(dst + off) = buf[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&rc->ready[slot], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    int gi = lw;
+    issue(A, gi);
+    while (gi < ng) {
+        issue(B, gi + NL);
+        drain(A, gi);
+        gi += NL;
+        if (gi >= ng) break;
+        issue(A, gi + NL);
+        drain(B, gi);
+        gi += NL;
+    }
+}
+
+// consumer: fetch the R*S pieces of the group in ring slot `slot` into registers
+template <int R, int S>
+__device__ __forceinline__ void ring_fetch(u32x4 (&w)[R][S], const unsigned char *slot, int D, int chunks, int lane)
+{
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        int c = lane + 64 * s;
+        c = c < chunks ? c : chunks - 1;
+#pragma unroll
+        for (int r = 0; r < R; r++) w[r][s] = *reinterpret_cast<const u32x4 *>(slot + (size_t)r * D + ((unsigned)c << 4));
+    }
+}
+
+// ln2 -> mix -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573): loader/consumer variant
+template <int S, int NSLOT>
+__global__ __launch_bounds__(NT) void k_ffn_rk_ring(FfnRKArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int XVD = xvd<S>();
+    constexpr int NQ = (S * 256 + NCT - 1) / NCT;      // quads per consumer thread
+    RingCtl *rc = reinterpret_cast<RingCtl *>(smem);
+    double *red = reinterpret_cast<double *>(smem + 128);
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + 128 + RED_BYTES);
+    float *stash = reinterpret_cast<float *>(xq + 2 * XVD);
+    const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = D >> 4, nqd = D >> 2;
+    const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
+    const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
+    const int ng = g1 - g0;
+    const int gpb = (D + gridDim.x - 1) / gridDim.x + 1;
+    unsigned char *ring = reinterpret_cast<unsigned char *>(stash + ((gpb * 5 + 3) & ~3));
+    const unsigned gbytes = 5u * (unsigned)D;
+
+    if (threadIdx.x < 32) reinterpret_cast<unsigned *>(rc)[threadIdx.x] = 0u;
+    __syncthreads();   // the only full-workgroup barrier: ring control words are zero
+    tl_stamp(a.tl, 0);
+
+    if (wave < NL) {   // ---------------- loader waves ----------------
+        // The CU's vector-memory pipe is shared: prologue loads (L2 hits) issued behind a saturating
+        // HBM stream see HBM-like latency (measured: staging 6 -> 11 us).  So the stream starts
+        // only when every consumer wave has RECEIVED its prologue inputs (~2 us), and then runs
+        // under the prologue's arithmetic.
+        spin_ge(&rc->go, NC, &rc->err);
+        ring_loader<5 * S, NSLOT>(a.w + (size_t)g0 * gbytes, gbytes, ng, ring, rc, wave, lane);
+        return;
+    }
+    // ---------------- consumer waves ----------------
+    const int cw = wave - NL, ct = threadIdx.x - NL * 64;
+    unsigned phase = 0;
+    const size_t so = (size_t)a.ctl->slot * a.slot_stride;
+    double xl[NQ][4], pv[NQ][4];
+    f32x4 P[NQ][4][2];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int qd = ct + i * NCT, qc = qd < nqd ? qd : nqd - 1;
+        load_quad_f64(a.x, qc, xl[i]);
+        load_quad_f64(a.sdd + so, qc, pv[i]);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { P[i][e][0] = a.pk[e * nqd + qc]; P[i][e][1] = a.pk[(4 + e) * nqd + qc]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // prologue inputs are in registers: release the loaders
+    if (lane == 0) __hip_atomic_fetch_add(&rc->go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    tl_stamp(a.tl, 1);
+    double st[2] = {0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const bool real = (ct + i * NCT) < nqd;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const double v = real ? xl[i][e] : 0.0; st[0] += v; st[1] += v * v; }
+    }
+    csum<2>(st, red, rc, phase, cw);
+    const double mean = st[0] / (double)D;
+    const double rstd = 1.0 / sqrt((st[1] - st[0] * mean) / (double)(D - 1));
+    tl_stamp(a.tl, 2);
+    double Ssum[2] = {0.0, 0.0};
+    float amax[2] = {0.f, 0.f};
+    float xr[NQ][2][4];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int qd = ct + i * NCT;
+        const bool real = qd < nqd;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const double xx = (double)P[i][e][0][0] * ((xl[i][e] - mean) * rstd) + (double)P[i][e][0][1];
+            const double prev = pv[i][e];
+            const double mk = (double)P[i][e][0][2], mr = (double)P[i][e][0][3];
+            const float fk = (float)(mk * xx + (1.0 - mk) * prev);
+            const float fr = (float)(mr * xx + (1.0 - mr) * prev);
+            xr[i][0][e] = fk * P[i][e][1][0]; xr[i][1][e] = fr * P[i][e][1][2];
+            if (real) {
+                Ssum[0] += (double)(fk * P[i][e][1][1]); Ssum[1] += (double)(fr * P[i][e][1][3]);
+                amax[0] = fmaxf(amax[0], fabsf(xr[i][0][e])); amax[1] = fmaxf(amax[1], fabsf(xr[i][1][e]));
+                if (qd * 4 + e >= g0 && qd * 4 + e < g1) a.xx_buf[qd * 4 + e] = xx;   // every workgroup publishes the channels it owns (not one straggler all of them)
+            }
+        }
+    }
+    cmax<2>(amax, red + 16, rc, phase, cw);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int qd = ct + i * NCT;
+        if (qd < S * 256) {
+            stage_quad(xq, qd, xr[i][0], inv_scale(amax[0]), qd < nqd);
+            stage_quad(xq + XVD, qd, xr[i][1], inv_scale(amax[1]), qd < nqd);
+        }
+    }
+    cbar(rc, phase);   // staged vectors visible to all consumers
+    tl_stamp(a.tl, 3);
+    const double sc[2] = {scale_of(amax[0]), scale_of(amax[1])};
+    bool first_ = true;
+
+    for (int gi = cw; gi < ng; gi += NC) {
+        const int slot = gi % NSLOT;
+        const unsigned gen = (unsigned)(gi / NSLOT) + 1u;
+        const unsigned rsum = a.rs[(g0 + gi) * 5 + (lane < 5 ? lane : 0)];
+        spin_ge(&rc->ready[slot], gen, &rc->err);
+        u32x4 w[5][S];
+        ring_fetch<5, S>(w, ring + (size_t)slot * gbytes, D, chunks, lane);
+        unsigned long long T[5];
+        group_dot<5, S, PAT_FFN_RK, false>(w, xq, lane, T, nullptr, 0, chunks, false);
+        // every lane's ring reads were consumed by the dots above: the slot may be refilled
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&rc->done[slot], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+            if (lane == r) stash[gi * 5 + r] = row_value(T[r], rsum, sc[r < 4 ? 0 : 1]);
+        if (first_) { tl_stamp(a.tl, 4); first_ = false; }
+    }
+    csum<2>(Ssum, red + 32, rc, phase, cw);   // offset terms + barrier: all stashes written
+    tl_stamp(a.tl, 5);
+
+    double part[1] = {0.0};
+    float pmax[1] = {0.f};
+    for (int t = ct; t < 5 * ng; t += NCT) {
+        const int q = t % 5, i = g0 + t / 5;
+        const float val = stash[t] + (float)Ssum[q < 4 ? 0 : 1];
+        if (q < 4) {
+            float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
+            h = h * h;
+            const int kk = 4 * i + q;
+            const float hs = h * a.r_fv[kk];
+            a.hbuf[kk] = hs;
+            part[0] += (double)(h * a.o_fv[kk]);
+            pmax[0] = fmaxf(pmax[0], fabsf(hs));
+        } else {
+            a.rgate[i] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
+        }
+    }
+    csum<1>(part, red + 48, rc, phase, cw);
+    cmax<1>(pmax, red + 56, rc, phase, cw);
+    if (ct == 0) { a.partS[blockIdx.x] = part[0]; a.partM[blockIdx.x] = pmax[0]; }
     tl_stamp(a.tl, 6);
 }
 
@@ -709,6 +1029,7 @@ struct FfnVArgs {
     const unsigned *rs;    // [D] row sums (whole 4D row)
     const float *hbuf;     // [4D] pre-scaled hidden vector
     const double *partS;
+    const float *partM;    // [n_part] partial max |hbuf|
     int n_part;
     const float *rgate;    // [D]
     double *x;             // residual stream (row-owned update)
@@ -743,6 +1064,7 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
             hl[q][i][0] = t[0]; hl[q][i][1] = t[1]; hl[q][i][2] = t[2]; hl[q][i][3] = t[3];
         }
     double Ssum[1] = {a.partS[(int)threadIdx.x < a.n_part ? threadIdx.x : 0]};
+    float amax[1] = {a.partM[(int)threadIdx.x < a.n_part ? threadIdx.x : 0]};   // one scale for the whole 4D vector
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
 
     u32x4 w[4][S];
@@ -750,15 +1072,18 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
     const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 4 * D;
     group_load<4, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
 
-    float amax[1] = {0.f};   // one scale for the whole 4D vector (its quarters are summed per row)
+    if ((int)threadIdx.x >= a.n_part) { Ssum[0] = 0.0; amax[0] = 0.f; }
+    {   // scale and offset from the producer's per-workgroup partials: one reduction round
+        float *redf = reinterpret_cast<float *>(red + RED_MAX);
+        const double ws = wave_sum(Ssum[0]);
+        const float wm = wave_max(amax[0]);
+        if (lane == 0) { red[RED_OFFS + wave] = ws; redf[wave] = wm; }
+        __syncthreads();
+        double ts = 0.0; float tm = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int i = 0; i < NQ; i++)
-            if ((int)(threadIdx.x + i * NT) < nqd)
-#pragma unroll
-                for (int e = 0; e < 4; e++) amax[0] = fmaxf(amax[0], fabsf(hl[q][i][e]));
-    block_max<1>(amax, red);
+        for (int i = 0; i < NW; i++) { ts += red[RED_OFFS + i]; tm = fmaxf(tm, redf[i]); }
+        Ssum[0] = ts; amax[0] = tm;
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -766,8 +1091,7 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
             const int qd = threadIdx.x + i * NT;
             if (qd < S * 256) stage_quad(xq + q * XVD, qd, hl[q][i], inv_scale(amax[0]), qd < nqd);
         }
-    if ((int)threadIdx.x >= a.n_part) Ssum[0] = 0.0;
-    block_sum<1>(Ssum, red);
+    __syncthreads();   // staged vector visible
     group_load<4, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
     const float Sf = (float)Ssum[0];
     const double sc = scale_of(amax[0]);
@@ -852,13 +1176,13 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
             if (real) { Ssum[0] += (double)(f * P[i][e][3]); amax[0] = fmaxf(amax[0], fabsf(xr[i][e])); }
         }
     }
-    block_max<1>(amax, red);
+    block_max<1>(amax, red + RED_MAX);
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
         const int qd = threadIdx.x + i * NT;
         if (qd < S * 256) stage_quad(xq, qd, xr[i], inv_scale(amax[0]), qd < nqd);
     }
-    block_sum<1>(Ssum, red);
+    block_sum<1>(Ssum, red + RED_OFFS);
     group_load<R, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
     const float Sf = (float)Ssum[0];
     const double sc = scale_of(amax[0]);
@@ -964,7 +1288,7 @@ __global__ __launch_bounds__(NT) void k_mm8(Mm8Args a)
                 if (real) { Ssum[0] += (double)(f * a.o[j]); amax[0] = fmaxf(amax[0], fabsf(xr[q][i][e])); }
             }
         }
-    block_max<1>(amax, red);
+    block_max<1>(amax, red + RED_MAX);
 #pragma unroll
     for (int q = 0; q < NVQ; q++)
 #pragma unroll
@@ -972,7 +1296,7 @@ __global__ __launch_bounds__(NT) void k_mm8(Mm8Args a)
             const int qd = threadIdx.x + i * NT;
             if (qd < S * 256) stage_quad(xq + q * XVD, qd, xr[q][i], inv_scale(amax[0]), qd < nqd);
         }
-    block_sum<1>(Ssum, red);
+    block_sum<1>(Ssum, red + RED_OFFS);
     const float Sf = (float)Ssum[0];
     const double sc = scale_of(amax[0]);
 

@@ -201,8 +201,7 @@ def test_pipeline_virtual_stages_equal_full_model(eng_mod):
     for slot, tk0 in ((0, 17), (1, 4242)):          # two independent streams on two state slots
         tk_p = tk_f = tk0
         for step in range(n):
-            lg = full.forward([0] * slot + [tk_f], eng_mod.MODE_PARRALEL) if False else None
-            # full model on the same slot: PARRALEL call with `slot+1` tokens would touch other slots, so use stage API
+            # the full model on the same state slot goes through the same single-token stage entry point
             tk_f = full.stage_forward(tk_f, slot, want_pick=True)
             for i, st in enumerate(stages):
                 if i > 0:

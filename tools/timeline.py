@@ -16,8 +16,9 @@ for rep in range(3):
     buf = m.debug_timeline(9).reshape(-1, 8, 8)[:256].astype(np.int64)
     t0 = buf[:, :, 0][buf[:, :, 0] > 0].min()
     us = (buf - t0) / 100.0
-    print(f"rep {rep}: kernel span {us[:, :, 6].max():.2f} us (first entry -> last end)")
+    print(f"rep {rep}: kernel span {us[:, :, 6][buf[:, :, 6] > 0].max():.2f} us (first entry -> last end)")
     for ph in range(7):
-        v = us[:, :, ph]
-        print(f"  {names[ph]:14s} min {v.min():7.2f}  mean {v.mean():7.2f}  max {v.max():7.2f}")
+        v = us[:, :, ph][buf[:, :, ph] > 0]          # loader waves of the ring variant only stamp phase 0
+        if v.size:
+            print(f"  {names[ph]:14s} min {v.min():7.2f}  mean {v.mean():7.2f}  max {v.max():7.2f}  (n={v.size})")
 m.close()
