@@ -90,7 +90,8 @@ def _buffers(a: int, b: int):
     t[X] = np.arange(b, dtype=_D)
     for s in (STATEXY, STATEAA, STATEBB, STATEDD):
         t[s] = np.zeros(a * b, dtype=_D)
-    t[STATEPP] = np.full(a * b, -1e30, dtype=_D)
+    # torch.tensor([...python floats...]) is float32, then .double() (convert_model.py:19-25): -1e30 rounded through f32
+    t[STATEPP] = np.full(a * b, np.float64(np.float32(-1e30)), dtype=_D)
     t[BUFFER1] = np.arange(b, dtype=_D)
     t[BUFFER2] = np.arange(VOCAB, dtype=_F)
     t[BUFFER3] = np.arange(b, dtype=_F)
