@@ -95,12 +95,20 @@ struct rwkv_ctx {
     float *attr = nullptr, *atto = nullptr, *fkr = nullptr, *fvr = nullptr, *frr = nullptr;
     float *fko = nullptr, *fvo = nullptr, *fro = nullptr, *headr = nullptr, *heado = nullptr;
     double *uw = nullptr, *ew = nullptr;
-    f32x4 *pk_att = nullptr, *pk_ffn = nullptr, *pk_head = nullptr;   // packed prologue parameter tables
+    // LayerNorm-site tables (kernels.hip.h "LayerNorm sites"): k = 0 ln1 -> K/V/R (3 vectors), 1 ln2 -> ffn k/r (2), 2 ln_out -> head (1)
+    float *siteC[3] = {nullptr, nullptr, nullptr};    // [L or 1][NV][D]
+    float *siteP[3] = {nullptr, nullptr, nullptr};    // [L or 1][D][PW]
+    double *siteTC[3] = {nullptr, nullptr, nullptr};  // [L or 1][NV]
+    float *siteMC[3] = {nullptr, nullptr, nullptr};   // [L or 1][NV]
+    float *siteB[3] = {nullptr, nullptr, nullptr};    // [NV][D]   per-token, emitted by the row owners
+    double *sitePD[3] = {nullptr, nullptr, nullptr};  // [grid][8] per-workgroup partial tuples
+    float *sitePF[3] = {nullptr, nullptr, nullptr};   // [grid][4]
+    double *lnstat = nullptr;                         // [3][2] mean, rstd per site
     uint8_t *w_kvr = nullptr, *w_att = nullptr, *w_frk = nullptr, *w_fv = nullptr, *w_head = nullptr;
     unsigned *rs_kvr = nullptr, *rs_att = nullptr, *rs_frk = nullptr, *rs_fv = nullptr, *rs_head = nullptr;   // row sums
     // state + scratch (device)
     double *state[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    double *x = nullptr, *xx1 = nullptr, *xx2 = nullptr, *partA = nullptr, *partF = nullptr;
+    double *x = nullptr, *partA = nullptr, *partF = nullptr;
     float *ybuf = nullptr, *hbuf = nullptr, *rgate = nullptr, *logits = nullptr, *blk_val = nullptr, *partMA = nullptr, *partMF = nullptr;
     unsigned *blk_idx = nullptr;
     Ctl *ctl = nullptr;
@@ -110,7 +118,7 @@ struct rwkv_ctx {
     hipGraphExec_t g_fwd = nullptr, g_greedy = nullptr;
     unsigned long long *tl = nullptr;   // phase-timeline buffer (debug), [grid][NW][8]
     bool tl_on = false;
-    bool ring = false;                  // loader/consumer (LDS ring) variant of the dominant kernel
+    int tl_cls = 3;                     // kernel class the timeline instruments (env RWKV_TL_CLASS, 1..4)
     std::vector<void *> allocs;
 };
 
@@ -129,12 +137,12 @@ template <typename T> int dalloc(rwkv_ctx *c, T **p, size_t count)
 size_t smem_att(int S, int gpb) { return RED_BYTES + 3 * (size_t)S * 3072 + (size_t)gpb * 3 * 4; }
 size_t smem_attout(int S) { return RED_BYTES + (size_t)S * 3072; }
 size_t smem_frk(int S, int gpb) { return RED_BYTES + 2 * (size_t)S * 3072 + (size_t)gpb * 5 * 4; }
-constexpr int RING_SLOTS_FRK = 5;
-size_t smem_frk_ring(int S, int gpb, int D) { return 128 + RED_BYTES + 2 * (size_t)S * 3072 + (size_t)((gpb * 5 + 3) & ~3) * 4 + (size_t)RING_SLOTS_FRK * 5 * D; }
 size_t smem_fv(int S) { return RED_BYTES + 4 * (size_t)S * 3072; }
 size_t smem_head(int S) { return RED_BYTES + (size_t)S * 3072 + NW * 8; }
 
 constexpr int ATTOUT_R = 2;
+constexpr int SITE_NV[3] = {3, 2, 1};
+constexpr int SITE_PW[3] = {site_pw<3>(), site_pw<2>(), site_pw<1>()};
 
 #define DISPATCH_S(S, ...)                                           \
     switch (S) {                                                     \
@@ -160,49 +168,74 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
     const uint64_t L = c->L;
     const size_t LD = (size_t)L * D, lo = (size_t)l * D;
     const int gpb = gpb_of(c);
+    // debug timeline: the kernel of class tl_cls in the stage's middle layer stamps its phases
+    auto tl_of = [&](int k) { return (c->tl_on && k == c->tl_cls && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr; };
+    auto site_static = [&](int k, uint64_t ll) {
+        const int nv = SITE_NV[k], pw = SITE_PW[k];
+        SiteStatic st;
+        st.C = c->siteC[k] + (size_t)ll * nv * D; st.P = c->siteP[k] + (size_t)ll * D * pw;
+        st.TC = c->siteTC[k] + (size_t)ll * nv; st.maxC = c->siteMC[k] + (size_t)ll * nv;
+        st.invD = 1.0 / (double)D; st.invDm1 = 1.0 / (double)(D - 1);
+        return st;
+    };
+    auto site_dyn = [&](int k, int n_part) {
+        SiteDyn dy;
+        dy.B = c->siteB[k]; dy.pd = c->sitePD[k]; dy.pf = c->sitePF[k]; dy.lnstat = c->lnstat + 2 * k; dy.n_part = n_part;
+        return dy;
+    };
+    // the ln1 site of the stage's first layer is opened by k_first (a few workgroups), every other site by a full grid
+    const int n_first = grid < 32 ? grid : 32;
     switch (cls) {
     case 0: {
-        EmbedArgs ea{c->embed, c->ln, c->x, c->ctl, D};
-        k_embed_ln0<<<dim3(1), dim3(NT), 0, c->stream>>>(ea);
+        FirstArgs fa;
+        fa.embed = c->embed; fa.ln = c->ln; fa.x = c->x; fa.st = site_static(0, c->l0); fa.dy = site_dyn(0, n_first);
+        fa.sxy = c->state[0] + (size_t)c->l0 * D; fa.slot_stride = LD; fa.ctl = c->ctl; fa.D = D; fa.from_token = c->l0 == 0;
+        k_first<<<dim3(n_first), dim3(NT), 0, c->stream>>>(fa);
     } break;
     case 1: {
         AttArgs aa;
-        aa.x = c->x; aa.pk = c->pk_att + lo * 3;
+        aa.x = c->x; aa.st = site_static(0, l); aa.dy = site_dyn(0, l == c->l0 ? n_first : grid);
         aa.w = c->w_kvr + (size_t)(l - c->l0) * 3 * D * D; aa.rs = c->rs_kvr + (size_t)(l - c->l0) * D * 3;
         aa.uw = c->uw + lo; aa.ew = c->ew + lo;
         aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
-        aa.sxy = c->state[0] + lo; aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
-        aa.slot_stride = LD; aa.xx_buf = c->xx1; aa.ybuf = c->ybuf; aa.partS = c->partA; aa.partM = c->partMA;
-        aa.ctl = c->ctl; aa.D = D;
+        aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
+        aa.slot_stride = LD; aa.ybuf = c->ybuf; aa.partS = c->partA; aa.partM = c->partMA;
+        aa.ctl = c->ctl; aa.D = D; aa.tl = tl_of(1);
         DISPATCH_S(S, k_att<S_><<<dim3(grid), dim3(NT), smem_att(S, gpb), c->stream>>>(aa));
     } break;
     case 2: {
         AttOutArgs ao;
         ao.w = c->w_att + (size_t)(l - c->l0) * D * D; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
-        ao.x = c->x; ao.xx_buf = c->xx1; ao.sxy = c->state[0] + lo; ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D;
+        ao.x = c->x; ao.lnw = c->ln + (4 * l + 2) * D; ao.lnb = c->ln + (4 * l + 3) * D; ao.lnstat = c->lnstat + 0;
+        ao.sxy = c->state[0] + lo; ao.st = site_static(1, l); ao.dy = site_dyn(1, grid); ao.sdd = c->state[4] + lo;
+        ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.tl = tl_of(2);
         DISPATCH_S(S, k_attout<S_, ATTOUT_R><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
     } break;
     case 3: {
         FfnRKArgs fa;
-        fa.x = c->x; fa.pk = c->pk_ffn + lo * 2;
+        fa.x = c->x; fa.st = site_static(1, l); fa.dy = site_dyn(1, grid);
         fa.w = c->w_frk + (size_t)(l - c->l0) * 5 * D * D; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5;
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
-        fa.sdd = c->state[4] + lo; fa.slot_stride = LD; fa.xx_buf = c->xx2;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.partM = c->partMF; fa.ctl = c->ctl; fa.D = D;
-        fa.tl = (c->tl_on && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr;
-        if (c->ring) { DISPATCH_S(S, k_ffn_rk_ring<S_, RING_SLOTS_FRK><<<dim3(grid), dim3(NT), smem_frk_ring(S, gpb, D), c->stream>>>(fa)); }
-        else { DISPATCH_S(S, k_ffn_rk<S_><<<dim3(grid), dim3(NT), smem_frk(S, gpb), c->stream>>>(fa)); }
+        fa.tl = tl_of(3);
+        DISPATCH_S(S, k_ffn_rk<S_><<<dim3(grid), dim3(NT), smem_frk(S, gpb), c->stream>>>(fa));
     } break;
     case 4: {
         FfnVArgs fv;
         fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
-        fv.rgate = c->rgate; fv.x = c->x; fv.xx_buf = c->xx2; fv.sdd = c->state[4] + lo;
-        fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D;
-        DISPATCH_S(S, k_ffnv<S_><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
+        fv.rgate = c->rgate; fv.x = c->x; fv.lnw = c->ln + (4 * l + 4) * D; fv.lnb = c->ln + (4 * l + 5) * D; fv.lnstat = c->lnstat + 2;
+        fv.sdd = c->state[4] + lo; fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D; fv.tl = tl_of(4);
+        if (l + 1 < c->l1) {   // next consumer: k_att of layer l+1
+            fv.st = site_static(0, l + 1); fv.dy = site_dyn(0, grid); fv.sprev = c->state[0] + lo + D;
+            DISPATCH_S(S, k_ffnv<S_, 3><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
+        } else {               // next consumer: k_head (on a non-final pipeline stage nobody reads it: the next stage's k_first re-opens its own site from x)
+            fv.st = site_static(2, 0); fv.dy = site_dyn(2, grid); fv.sprev = nullptr;
+            DISPATCH_S(S, k_ffnv<S_, 1><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
+        }
     } break;
     case 5: {
         HeadArgs ha;
-        ha.x = c->x; ha.pk = c->pk_head; ha.w = c->w_head; ha.rs = c->rs_head; ha.logits = c->logits;
+        ha.x = c->x; ha.st = site_static(2, 0); ha.dy = site_dyn(2, grid); ha.w = c->w_head; ha.rs = c->rs_head; ha.logits = c->logits;
         ha.blk_val = c->blk_val; ha.blk_idx = c->blk_idx; ha.ctl = c->ctl; ha.D = D;
         DISPATCH_S(S, k_head<S_><<<dim3(grid), dim3(NT), smem_head(S), c->stream>>>(ha));
     } break;
@@ -215,11 +248,11 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
 // (4L + 4) events recorded before each launch and after the last (profiling).
 int enqueue_token(rwkv_ctx *c, bool with_argmax, hipEvent_t *ev)
 {
-    const bool first = c->l0 == 0, last = c->l1 == c->L;
+    const bool last = c->l1 == c->L;
     int evi = 0;
 #define EV() do { if (ev) HIPCHK(hipEventRecord(ev[evi++], c->stream)); } while (0)
     EV();
-    if (first) launch_class(c, 0, 0);
+    launch_class(c, 0, 0);   // first stage: embed + ln0; every stage: open the ln1 site of its first layer
     for (uint64_t l = c->l0; l < c->l1; l++)
         for (int cls = 1; cls <= 4; cls++) { EV(); launch_class(c, cls, l); }
     EV();
@@ -283,8 +316,8 @@ int set_smem_limits(rwkv_ctx *c)
     DISPATCH_S(S, rc = allow_smem(k_att<S_>, smem_att(S, gpb))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R>, smem_attout(S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_>, smem_frk(S, gpb))); if (rc) return rc;
-    if (c->ring) { DISPATCH_S(S, rc = allow_smem(k_ffn_rk_ring<S_, RING_SLOTS_FRK>, smem_frk_ring(S, gpb, (int)c->D))); if (rc) return rc; }
-    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_>, smem_fv(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3>, smem_fv(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1>, smem_fv(S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_head<S_>, smem_head(S))); if (rc) return rc;
     return 0;
 }
@@ -336,21 +369,31 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if ((rc = dalloc(c, &c->ew, L * D))) return rc;
     hipLaunchKernelGGL(k_prep_wkv, dim3((unsigned)((L * D + 255) / 256)), dim3(256), 0, c->stream, decay, bonus, c->uw, c->ew, (size_t)(L * D));
 
-    // packed prologue parameter tables
-    if ((rc = dalloc(c, &c->pk_att, L * D * 3))) return rc;
-    if ((rc = dalloc(c, &c->pk_ffn, L * D * 2))) return rc;
-    if ((rc = dalloc(c, &c->pk_head, D))) return rc;
+    // LayerNorm-site tables for the layers of this stage (+ the head site)
+    for (int k = 0; k < 3; k++) {
+        const uint64_t n = k == 2 ? 1 : L;
+        if ((rc = dalloc(c, &c->siteC[k], n * SITE_NV[k] * D))) return rc;
+        if ((rc = dalloc(c, &c->siteP[k], n * D * SITE_PW[k]))) return rc;
+        if ((rc = dalloc(c, &c->siteTC[k], n * SITE_NV[k]))) return rc;
+        if ((rc = dalloc(c, &c->siteMC[k], n * SITE_NV[k]))) return rc;
+        HIPCHK(hipMemsetAsync(c->siteP[k], 0, n * D * SITE_PW[k] * sizeof(float), c->stream));
+    }
     {
-        const dim3 pg((unsigned)((D + 255) / 256)), pb(256);
-        for (uint64_t l = 0; l < L; l++) {
+        auto build = [&](int k, uint64_t ll, int m, const double *lnw, const double *lnb, const double *mix, const float *r, const float *o) {
+            k_site_static<<<dim3(1), dim3(NT), 0, c->stream>>>(lnw, lnb, mix, r, o, c->siteC[k] + (size_t)ll * SITE_NV[k] * D,
+                                                               c->siteP[k] + (size_t)ll * D * SITE_PW[k], c->siteTC[k] + (size_t)ll * SITE_NV[k],
+                                                               c->siteMC[k] + (size_t)ll * SITE_NV[k], m, SITE_PW[k], (int)D);
+        };
+        for (uint64_t l = l0; l < l1; l++) {
             const size_t lo = (size_t)l * D;
-            k_pack_att<<<pg, pb, 0, c->stream>>>(c->pk_att + lo * 3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D,
-                                                 c->mixk + lo, c->mixv + lo, c->mixr + lo, c->kr + lo, c->vr + lo, c->rr + lo,
-                                                 c->o1 + lo, c->o2 + lo, c->o3 + lo, (int)D);
-            k_pack_ffn<<<pg, pb, 0, c->stream>>>(c->pk_ffn + lo * 2, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D,
-                                                 c->fmixk + lo, c->fmixr + lo, c->fkr + lo, c->fko + lo, c->frr + lo, c->fro + lo, (int)D);
+            const double *w1 = c->ln + (4 * l + 2) * D, *b1 = c->ln + (4 * l + 3) * D, *w2 = c->ln + (4 * l + 4) * D, *b2 = c->ln + (4 * l + 5) * D;
+            build(0, l, 0, w1, b1, c->mixk + lo, c->kr + lo, c->o1 + lo);
+            build(0, l, 1, w1, b1, c->mixv + lo, c->vr + lo, c->o2 + lo);
+            build(0, l, 2, w1, b1, c->mixr + lo, c->rr + lo, c->o3 + lo);
+            build(1, l, 0, w2, b2, c->fmixk + lo, c->fkr + lo, c->fko + lo);
+            build(1, l, 1, w2, b2, c->fmixr + lo, c->frr + lo, c->fro + lo);
         }
-        k_pack_head<<<pg, pb, 0, c->stream>>>(c->pk_head, c->ln + (4 * L + 2) * D, c->ln + (4 * L + 3) * D, c->headr, c->heado, (int)D);
+        build(2, 0, 0, c->ln + (4 * L + 2) * D, c->ln + (4 * L + 3) * D, nullptr, c->headr, c->heado);
         HIPCHK(hipGetLastError());
     }
 
@@ -373,7 +416,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         if (!rc) rc = retile(c, src, FFNV, l, 4 * D, D, c->w_fv + (l - l0) * 4 * D * D, 1, 1, 0, staging);
     }
     if (!rc && last) rc = retile(c, src, HEAD, 0, D, V, c->w_head, 1, 1, 0, staging);
-    // row sums of the re-tiled matrices (the 2^23 offset of the activation limbs is removed with them)
+    // row sums of the re-tiled matrices (the 2^22 offset of the activation limbs is removed with them)
     if (!rc) rc = dalloc(c, &c->rs_kvr, nl * 3 * D);
     if (!rc) rc = dalloc(c, &c->rs_att, nl * D);
     if (!rc) rc = dalloc(c, &c->rs_frk, nl * 5 * D);
@@ -401,8 +444,14 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         HIPCHK(hipMemsetAsync(c->state[s], 0, max_ctx * L * D * sizeof(double), c->stream));
     }
     if ((rc = dalloc(c, &c->x, D))) return rc;
-    if ((rc = dalloc(c, &c->xx1, D))) return rc;
-    if ((rc = dalloc(c, &c->xx2, D))) return rc;
+    for (int k = 0; k < 3; k++) {
+        if ((rc = dalloc(c, &c->siteB[k], (size_t)SITE_NV[k] * D))) return rc;
+        if ((rc = dalloc(c, &c->sitePD[k], (size_t)c->grid * 8))) return rc;
+        if ((rc = dalloc(c, &c->sitePF[k], (size_t)c->grid * 4))) return rc;
+        HIPCHK(hipMemsetAsync(c->sitePD[k], 0, (size_t)c->grid * 8 * sizeof(double), c->stream));
+        HIPCHK(hipMemsetAsync(c->sitePF[k], 0, (size_t)c->grid * 4 * sizeof(float), c->stream));
+    }
+    if ((rc = dalloc(c, &c->lnstat, 6))) return rc;
     if ((rc = dalloc(c, &c->ybuf, D))) return rc;
     if ((rc = dalloc(c, &c->hbuf, 4 * D))) return rc;
     if ((rc = dalloc(c, &c->rgate, D))) return rc;
@@ -459,9 +508,7 @@ int rwkv_create(rwkv_ctx **out, int device)
     c->grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char *g = getenv("RWKV_GRID");
     if (g && atoi(g) > 0) c->grid = atoi(g);
-    if (c->grid > NT) c->grid = NT;   // consumers sum one partial per thread
-    const char *rg = getenv("RWKV_RING");
-    c->ring = rg && rg[0] == '1';
+    if (c->grid > NT / 2) c->grid = NT / 2;   // consumers sum one partial per thread of the prologue waves (half the workgroup)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(RWKV_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = c;
@@ -726,6 +773,7 @@ int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, ui
     HIPCHK(hipMemsetAsync(c->tl, 0, n * 8, c->stream));
     c->h_ctl[0].token = token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+    { const char *e = getenv("RWKV_TL_CLASS"); c->tl_cls = e ? atoi(e) : 3; }
     c->tl_on = true;
     int rc = enqueue_token(c, false, nullptr);
     c->tl_on = false;

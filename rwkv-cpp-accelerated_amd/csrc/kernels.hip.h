@@ -3,11 +3,11 @@
 // One token = 4 launches per layer + embed + head (+ argmax), replacing the ~28 stream
 // operations per layer of the reference driver (rwkv.cu:528-581):
 //
-//   k_embed_ln0   rwkv.cu:513-524   embedding row gather (device-resident table) + ln0
+//   k_first       rwkv.cu:513-524   embedding row gather (device-resident table) + ln0; opens ln1 site
 //   k_att         rwkv.cu:535-545   ln1 + token-shift mix + K/V/R dequant-GEMV + WKV recurrence
-//   k_attout      rwkv.cu:548-553   att_out dequant-GEMV + residual (+ commits state xy)
+//   k_attout      rwkv.cu:548-553   att_out dequant-GEMV + residual; commits state xy; opens ln2 site
 //   k_ffn_rk      rwkv.cu:557-573   ln2 + mix + ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2
-//   k_ffnv        rwkv.cu:574-577   ffn_v dequant-GEMV, x += v * sigmoid(r) (+ commits state dd)
+//   k_ffnv        rwkv.cu:574-577   ffn_v dequant-GEMV, x += v * sigmoid(r); commits state dd; opens next site
 //   k_head        rwkv.cu:585-589   ln_out + head dequant-GEMV -> logits (+ per-block argmax)
 //
 // Design (DESIGN.md has the long form and the measurements behind each choice):
@@ -19,16 +19,17 @@
 //    (WKV, sigmoid, relu^2, residual) fuses into the kernel that finished the row.
 //  * sum_j x_j (u_jk r_j + o_j) = sum_j (x_j r_j) u_jk + sum_j x_j o_j.  The first term is an
 //    integer contraction: the pre-scaled activation vector is quantised ONCE per workgroup to
-//    24-bit fixed point (3 unsigned byte limbs, scale = max|.|/8388000) and staged in LDS, and
+//    23-bit fixed point (3 unsigned byte limbs, scale = max|.|/4194000) and staged in LDS, and
 //    the u8 x u8 products run on v_dot4_u32_u8 (4 MACs per lane-instruction, exact u32
 //    accumulation, no byte->float converts).  Measured on MI355X the f32 formulation
 //    (v_cvt_f32_ubyteN + v_fma_f32 per weight byte) cost as much VALU time as the HBM stream
 //    itself; the limb form needs 12 instructions per 16 weight bytes instead of 32 and its
-//    rounding error (<= 1.2e-7 max|x|) is below that of an f32 FMA chain.  The offset term is
+//    rounding error (<= 1.2e-7 max|x| per element) is below that of an f32 FMA chain.  The offset term is
 //    one scalar per vector.
-//  * Every GEMV needs its complete input vector, so LayerNorm / token-shift prologues are
-//    recomputed per workgroup from the D-vector (L2 resident).  Prologue inputs are requested
-//    first, then the first steps of the weight stream, so the prologue runs under the stream.
+//  * Every GEMV needs its complete input vector in every workgroup.  The LayerNorm / token-shift
+//    work is split by ownership ("LayerNorm sites" below): the kernel that owns rows of x emits the
+//    state-dependent part and per-workgroup partial sums, the consumer needs one reduction round
+//    and one multiply-add per element before it can stage the vector.
 //  * Grid = one 512-thread workgroup per CU (8 waves); each wave keeps R*S x 16 B loads in flight
 //    and refills a step's registers with the next row group as soon as the step is consumed.
 #pragma once
@@ -41,8 +42,9 @@ constexpr int NT = 512;          // threads per workgroup
 constexpr int NW = NT / 64;      // wavefronts per workgroup
 constexpr int RED_BYTES = 1024;  // LDS scratch for workgroup reductions
 constexpr unsigned VOCAB = 50277u;
-constexpr float QLIM = 8388000.0f;       // |quantised activation| <= QLIM < 2^23
-constexpr double QOFF = 8388608.0;       // 2^23: limbs hold q + 2^23 as an unsigned 24-bit number
+constexpr float QLIM = 4194000.0f;       // |quantised activation| <= QLIM < 2^22
+constexpr double QOFF = 4194304.0;       // 2^22: limbs hold q + 2^22 as an unsigned 23-bit number
+constexpr float QMAGIC = 12582912.0f;    // 1.5 * 2^23: float(q + QMAGIC) has q + 2^22 in its low three bytes
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -167,17 +169,22 @@ template <int S> __device__ __forceinline__ constexpr int nquads() { return (S *
 
 // quantise 4 consecutive elements (quad qd = j/4) with 1/scale `inv_s` and store their 3 limb dwords.
 // real == false writes zero limbs: padding must contribute nothing to the integer sums (it is
-// outside the row sums used for the 2^23 offset correction).
+// outside the row sums used for the 2^22 offset correction).
 __device__ __forceinline__ void stage_quad(unsigned *xq, int qd, const float (&xr)[4], float inv_s, bool real)
 {
-    unsigned d0 = 0, d1 = 0, d2 = 0;
+    // One fma per element does scale, round-to-nearest-even and offset: for |x * inv_s| < 2^22 the
+    // float x * inv_s + 1.5 * 2^23 has ulp 1 and bit pattern 0x4B400000 + q, i.e. its bytes 0..2 are the
+    // three limbs of q + 2^22.  v_perm_b32 then transposes 4 elements x 3 bytes into 3 limb dwords.
+    unsigned t[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const unsigned qi = (unsigned)(__float2int_rn(xr[e] * inv_s) + 8388608);
-        d0 |= (qi & 255u) << (8 * e);
-        d1 |= ((qi >> 8) & 255u) << (8 * e);
-        d2 |= ((qi >> 16) & 255u) << (8 * e);
-    }
+    for (int e = 0; e < 4; e++) t[e] = __float_as_uint(fmaf(xr[e], inv_s, QMAGIC));
+    const unsigned p01 = __builtin_amdgcn_perm(t[1], t[0], 0x05010400u);   // {t0.b0, t1.b0, t0.b1, t1.b1}
+    const unsigned p23 = __builtin_amdgcn_perm(t[3], t[2], 0x05010400u);
+    const unsigned h01 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u);   // {t0.b2, t1.b2, 0, 0}
+    const unsigned h23 = __builtin_amdgcn_perm(t[3], t[2], 0x0c0c0602u);
+    const unsigned d0 = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+    const unsigned d1 = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+    const unsigned d2 = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
     const int c = qd >> 2, q = qd & 3;
     unsigned *p = xq + ((((c >> 6) * 3) * 64 + (c & 63)) << 2) + q;
     p[0] = real ? d0 : 0u;
@@ -242,7 +249,7 @@ __device__ __forceinline__ void group_load(u32x4 (&w)[R][S], const uint8_t *__re
 template <int S> __device__ __forceinline__ constexpr int pre_steps() { return RWKV_PRE_STEPS < S ? RWKV_PRE_STEPS : S; }
 
 // Integer dot products of the loaded group with the staged vector(s): T[r] = sum_j u_rj * q'_j
-// (q' = 24-bit unsigned limb value), every lane gets all R sums.
+// (q' = 23-bit unsigned limb value), every lane gets all R sums.
 //  * The LDS reads of the limb pieces are software-pipelined one (step, vector) item ahead and
 //    pinned with sched barriers, so at most two 12-dword pieces are live.
 //  * Refill: as soon as step s of this group has been consumed its registers are re-loaded with
@@ -303,6 +310,23 @@ __device__ __forceinline__ void group_dot(u32x4 (&w)[R][S], const unsigned *xq, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LayerNorm "sites": where a LayerNorm + token-shift mix feeds a GEMV (ln1 -> K/V/R, ln2 -> ffn k/r,
+// ln_out -> head).  Every consumer workgroup needs the whole mixed vector, and computing it per
+// workgroup from scratch (x, state, ~10 parameter vectors, two dependent reductions) was the largest
+// loss of the first design (phase timeline: ~6 us before the first dot of a 22 us kernel).  So the
+// work is split by OWNERSHIP.  With xhat = (x - mean) * rstd the staged vector of a site is
+//     v_m[j] = r_m (mix_m (lnw xhat + lnb) + (1 - mix_m) prev) = C_m[j] * xhat[j] + B_m[j]
+//     C_m = r_m mix_m lnw                          (static, packed at load)
+//     B_m = r_m (mix_m lnb + (1 - mix_m) prev[j])  (needs only the OLD state: emitted by the row owner)
+// and the offset scalar  S_m = sum_j o_m f_m[j] = rstd * PA_m - mean rstd * TC_m + PB_m  with
+// PA_m = sum Co_m x,  PB_m = sum (BoL_m + BoP_m prev),  TC_m = sum Co_m  (Co = o mix lnw, ...).
+// The kernel whose lanes OWN rows of x (k_first / k_attout / k_ffnv) emits B_m[j] for its rows and one
+// partial tuple per workgroup {sum x, sum x^2, PA_m, PB_m; max|x|, max|B_m|}; the consumer reduces
+// the tuples in ONE round (mean, rstd, S_m, and an upper bound of max|v_m| for the fixed-point scale:
+// maxC_m (max|x| + |mean|) rstd + max|B_m|), then only does C*xhat + B per element.  The new state
+// (ln output of this token) is committed by the row owner that overwrites x, from (mean, rstd)
+// published by the consumer.  Prologue traffic drops from 48-64 to 24-32 bytes per channel.
 // optional phase timeline (debug / tuning): lane 0 of every wave stamps the 100 MHz wall clock
 // into tl[((block * NW) + wave) * 8 + phase].  tl == nullptr in production.
 __device__ __forceinline__ void tl_stamp(unsigned long long *tl, int phase)
@@ -315,86 +339,433 @@ __device__ __forceinline__ void tl_stamp(unsigned long long *tl, int phase)
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Prologue discipline.  vmcnt retires loads IN ORDER, so a prologue load issued after the weight
-// loads would not return before every weight byte of the wave has landed.  Each kernel therefore
-// issues, in program order: (1) ALL of its prologue inputs, straight-line and branch-free
-// (out-of-range elements clamp their index), (2) the first steps of the first row group, and only
-// then (3) consumes the prologue inputs -- hipcc's counted s_waitcnt vmcnt(N) lets the LayerNorm /
-// mix / quantise / LDS staging run while the weight loads are in flight.  The static per-channel
-// parameters are packed at load time into float4 tables (k_pack_*).  A thread owns QUADS of 4
-// consecutive elements (quad qd = tid + i*NT), which is what one limb dword holds.
-
-// LayerNorm statistics of a D-vector held as NQ quads per thread (reference semantics: mean =
-// sum/D, variance over D-1, no epsilon -- rwkv.cu:40-57,412-450), in f64: one workgroup reduction
-// of (sum, sum of squares); var = (sumsq - sum*mean)/(D-1).
-template <int NQ>
-__device__ __forceinline__ void ln_stats(const double (&xl)[NQ][4], int D, double &mean, double &rstd, double *red)
+template <int NV> __host__ __device__ constexpr int site_pw() { return NV == 3 ? 16 : NV == 2 ? 12 : 8; }
+struct SiteStatic {               // one site of one layer
+    const float *C;               // [NV][D]  consumer side
+    const float *P;               // [D][PW]  producer side: per channel, per vector m: BL, BP, Co, BoL, BoP at [m*5 + k]
+    const double *TC;             // [NV]
+    const float *maxC;            // [NV]
+    double invD, invDm1;          // 1/D, 1/(D-1)
+};
+struct SiteDyn {
+    float *B;                     // [NV][D]
+    double *pd;                   // [n_part][8]: sum x, sum x^2, PA_0..2, PB_0..2
+    float *pf;                    // [n_part][4]: max|x|, max|B_0..2|
+    double *lnstat;               // [2]: mean, rstd of this site (written by consumer workgroup 0)
+    int n_part;
+};
+template <int NV> struct SiteAcc {
+    double d[8];
+    float f[4];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) f[k] = 0.f;
+    }
+};
+template <int NV> struct SitePre { f32x4 p[site_pw<NV>() / 4]; };
+// row owner, before its dot product: request the producer-side constants of channel j
+template <int NV>
+__device__ __forceinline__ void site_prefetch(const SiteStatic &st, int j, SitePre<NV> &pre)
 {
-    double s[2] = {0.0, 0.0};
+    constexpr int PW = site_pw<NV>();
 #pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const bool real = (int)(threadIdx.x + i * NT) * 4 < D;
+    for (int k = 0; k < PW / 4; k++) pre.p[k] = reinterpret_cast<const f32x4 *>(st.P + (size_t)j * PW)[k];
+}
+// row owner: emit B_m[j] and accumulate this thread's share of the workgroup tuple
+template <int NV>
+__device__ __forceinline__ void site_emit(const SitePre<NV> &pre, const SiteDyn &dy, int D, int j, double x, double prev, SiteAcc<NV> &acc)
+{
+    acc.d[0] += x;
+    acc.d[1] += x * x;
+    acc.f[0] = fmaxf(acc.f[0], (float)fabs(x) * 1.0000002f);   // round-up guard: used as an upper bound
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const double v = real ? xl[i][e] : 0.0;
-            s[0] += v;
-            s[1] += v * v;
+    for (int m = 0; m < NV; m++) {
+        const float bl = pre.p[(m * 5 + 0) >> 2][(m * 5 + 0) & 3], bp = pre.p[(m * 5 + 1) >> 2][(m * 5 + 1) & 3];
+        const float co = pre.p[(m * 5 + 2) >> 2][(m * 5 + 2) & 3];
+        const float bol = pre.p[(m * 5 + 3) >> 2][(m * 5 + 3) & 3], bop = pre.p[(m * 5 + 4) >> 2][(m * 5 + 4) & 3];
+        const float b = (float)((double)bl + (double)bp * prev);
+        dy.B[(size_t)m * D + j] = b;
+        acc.d[2 + m] += (double)co * x;
+        acc.d[5 + m] += (double)bol + (double)bop * prev;
+        acc.f[1 + m] = fmaxf(acc.f[1 + m], fabsf(b));
+    }
+}
+// all threads: fold the accumulators into this workgroup's tuple.  LIVE = lanes per wave that hold
+// one (the row owners are lanes 0..R-1 of every wave; 64 = every lane).  scratch: NW*LIVE*12 words of
+// LDS (or the 640-byte reduction block for LIVE == 64) that no wave still reads.
+template <int NV, int LIVE>
+__device__ __forceinline__ void site_publish(SiteAcc<NV> &acc, const SiteDyn &dy, void *scratch)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NE = LIVE == 64 ? NW : NW * LIVE;   // entries to add up
+    double *red = reinterpret_cast<double *>(scratch);
+    float *redf = reinterpret_cast<float *>(red + NE * 8);
+    if (LIVE == 64) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < 2 || (k - 2) % 3 < NV) acc.d[k] = wave_sum(acc.d[k]);
+#pragma unroll
+        for (int k = 0; k < 1 + NV; k++) acc.f[k] = wave_max(acc.f[k]);
+    }
+    if (lane < (LIVE == 64 ? 1 : LIVE)) {
+        const int e = LIVE == 64 ? w : w * LIVE + lane;
+#pragma unroll
+        for (int k = 0; k < 8; k++) red[e * 8 + k] = acc.d[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) redf[e * 4 + k] = acc.f[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double t = 0.0;
+        for (int i = 0; i < NE; i++) t += red[i * 8 + threadIdx.x];
+        dy.pd[(size_t)blockIdx.x * 8 + threadIdx.x] = t;
+    } else if (threadIdx.x < 12) {
+        float t = 0.f;
+        for (int i = 0; i < NE; i++) t = fmaxf(t, redf[i * 4 + (threadIdx.x - 8)]);
+        dy.pf[(size_t)blockIdx.x * 4 + (threadIdx.x - 8)] = t;
+    }
+}
+template <int NV> struct SiteRed {
+    double mean, rstd;
+    double S[NV];
+    float amax[NV];
+};
+// consumer, step 1 (first loads of the kernel): this thread's partial tuple
+struct SiteTuple { f64x2 d[4]; f32x4 f; };
+__device__ __forceinline__ void site_tuple_load(const SiteDyn &dy, SiteTuple &t)
+{
+    const int i = (int)threadIdx.x < dy.n_part ? threadIdx.x : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) t.d[k] = reinterpret_cast<const f64x2 *>(dy.pd)[i * 4 + k];
+    t.f = reinterpret_cast<const f32x4 *>(dy.pf)[i];
+}
+// consumer, step 2: one reduction round -> LayerNorm statistics, offset scalars, scale bounds
+// NWR = number of waves taking part (waves 0..NWR-1).  spin != nullptr: the waves meet on an LDS
+// counter (zeroed by the caller behind an earlier barrier) instead of the workgroup barrier, so the
+// remaining waves of the workgroup need not take part.
+template <int NV, int NWR = NW>
+__device__ __forceinline__ void site_reduce(const SiteStatic &st, const SiteDyn &dy, const SiteTuple &t, int D, double *red, SiteRed<NV> &out,
+                                            unsigned long long *tl = nullptr, unsigned *spin = nullptr)
+{
+    float *redf = reinterpret_cast<float *>(red + NW * 8);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool real = (int)threadIdx.x < dy.n_part;
+    double d[8];
+    float f[4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = real ? t.d[k >> 1][k & 1] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) f[k] = real ? t.f[k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (k < 2 || (k - 2) % 3 < NV) d[k] = wave_sum(d[k]);
+#pragma unroll
+    for (int k = 0; k < 1 + NV; k++) f[k] = wave_max(f[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) red[w * 8 + k] = d[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) redf[w * 4 + k] = f[k];
+    }
+    tl_stamp(tl, 3);
+    if (spin) {
+        if (lane == 0) __hip_atomic_fetch_add(spin, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(spin, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)NWR) __builtin_amdgcn_s_sleep(1);
+    } else {
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k < 2 || (k - 2) % 3 < NV) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NWR; i++) s += red[i * 8 + k];
+            d[k] = s;
         }
     }
-    block_sum<2>(s, red + RED_STATS);
-    mean = s[0] / (double)D;
-    const double var = (s[1] - s[0] * mean) / (double)(D - 1);
-    rstd = 1.0 / sqrt(var);
+#pragma unroll
+    for (int k = 0; k < 1 + NV; k++) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NWR; i++) s = fmaxf(s, redf[i * 4 + k]);
+        f[k] = s;
+    }
+    out.mean = d[0] * st.invD;
+    const double var = (d[1] - d[0] * out.mean) * st.invDm1;   // reference: (D-1), no epsilon (rwkv.cu:43-44,53)
+    out.rstd = rsqrt(var);
+    const double mrs = out.mean * out.rstd;
+#pragma unroll
+    for (int m = 0; m < NV; m++) {
+        out.S[m] = out.rstd * d[2 + m] - mrs * st.TC[m] + d[5 + m];
+        out.amax[m] = (st.maxC[m] * (float)(((double)f[0] + fabs(out.mean)) * out.rstd) + f[1 + m]) * 1.0001f;
+    }
 }
 __device__ __forceinline__ void load_quad_f64(const double *p, int qd, double (&out)[4])
 {
     const f64x2 a = reinterpret_cast<const f64x2 *>(p)[qd * 2], b = reinterpret_cast<const f64x2 *>(p)[qd * 2 + 1];
     out[0] = a[0]; out[1] = a[1]; out[2] = b[0]; out[3] = b[1];
 }
+// consumer, step 3: v_m = C_m * xhat + B_m for this thread's quads, quantised and staged
+template <int NV, int NQ, int S, int NTP = NT>
+__device__ __forceinline__ void site_stage(const double (&xl)[NQ][4], const f32x4 (&Cq)[NQ][NV], const f32x4 (&Bq)[NQ][NV],
+                                           const SiteRed<NV> &sr, unsigned *xq, int nqd)
+{
+    constexpr int XVD = xvd<S>();
+    const float rstdf = (float)sr.rstd;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NTP;
+        if (qd < S * 256) {
+            float xh[4];   // the subtraction stays in f64 (|mean| may dwarf the deviation); the rest is f32
+#pragma unroll
+            for (int e = 0; e < 4; e++) xh[e] = (float)(xl[i][e] - sr.mean) * rstdf;
+#pragma unroll
+            for (int m = 0; m < NV; m++) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaf(Cq[i][m][e], xh[e], Bq[i][m][e]);
+                stage_quad(xq + m * XVD, qd, v, inv_scale(sr.amax[m]), qd < nqd);
+            }
+        }
+    }
+}
+// ------------------------------------------------------------------------------------------
+// Kernel prologues.  What the first microseconds of a kernel look like decides a third of its run
+// time, and three measured properties of the CU's vector-memory path shape them:
+//  * data returns IN ORDER per CU (no hit-under-miss): a prologue load queued behind weight loads
+//    arrives after them, however warm its line is in L2;
+//  * the path holds only ~16 KB of requests: a wave that asks for more blocks at issue until HBM has
+//    delivered -- and a blocked wave cannot run the prologue or reach a barrier;
+//  * every workgroup reads the same ~100 KB of prologue inputs, 3.6 MB per XCD through one L2.
+// SPLIT prologues therefore give the waves roles until the vector is staged: waves 0..NW/2-1 request
+// the prologue inputs of the WHOLE vector, an order barrier lets those requests enter the pipe first,
+// then waves NW/2.. ("loaders") request their entire first row group -- they block at issue, which
+// is the point: the weight stream starts in the second microsecond and runs under the prologue --
+// while the prologue waves reduce (meeting on an LDS counter, not the workgroup barrier), quantise
+// and stage, publish the scalars through LDS, and join the loaders at the "staged" barrier.
+// which kernels use the role split (bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv, 4 k_head): measured per kernel
+#ifndef RWKV_SPLIT
+#define RWKV_SPLIT 7
+#endif
+constexpr int RED_BC = 96;     // doubles: scalars published by the prologue waves (8 floats) + spin counter
+
+// Row groups of a workgroup are handed out through an LDS counter (DYN): the waves that ran the
+// prologue start their first group late, the others take more of the remaining groups.  The counter
+// lives next to the published scalars and is set by thread 0 before the prologue's barriers.
+#ifndef RWKV_DYN
+#define RWKV_DYN 1
+#endif
+__device__ __forceinline__ unsigned *group_counter(double *red) { return reinterpret_cast<unsigned *>(red + RED_BC) + 9; }
+__device__ __forceinline__ int next_group(unsigned *ctr, int after)
+{
+#if RWKV_DYN
+    unsigned v = 0;
+    if ((threadIdx.x & 63) == 0) v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane((int)v);
+#else
+    return after + NW;
+#endif
+}
+
+// LayerNorm-site consumer (k_att, k_ffn_rk, k_head): on return the NV vectors are staged in xq,
+// sr.S / sr.amax are valid in every wave and w holds (requests for) the wave's first row group.
+template <int NV, int R, int S, bool SPLIT>
+__device__ __forceinline__ void site_open(const SiteStatic &st, const SiteDyn &dy, const double *x, int D, double *red, unsigned *xq,
+                                          u32x4 (&w)[R][S], const uint8_t *wb, size_t stride, SiteRed<NV> &sr, bool publish_stats,
+                                          unsigned long long *tl)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = D >> 4, nqd = D >> 2;
+    constexpr int NTP = SPLIT ? NT / 2 : NT, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
+    float *bc = reinterpret_cast<float *>(red + RED_BC);
+    unsigned *spin = reinterpret_cast<unsigned *>(bc + 8);
+    if (SPLIT && wave >= NWP) {
+        __syncthreads();   // order: the prologue waves' requests are in the memory pipe
+        group_load<R, S, 0, S>(w, wb, stride, chunks, lane);
+        tl_stamp(tl, 2);
+        __syncthreads();   // staged
+    } else {
+        SiteTuple tup;
+        site_tuple_load(dy, tup);
+        double xl[NQP][4];
+        f32x4 Cq[NQP][NV], Bq[NQP][NV];
+#pragma unroll
+        for (int i = 0; i < NQP; i++) {
+            const int qd = threadIdx.x + i * NTP, qc = qd < nqd ? qd : nqd - 1;
+            load_quad_f64(x, qc, xl[i]);
+#pragma unroll
+            for (int m = 0; m < NV; m++) {
+                Cq[i][m] = reinterpret_cast<const f32x4 *>(st.C + (size_t)m * D)[qc];
+                Bq[i][m] = reinterpret_cast<const f32x4 *>(dy.B + (size_t)m * D)[qc];
+            }
+        }
+        tl_stamp(tl, 1);
+        if (SPLIT) {
+            if (threadIdx.x == 0) *spin = 0u;
+            __syncthreads();   // order (see the loader role)
+            site_reduce<NV, NWP>(st, dy, tup, D, red, sr, tl, spin);
+        } else {
+            // a small pre-issue of the weight stream; more would block this wave's prologue
+            group_load<R, S, 0, pre_steps<S>()>(w, wb, stride, chunks, lane);
+            tl_stamp(tl, 2);
+            site_reduce<NV, NWP>(st, dy, tup, D, red, sr, tl);
+        }
+        if (publish_stats && blockIdx.x == 0 && threadIdx.x == 0) { dy.lnstat[0] = sr.mean; dy.lnstat[1] = sr.rstd; }
+        tl_stamp(tl, 4);
+        site_stage<NV, NQP, S, NTP>(xl, Cq, Bq, sr, xq, nqd);
+        if (SPLIT && threadIdx.x == 0) {
+#pragma unroll
+            for (int m = 0; m < NV; m++) { bc[m] = (float)sr.S[m]; bc[4 + m] = sr.amax[m]; }
+        }
+        __syncthreads();   // staged
+        group_load<R, S, SPLIT ? 0 : pre_steps<S>(), S>(w, wb, stride, chunks, lane);
+    }
+    if (SPLIT) {
+#pragma unroll
+        for (int m = 0; m < NV; m++) { sr.S[m] = (double)bc[m]; sr.amax[m] = bc[4 + m]; }
+    }
+    tl_stamp(tl, 5);
+}
+
+// Plain-vector consumer (k_attout: NVEC = 1; k_ffnv: the four quarter vectors of the hidden vector).
+// The producer left the pre-scaled vector and per-workgroup partials of the offset sum and of max|.|.
+template <int NVEC, int R, int S, bool SPLIT>
+__device__ __forceinline__ void vec_open(const float *vec, const double *partS, const float *partM, int n_part, int D, double *red,
+                                         unsigned *xq, u32x4 (&w)[R][S], const uint8_t *wb, size_t stride, float &Sf, float &amax,
+                                         unsigned long long *tl)
+{
+    constexpr int XVD = xvd<S>();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = D >> 4, nqd = D >> 2;
+    constexpr int NTP = SPLIT ? NT / 2 : NT, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
+    float *bc = reinterpret_cast<float *>(red + RED_BC);
+    unsigned *spin = reinterpret_cast<unsigned *>(bc + 8);
+    if (SPLIT && wave >= NWP) {
+        __syncthreads();   // order
+        group_load<R, S, 0, S>(w, wb, stride, chunks, lane);
+        tl_stamp(tl, 2);
+        __syncthreads();   // staged
+    } else {
+        double ps = partS[(int)threadIdx.x < n_part ? threadIdx.x : 0];
+        float pm = partM[(int)threadIdx.x < n_part ? threadIdx.x : 0];
+        float vl[NVEC][NQP][4];
+#pragma unroll
+        for (int q = 0; q < NVEC; q++)
+#pragma unroll
+            for (int i = 0; i < NQP; i++) {
+                const int qd = threadIdx.x + i * NTP, qc = qd < nqd ? qd : nqd - 1;
+                const f32x4 t = reinterpret_cast<const f32x4 *>(vec + (size_t)q * D)[qc];
+                vl[q][i][0] = t[0]; vl[q][i][1] = t[1]; vl[q][i][2] = t[2]; vl[q][i][3] = t[3];
+            }
+        tl_stamp(tl, 1);
+        if (SPLIT) {
+            if (threadIdx.x == 0) *spin = 0u;
+            __syncthreads();   // order
+        } else {
+            group_load<R, S, 0, pre_steps<S>()>(w, wb, stride, chunks, lane);
+            tl_stamp(tl, 2);
+        }
+        if ((int)threadIdx.x >= n_part) { ps = 0.0; pm = 0.f; }
+        {   // scale and offset from the producer's per-workgroup partials: one reduction round
+            float *redf = reinterpret_cast<float *>(red + RED_MAX);
+            const double ws = wave_sum(ps);
+            const float wm = wave_max(pm);
+            if (lane == 0) { red[RED_OFFS + wave] = ws; redf[wave] = wm; }
+            tl_stamp(tl, 3);
+            if (SPLIT) {
+                if (lane == 0) __hip_atomic_fetch_add(spin, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(spin, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)NWP) __builtin_amdgcn_s_sleep(1);
+            } else {
+                __syncthreads();
+            }
+            double ts = 0.0; float tm = 0.f;
+#pragma unroll
+            for (int i = 0; i < NWP; i++) { ts += red[RED_OFFS + i]; tm = fmaxf(tm, redf[i]); }
+            Sf = (float)ts; amax = tm;
+        }
+        tl_stamp(tl, 4);
+#pragma unroll
+        for (int q = 0; q < NVEC; q++)
+#pragma unroll
+            for (int i = 0; i < NQP; i++) {
+                const int qd = threadIdx.x + i * NTP;
+                if (qd < S * 256) stage_quad(xq + q * XVD, qd, vl[q][i], inv_scale(amax), qd < nqd);
+            }
+        if (SPLIT && threadIdx.x == 0) { bc[0] = Sf; bc[4] = amax; }
+        __syncthreads();   // staged
+        group_load<R, S, SPLIT ? 0 : pre_steps<S>(), S>(w, wb, stride, chunks, lane);
+    }
+    if (SPLIT) { Sf = bc[0]; amax = bc[4]; }
+    tl_stamp(tl, 5);
+}
 
 // ------------------------------------------------------------------------------------------
-struct EmbedArgs {
-    const float *embed;   // [V][D] f32 (device resident)
+struct FirstArgs {
+    const float *embed;   // [V][D] f32 (device resident), first stage only
     const double *ln;     // layernorm table; rows 0,1 = ln0 weight, bias
-    double *x;            // residual stream [D]
+    double *x;            // residual stream [D]: written (first stage) or read (later pipeline stage)
+    SiteStatic st;        // ln1 site of this stage's first layer
+    SiteDyn dy;
+    const double *sxy;    // state xy of that layer
+    size_t slot_stride;
     const Ctl *ctl;
     int D;
+    int from_token;       // 1: x = ln0(embed[token]) (rwkv.cu:513-524); 0: x was handed over by the previous stage
 };
-// rwkv.cu:513-524.  One workgroup.
-__global__ __launch_bounds__(NT) void k_embed_ln0(EmbedArgs a)
+// Produce the residual vector (first stage) and open the first layer's ln1 site.  A few workgroups,
+// each owning a slice of the channels (every one recomputes the ln0 statistics of the 16 KB row).
+__global__ __launch_bounds__(NT) void k_first(FirstArgs a)
 {
-    __shared__ double red[NW * 2];
+    __shared__ double red[RED_BYTES / 8];
     const int D = a.D;
-    const float *row = a.embed + (size_t)a.ctl->token * D;
-    double s[2] = {0.0, 0.0};
-    for (int j = threadIdx.x; j < D; j += NT) { const double v = (double)row[j]; s[0] += v; s[1] += v * v; }
-    block_sum<2>(s, red);
-    const double mean = s[0] / (double)D;
-    const double rstd = 1.0 / sqrt((s[1] - s[0] * mean) / (double)(D - 1));
-    for (int j = threadIdx.x; j < D; j += NT)
-        a.x[j] = a.ln[j] * (((double)row[j] - mean) * rstd) + a.ln[D + j];
+    const int j0 = (int)(((long long)blockIdx.x * D) / gridDim.x), j1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
+    const size_t so = (size_t)a.ctl->slot * a.slot_stride;
+    double mean = 0.0, rstd = 1.0;
+    const float *row = a.from_token ? a.embed + (size_t)a.ctl->token * D : nullptr;
+    if (a.from_token) {
+        double s[2] = {0.0, 0.0};
+        for (int j = threadIdx.x; j < D; j += NT) { const double v = (double)row[j]; s[0] += v; s[1] += v * v; }
+        block_sum<2>(s, red + RED_STATS);
+        mean = s[0] / (double)D;
+        rstd = 1.0 / sqrt((s[1] - s[0] * mean) / (double)(D - 1));
+        __syncthreads();
+    }
+    SiteAcc<3> acc;
+    acc.clear();
+    for (int j = j0 + threadIdx.x; j < j1; j += NT) {
+        double x;
+        if (a.from_token) { x = a.ln[j] * (((double)row[j] - mean) * rstd) + a.ln[D + j]; a.x[j] = x; }
+        else x = a.x[j];
+        SitePre<3> pre;
+        site_prefetch<3>(a.st, j, pre);
+        site_emit<3>(pre, a.dy, D, j, x, a.sxy[so + j], acc);
+    }
+    site_publish<3, 64>(acc, a.dy, red);
 }
 
 // ------------------------------------------------------------------------------------------
 struct AttArgs {
     const double *x;                      // residual stream [D]
-    const f32x4 *pk;                      // [3][4][D/4] packed {lnw,lnb,mixk,mixv | mixr,rk,rv,rr | ok,ov,or,0}, see k_pack_att
+    SiteStatic st;                        // ln1 site (3 vectors: k, v, r)
+    SiteDyn dy;
     const uint8_t *w;                     // [D][3][D] u8: rows K_i, V_i, R_i of channel i
-    const unsigned *rs;                   // [D][3] row sums of w (for the 2^23 limb offset)
+    const unsigned *rs;                   // [D][3] row sums of w (for the 2^22 limb offset)
     const double *uw, *ew;                // precomputed bonus+decay and exp(decay), [D]
     const float *r_att, *o_att;           // att_out scale / offset (to pre-scale the gated wkv)
-    double *sxy, *saa, *sbb;              // state arrays [slots][L][D], already offset to this layer
+    double *saa, *sbb;                    // state arrays [slots][L][D], already offset to this layer
     size_t slot_stride;                   // L*D
-    double *xx_buf;                       // [D] ln1 output, committed to sxy by k_attout
     float *ybuf;                          // [D] gated wkv * r_att (input vector of k_attout)
     double *partS;                        // [gridDim.x] partial sums of gated wkv * o_att
     float *partM;                         // [gridDim.x] partial max |ybuf| (k_attout's quantisation scale)
     const Ctl *ctl;
     int D;
+    unsigned long long *tl;               // optional phase timeline (see tl_stamp)
 };
 
-// ln1 -> mix -> K,V,R dequant-GEMV -> WKV (rwkv.cu:535-545; kernels :351-392, :58-100, :221-259)
+// ln1 site -> K,V,R dequant-GEMV -> WKV (rwkv.cu:535-545; kernels :351-392, :58-100, :221-259)
 template <int S>
 __global__ __launch_bounds__(NT) void k_att(AttArgs a)
 {
@@ -410,89 +781,41 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
 
-    // (1) prologue inputs
-    double xl[NQ][4], pv[NQ][4];
-    f32x4 P[NQ][4][3];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
-        load_quad_f64(a.x, qc, xl[i]);
-        load_quad_f64(a.sxy + so, qc, pv[i]);
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-#pragma unroll
-            for (int q = 0; q < 3; q++) P[i][e][q] = a.pk[(q * 4 + e) * nqd + qc];   // [piece][elem-in-quad][quad]: lane-contiguous
-    }
-    // (2) first steps of the first group's weights.  Unconditional (a wave without a group re-reads
-    // a neighbour's rows): a branch around the loads would make hipcc's waitcnt pass assume the
-    // no-load path and drain the weights early.
+    tl_stamp(a.tl, 0);
     u32x4 w[3][S];
     int g = g0 + wave;
+    unsigned *gctr = group_counter(red);
+    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NW);   // visible behind the prologue's barriers
+    // every wave requests a first group, even one without work (it re-reads a neighbour's rows): a
+    // branch around the loads would make hipcc's waitcnt pass drain the weights early
     const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 3 * D;
-    group_load<3, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
+    SiteRed<3> sr;
+    site_open<3, 3, S, (RWKV_SPLIT & 1) != 0>(a.st, a.dy, a.x, D, red, xq, w, wb, (size_t)D, sr, true, a.tl);
+    const double sc[3] = {scale_of(sr.amax[0]), scale_of(sr.amax[1]), scale_of(sr.amax[2])};
 
-    // (3) LayerNorm, token-shift mix, pre-scale by the per-row quantisation scale
-    double mean, rstd;
-    ln_stats<NQ>(xl, D, mean, rstd, red);
-    double Ssum[3] = {0.0, 0.0, 0.0};
-    float amax[3] = {0.f, 0.f, 0.f};
-    float xr[NQ][3][4];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = threadIdx.x + i * NT;
-        const bool real = qd < nqd;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const double xx = (double)P[i][e][0][0] * ((xl[i][e] - mean) * rstd) + (double)P[i][e][0][1];
-            const double prev = pv[i][e];
-            const double mk = (double)P[i][e][0][2], mv = (double)P[i][e][0][3], mr = (double)P[i][e][1][0];
-            const float fk = (float)(mk * xx + (1.0 - mk) * prev);   // rwkv.cu:382-384: rounded to f32
-            const float fv = (float)(mv * xx + (1.0 - mv) * prev);
-            const float fr = (float)(mr * xx + (1.0 - mr) * prev);
-            xr[i][0][e] = fk * P[i][e][1][1]; xr[i][1][e] = fv * P[i][e][1][2]; xr[i][2][e] = fr * P[i][e][1][3];
-            if (real) {
-                Ssum[0] += (double)(fk * P[i][e][2][0]); Ssum[1] += (double)(fv * P[i][e][2][1]); Ssum[2] += (double)(fr * P[i][e][2][2]);
-#pragma unroll
-                for (int m = 0; m < 3; m++) amax[m] = fmaxf(amax[m], fabsf(xr[i][m][e]));
-                if (qd * 4 + e >= g0 && qd * 4 + e < g1) a.xx_buf[qd * 4 + e] = xx;   // every workgroup publishes the channels it owns (not one straggler all of them)
-            }
-        }
-    }
-    block_max<3>(amax, red + RED_MAX);
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = threadIdx.x + i * NT;
-        if (qd < S * 256) {
-#pragma unroll
-            for (int m = 0; m < 3; m++) stage_quad(xq + m * XVD, qd, xr[i][m], inv_scale(amax[m]), qd < nqd);
-        }
-    }
-    __syncthreads();                                                       // staged vectors visible
-    // the bulk of the first group is requested only now: its issue stalls on the full memory pipe,
-    // and a stall in front of a workgroup barrier would make every wave wait for the slowest one
-    group_load<3, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);
-    const double sc[3] = {scale_of(amax[0]), scale_of(amax[1]), scale_of(amax[2])};
-
-    for (; g < g1; g += NW) {
+    int gn = next_group(gctr, g);   // the group whose rows refill the registers during the next dot
+    while (g < g1) {
         unsigned long long T[3];
-        const bool nv = g + NW < g1;
+        const bool nv = gn < g1;
+        const int gnn = nv ? next_group(gctr, gn) : g1;
         // per-group epilogue inputs are requested BEFORE the dot issues the refill loads: a load
         // placed after them would, by in-order vmcnt, wait for the whole next group to land
         const unsigned rsum = a.rs[g * 3 + (lane < 3 ? lane : 0)];
-        group_dot<3, S, PAT_PER_ROW>(w, xq, lane, T, a.w + (size_t)(nv ? g + NW : 0) * 3 * D, (size_t)D, chunks, nv);
+        group_dot<3, S, PAT_PER_ROW>(w, xq, lane, T, a.w + (size_t)(nv ? gn : 0) * 3 * D, (size_t)D, chunks, nv);
 #pragma unroll
         for (int m = 0; m < 3; m++)
-            if (lane == m) stash[(g - g0) * 3 + m] = row_value(T[m], rsum, sc[m]);
+            if (lane == m) stash[(g - g0) * 3 + m] = row_value(T[m], rsum, sc[m]) + (float)sr.S[m];
+        g = gn; gn = gnn;
     }
-    block_sum<3>(Ssum, red + RED_OFFS);   // offset terms: only needed by the epilogue (also the barrier before it)
+    __syncthreads();
+    tl_stamp(a.tl, 6);
 
     // WKV recurrence + receptance gate, one lane per channel (rwkv.cu:242-255)
     double part[1] = {0.0};
     float pmax[1] = {0.f};
     if ((int)threadIdx.x < g1 - g0) {
         const int i = g0 + threadIdx.x;
-        const float k = stash[threadIdx.x * 3 + 0] + (float)Ssum[0], v = stash[threadIdx.x * 3 + 1] + (float)Ssum[1],
-                    r = stash[threadIdx.x * 3 + 2] + (float)Ssum[2];
+        const float k = stash[threadIdx.x * 3 + 0], v = stash[threadIdx.x * 3 + 1], r = stash[threadIdx.x * 3 + 2];
         const double aa = a.saa[so + i], bb = a.sbb[so + i];
         const double vv = (double)v;
         const double e1 = exp(a.uw[i] + (double)k);
@@ -510,6 +833,7 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     block_sum<1>(part, red + RED_PART);
     block_max<1>(pmax, red + RED_AUX);
     if (threadIdx.x == 0) { a.partS[blockIdx.x] = part[0]; a.partM[blockIdx.x] = pmax[0]; }
+    tl_stamp(a.tl, 7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -521,14 +845,20 @@ struct AttOutArgs {
     const float *partM;    // [n_part] partial max |ybuf|
     int n_part;
     double *x;             // residual stream, updated in place (row-owned)
-    const double *xx_buf;  // ln1 output of this token -> new state xy
+    const double *lnw, *lnb;   // ln1 rows of this layer (f64): the state xy written here is ln1's output
+    const double *lnstat;  // [2] mean, rstd of the ln1 site (published by k_att)
     double *sxy;           // state xy of this layer
+    SiteStatic st;         // ln2 site (2 vectors) that this kernel opens for k_ffn_rk
+    SiteDyn dy;
+    const double *sdd;     // state dd of this layer (the ln2 site's prev)
     size_t slot_stride;
     const Ctl *ctl;
     int D;
+    unsigned long long *tl;
 };
 
-// att_out dequant-GEMV + residual through f32 (rwkv.cu:548-553), R rows per group
+// att_out dequant-GEMV + residual through f32 (rwkv.cu:548-553), R rows per group; commits state xy;
+// opens the ln2 site for the rows it owns
 template <int S, int R>
 __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
 {
@@ -538,86 +868,70 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = D >> 4, nqd = D >> 2;
+    tl_stamp(a.tl, 0);
     const int G = (D + R - 1) / R;
     const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
 
-    float yl[NQ][4];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
-        const f32x4 t = reinterpret_cast<const f32x4 *>(a.ybuf)[qc];
-        yl[i][0] = t[0]; yl[i][1] = t[1]; yl[i][2] = t[2]; yl[i][3] = t[3];
-    }
-    double Ssum[1] = {a.partS[(int)threadIdx.x < a.n_part ? threadIdx.x : 0]};
-    float amax[1] = {a.partM[(int)threadIdx.x < a.n_part ? threadIdx.x : 0]};
+    const double mean1 = a.lnstat[0], rstd1 = a.lnstat[1];
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
-
     u32x4 w[R][S];
     int g = g0 + wave;
+    unsigned *gctr = group_counter(red);
+    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NW);   // visible behind the prologue's barriers
     auto rowbase = [&](int gg) {
         int row = gg * R;
         if (row > D - R) row = D - R;
         return a.w + (size_t)row * D;
     };
     const uint8_t *wb = rowbase(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0));
-    group_load<R, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
+    float Sf, amax;
+    vec_open<1, R, S, (RWKV_SPLIT & 2) != 0>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, w, wb, (size_t)D, Sf, amax, a.tl);
+    const double sc = scale_of(amax);
+    SiteAcc<2> acc;
+    acc.clear();
 
-    // scale and offset come from the producer's per-workgroup partials: one reduction round
-    if ((int)threadIdx.x >= a.n_part) { Ssum[0] = 0.0; amax[0] = 0.f; }
-    {
-        float *redf = reinterpret_cast<float *>(red + RED_MAX);
-        const double ws = wave_sum(Ssum[0]);
-        const float wm = wave_max(amax[0]);
-        if (lane == 0) { red[RED_OFFS + wave] = ws; redf[wave] = wm; }
-        __syncthreads();
-        double ts = 0.0; float tm = 0.f;
-#pragma unroll
-        for (int i = 0; i < NW; i++) { ts += red[RED_OFFS + i]; tm = fmaxf(tm, redf[i]); }
-        Ssum[0] = ts; amax[0] = tm;
-    }
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = threadIdx.x + i * NT;
-        if (qd < S * 256) stage_quad(xq, qd, yl[i], inv_scale(amax[0]), qd < nqd);
-    }
-    __syncthreads();   // staged vector visible
-    group_load<R, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
-    const float Sf = (float)Ssum[0];
-    const double sc = scale_of(amax[0]);
-
-    for (; g < g1; g += NW) {
+    int gn = next_group(gctr, g);   // the group whose rows refill the registers during the next dot
+    while (g < g1) {
         unsigned long long T[R];
-        const bool nv = g + NW < g1;
+        const bool nv = gn < g1;
+        const int gnn = nv ? next_group(gctr, gn) : g1;
         int row0 = g * R;
         const int shift = (row0 > D - R) ? row0 - (D - R) : 0;   // last group may overlap the previous one
         row0 -= shift;
-        // epilogue inputs first (see k_att): lane r owns row row0 + r
+        // epilogue inputs first (before the refills): lane r owns row row0 + r
         const int mi = row0 + (lane < R ? lane : 0);
         const unsigned rsum = a.rs[mi];
-        const double xold = a.x[mi], xxn = a.xx_buf[mi];
-        group_dot<R, S, PAT_SHARED>(w, xq, lane, T, rowbase(nv ? g + NW : 0), (size_t)D, chunks, nv);
+        const double xold = a.x[mi], lw = a.lnw[mi], lb = a.lnb[mi], prev2 = a.sdd[so + mi];
+        SitePre<2> pre;
+        site_prefetch<2>(a.st, mi, pre);
+        group_dot<R, S, PAT_SHARED>(w, xq, lane, T, rowbase(nv ? gn : 0), (size_t)D, chunks, nv);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (lane == r && r >= shift) {
-                const float acc = (float)xold + (row_value(T[r], rsum, sc) + Sf);   // f32 accumulator pre-loaded with x (:548)
-                a.x[mi] = (double)acc;                                              // :553
-                a.sxy[so + mi] = xxn;                                               // mixatt's state write (:385), deferred
+                const float accf = (float)xold + (row_value(T[r], rsum, sc) + Sf);   // f32 accumulator pre-loaded with x (:548)
+                const double xnew = (double)accf;                                     // :553
+                a.x[mi] = xnew;
+                a.sxy[so + mi] = lw * ((xold - mean1) * rstd1) + lb;                  // mixatt's state write (:385): ln1 output
+                site_emit<2>(pre, a.dy, D, mi, xnew, prev2, acc);
             }
         }
+        g = gn; gn = gnn;
     }
+    __syncthreads();   // every wave is past its last read of the reduction scratch
+    tl_stamp(a.tl, 6);
+    site_publish<2, R>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
+    tl_stamp(a.tl, 7);
 }
 
 // ------------------------------------------------------------------------------------------
 struct FfnRKArgs {
     const double *x;
-    const f32x4 *pk;                  // [2][4][D/4] packed {lnw,lnb,mixk,mixr | rk,ok,rr,or}, see k_pack_ffn
+    SiteStatic st;                    // ln2 site (2 vectors: ffn k, ffn r)
+    SiteDyn dy;
     const uint8_t *w;                 // [D][5][D]: rows ffn_k out 4i..4i+3, then ffn_r out i
     const unsigned *rs;               // [D][5] row sums
     const float *r_fv, *o_fv;         // ffn_v scale / offset [4D]
-    const double *sdd;                // state dd of this layer (read only here)
-    size_t slot_stride;
-    double *xx_buf;                   // [D] ln2 output -> committed to sdd by k_ffnv
     float *hbuf;                      // [4D] relu^2(k) * r_fv
     float *rgate;                     // [D] sigmoid(r)
     double *partS;                    // [gridDim.x]
@@ -627,7 +941,7 @@ struct FfnRKArgs {
     unsigned long long *tl;           // optional phase timeline (see tl_stamp)
 };
 
-// ln2 -> mix -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573)
+// ln2 site -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573)
 template <int S>
 __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
 {
@@ -641,88 +955,37 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     const int chunks = D >> 4, nqd = D >> 2;
     const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
-    const size_t so = (size_t)a.ctl->slot * a.slot_stride;
     tl_stamp(a.tl, 0);
 
-    double xl[NQ][4], pv[NQ][4];
-    f32x4 P[NQ][4][2];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
-        load_quad_f64(a.x, qc, xl[i]);
-        load_quad_f64(a.sdd + so, qc, pv[i]);
-#pragma unroll
-        for (int e = 0; e < 4; e++) { P[i][e][0] = a.pk[e * nqd + qc]; P[i][e][1] = a.pk[(4 + e) * nqd + qc]; }   // lane-contiguous
-    }
     u32x4 w[5][S];
     int g = g0 + wave;
-#ifdef RWKV_EXP_SAMEROWS   // timing experiment only: waves stream 64 cache-resident groups -> compute-only time
-#define RWKV_EXP_G(gg) ((gg) % 64)
-#else
-#define RWKV_EXP_G(gg) (gg)
-#endif
-    const uint8_t *wb = a.w + (size_t)RWKV_EXP_G(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 5 * D;
-    group_load<5, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
-    tl_stamp(a.tl, 1);
+    unsigned *gctr = group_counter(red);
+    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NW);   // visible behind the prologue's barriers
+    const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 5 * D;
+    SiteRed<2> sr;
+    site_open<2, 5, S, (RWKV_SPLIT & 4) != 0>(a.st, a.dy, a.x, D, red, xq, w, wb, (size_t)D, sr, true, a.tl);
+    const double sc[2] = {scale_of(sr.amax[0]), scale_of(sr.amax[1])};
 
-    double mean, rstd;
-    ln_stats<NQ>(xl, D, mean, rstd, red);
-    tl_stamp(a.tl, 2);
-    double Ssum[2] = {0.0, 0.0};
-    float amax[2] = {0.f, 0.f};
-    float xr[NQ][2][4];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = threadIdx.x + i * NT;
-        const bool real = qd < nqd;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const double xx = (double)P[i][e][0][0] * ((xl[i][e] - mean) * rstd) + (double)P[i][e][0][1];
-            const double prev = pv[i][e];
-            const double mk = (double)P[i][e][0][2], mr = (double)P[i][e][0][3];
-            const float fk = (float)(mk * xx + (1.0 - mk) * prev);   // f64 mix (:341-342), f32 cast in the GEMV (:290)
-            const float fr = (float)(mr * xx + (1.0 - mr) * prev);
-            xr[i][0][e] = fk * P[i][e][1][0]; xr[i][1][e] = fr * P[i][e][1][2];
-            if (real) {
-                Ssum[0] += (double)(fk * P[i][e][1][1]); Ssum[1] += (double)(fr * P[i][e][1][3]);
-                amax[0] = fmaxf(amax[0], fabsf(xr[i][0][e])); amax[1] = fmaxf(amax[1], fabsf(xr[i][1][e]));
-                if (qd * 4 + e >= g0 && qd * 4 + e < g1) a.xx_buf[qd * 4 + e] = xx;   // every workgroup publishes the channels it owns (not one straggler all of them)
-            }
-        }
-    }
-    block_max<2>(amax, red + RED_MAX);
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = threadIdx.x + i * NT;
-        if (qd < S * 256) {
-            stage_quad(xq, qd, xr[i][0], inv_scale(amax[0]), qd < nqd);
-            stage_quad(xq + XVD, qd, xr[i][1], inv_scale(amax[1]), qd < nqd);
-        }
-    }
-    __syncthreads();
-    tl_stamp(a.tl, 3);
-    group_load<5, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
-    const double sc[2] = {scale_of(amax[0]), scale_of(amax[1])};
-    bool first_ = true;
-
-    for (; g < g1; g += NW) {
+    int gn = next_group(gctr, g);   // the group whose rows refill the registers during the next dot
+    while (g < g1) {
         unsigned long long T[5];
-        const bool nv = g + NW < g1;
+        const bool nv = gn < g1;
+        const int gnn = nv ? next_group(gctr, gn) : g1;
         const unsigned rsum = a.rs[g * 5 + (lane < 5 ? lane : 0)];   // before the refills (see k_att)
-        group_dot<5, S, PAT_FFN_RK>(w, xq, lane, T, a.w + (size_t)RWKV_EXP_G(nv ? g + NW : 0) * 5 * D, (size_t)D, chunks, nv);
+        group_dot<5, S, PAT_FFN_RK>(w, xq, lane, T, a.w + (size_t)(nv ? gn : 0) * 5 * D, (size_t)D, chunks, nv);
 #pragma unroll
         for (int r = 0; r < 5; r++)
-            if (lane == r) stash[(g - g0) * 5 + r] = row_value(T[r], rsum, sc[r < 4 ? 0 : 1]);
-        if (first_) { tl_stamp(a.tl, 4); first_ = false; }
+            if (lane == r) stash[(g - g0) * 5 + r] = row_value(T[r], rsum, sc[r < 4 ? 0 : 1]) + (float)sr.S[r < 4 ? 0 : 1];
+        g = gn; gn = gnn;
     }
-    block_sum<2>(Ssum, red + RED_OFFS);   // offset terms: only needed by the epilogue (also the barrier before it)
-    tl_stamp(a.tl, 5);
+    __syncthreads();
+    tl_stamp(a.tl, 6);
 
     double part[1] = {0.0};
     float pmax[1] = {0.f};
     for (int t = threadIdx.x; t < 5 * (g1 - g0); t += NT) {
         const int q = t % 5, i = g0 + t / 5;
-        const float val = stash[t] + (float)Ssum[q < 4 ? 0 : 1];
+        const float val = stash[t];
         if (q < 4) {
             float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
             h = h * h;
@@ -738,289 +1001,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     block_sum<1>(part, red + RED_PART);
     block_max<1>(pmax, red + RED_AUX);
     if (threadIdx.x == 0) { a.partS[blockIdx.x] = part[0]; a.partM[blockIdx.x] = pmax[0]; }
-    tl_stamp(a.tl, 6);
-}
-
-// ------------------------------------------------------------------------------------------
-// Wave-specialised variant: loader waves + LDS ring.
-//
-// Measured on MI355X (tools/timeline.py): in the all-waves-do-everything kernels above the weight
-// stream and the prologue fight for the same in-order waves -- a wave that has asked for more loads
-// than the memory pipe accepts stalls AT ISSUE and cannot run its share of the prologue, and a
-// wave that asks for little leaves HBM idle for the ~6 us the prologue takes.  Here the roles are
-// split inside the workgroup: NL loader waves do nothing but copy the workgroup's (contiguous)
-// weight region HBM -> registers -> LDS ring, one row group per ring slot, two groups in flight per
-// loader; the other NC waves run the prologue and then drain the ring with the same dot4 code.
-// The ring fills while the prologue runs, so the stream never waits for it.
-// No s_barrier after the role split (it would need the loaders): the consumers synchronise among
-// themselves through LDS counters; every spin is bounded.
-constexpr int NL = 2;           // loader waves
-constexpr int NC = NW - NL;     // consumer waves
-constexpr int NCT = NC * 64;    // consumer threads
-struct RingCtl {
-    unsigned ready[8];          // ready[slot] = generation whose data is complete in the slot
-    unsigned done[8];           // done[slot]  = generation the consumers have finished reading
-    unsigned bar;               // consumer barrier arrivals
-    unsigned err;               // a bounded spin gave up
-    unsigned go;                // consumer waves whose prologue loads have landed (loaders start at NC)
-    unsigned pad[13];
-};
-__device__ __forceinline__ bool spin_ge(unsigned *p, unsigned want, unsigned *err)
-{
-    for (int i = 0; i < (1 << 22); i++) {
-        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return false;
-}
-// barrier among the NC consumer waves only (phase counts the barriers executed so far)
-__device__ __forceinline__ void cbar(RingCtl *rc, unsigned &phase)
-{
-    phase++;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&rc->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    spin_ge(&rc->bar, phase * NC, &rc->err);
-}
-// reductions among the consumer waves; `red` must be a scratch region that is not reused by a
-// later reduction before every wave has read it (callers pass distinct regions), so one barrier each
-template <int K>
-__device__ __forceinline__ void csum(double (&v)[K], double *red, RingCtl *rc, unsigned &phase, int cw)
-{
-#pragma unroll
-    for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < K; k++) red[cw * K + k] = v[k];
-    }
-    cbar(rc, phase);
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        double t = 0.0;
-#pragma unroll
-        for (int i = 0; i < NC; i++) t += red[i * K + k];
-        v[k] = t;
-    }
-}
-template <int K>
-__device__ __forceinline__ void cmax(float (&v)[K], double *redd, RingCtl *rc, unsigned &phase, int cw)
-{
-    float *red = reinterpret_cast<float *>(redd);
-#pragma unroll
-    for (int k = 0; k < K; k++) v[k] = wave_max(v[k]);
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < K; k++) red[cw * K + k] = v[k];
-    }
-    cbar(rc, phase);
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < NC; i++) t = fmaxf(t, red[i * K + k]);
-        v[k] = t;
-    }
-}
-
-// loader wave `lw`: copies groups lw, lw+NL, ... (gbytes each, contiguous from `base`) into the ring.
-// NLD = 1 KiB wave-loads per group.  Two register sets: the next group's loads are in flight while
-// the current one is written to LDS.  The issue is branch-free (see group_dot's refill).
-template <int NLD, int NSLOT>
-__device__ __forceinline__ void ring_loader(const uint8_t *__restrict__ base, unsigned gbytes, int ng, unsigned char *ring,
-                                            RingCtl *rc, int lw, int lane)
-{
-    u32x4 A[NLD], B[NLD];
-    auto issue = [&](u32x4 (&buf)[NLD], int gi) {
-        const bool valid = gi < ng;
-        const uint8_t *gb = base + (size_t)(valid ? gi : 0) * gbytes;
-        const unsigned mask = valid ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int i = 0; i < NLD; i++) {
-            unsigned off = (unsigned)(i * 1024 + lane * 16);
-            off = off < gbytes ? off : gbytes - 16;
-            buf[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(gb + (off & mask)));
-        }
-    };
-    auto drain = [&](u32x4 (&buf)[NLD], int gi) {
-        const int slot = gi % NSLOT;
-        const unsigned gen = (unsigned)(gi / NSLOT) + 1u;
-        if (gen > 1u) spin_ge(&rc->done[slot], gen - 1u, &rc->err);   // previous tenant fully consumed
-        unsigned char *dst = ring + (size_t)slot * gbytes;
-#pragma unroll
-        for (int i = 0; i < NLD; i++) {
-            const unsigned off = (unsigned)(i * 1024 + lane * 16);
-            if (off < gbytes) *reinterpret_cast<u32x4 *>(dst + off) = buf[i];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&rc->ready[slot], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    int gi = lw;
-    issue(A, gi);
-    while (gi < ng) {
-        issue(B, gi + NL);
-        drain(A, gi);
-        gi += NL;
-        if (gi >= ng) break;
-        issue(A, gi + NL);
-        drain(B, gi);
-        gi += NL;
-    }
-}
-
-// consumer: fetch the R*S pieces of the group in ring slot `slot` into registers
-template <int R, int S>
-__device__ __forceinline__ void ring_fetch(u32x4 (&w)[R][S], const unsigned char *slot, int D, int chunks, int lane)
-{
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        int c = lane + 64 * s;
-        c = c < chunks ? c : chunks - 1;
-#pragma unroll
-        for (int r = 0; r < R; r++) w[r][s] = *reinterpret_cast<const u32x4 *>(slot + (size_t)r * D + ((unsigned)c << 4));
-    }
-}
-
-// ln2 -> mix -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573): loader/consumer variant
-template <int S, int NSLOT>
-__global__ __launch_bounds__(NT) void k_ffn_rk_ring(FfnRKArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XVD = xvd<S>();
-    constexpr int NQ = (S * 256 + NCT - 1) / NCT;      // quads per consumer thread
-    RingCtl *rc = reinterpret_cast<RingCtl *>(smem);
-    double *red = reinterpret_cast<double *>(smem + 128);
-    unsigned *xq = reinterpret_cast<unsigned *>(smem + 128 + RED_BYTES);
-    float *stash = reinterpret_cast<float *>(xq + 2 * XVD);
-    const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4, nqd = D >> 2;
-    const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
-    const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
-    const int ng = g1 - g0;
-    const int gpb = (D + gridDim.x - 1) / gridDim.x + 1;
-    unsigned char *ring = reinterpret_cast<unsigned char *>(stash + ((gpb * 5 + 3) & ~3));
-    const unsigned gbytes = 5u * (unsigned)D;
-
-    if (threadIdx.x < 32) reinterpret_cast<unsigned *>(rc)[threadIdx.x] = 0u;
-    __syncthreads();   // the only full-workgroup barrier: ring control words are zero
-    tl_stamp(a.tl, 0);
-
-    if (wave < NL) {   // ---------------- loader waves ----------------
-        // The CU's vector-memory pipe is shared: prologue loads (L2 hits) issued behind a saturating
-        // HBM stream see HBM-like latency (measured: staging 6 -> 11 us).  So the stream starts
-        // only when every consumer wave has RECEIVED its prologue inputs (~2 us), and then runs
-        // under the prologue's arithmetic.
-        spin_ge(&rc->go, NC, &rc->err);
-        ring_loader<5 * S, NSLOT>(a.w + (size_t)g0 * gbytes, gbytes, ng, ring, rc, wave, lane);
-        return;
-    }
-    // ---------------- consumer waves ----------------
-    const int cw = wave - NL, ct = threadIdx.x - NL * 64;
-    unsigned phase = 0;
-    const size_t so = (size_t)a.ctl->slot * a.slot_stride;
-    double xl[NQ][4], pv[NQ][4];
-    f32x4 P[NQ][4][2];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = ct + i * NCT, qc = qd < nqd ? qd : nqd - 1;
-        load_quad_f64(a.x, qc, xl[i]);
-        load_quad_f64(a.sdd + so, qc, pv[i]);
-#pragma unroll
-        for (int e = 0; e < 4; e++) { P[i][e][0] = a.pk[e * nqd + qc]; P[i][e][1] = a.pk[(4 + e) * nqd + qc]; }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // prologue inputs are in registers: release the loaders
-    if (lane == 0) __hip_atomic_fetch_add(&rc->go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    tl_stamp(a.tl, 1);
-    double st[2] = {0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const bool real = (ct + i * NCT) < nqd;
-#pragma unroll
-        for (int e = 0; e < 4; e++) { const double v = real ? xl[i][e] : 0.0; st[0] += v; st[1] += v * v; }
-    }
-    csum<2>(st, red, rc, phase, cw);
-    const double mean = st[0] / (double)D;
-    const double rstd = 1.0 / sqrt((st[1] - st[0] * mean) / (double)(D - 1));
-    tl_stamp(a.tl, 2);
-    double Ssum[2] = {0.0, 0.0};
-    float amax[2] = {0.f, 0.f};
-    float xr[NQ][2][4];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = ct + i * NCT;
-        const bool real = qd < nqd;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const double xx = (double)P[i][e][0][0] * ((xl[i][e] - mean) * rstd) + (double)P[i][e][0][1];
-            const double prev = pv[i][e];
-            const double mk = (double)P[i][e][0][2], mr = (double)P[i][e][0][3];
-            const float fk = (float)(mk * xx + (1.0 - mk) * prev);
-            const float fr = (float)(mr * xx + (1.0 - mr) * prev);
-            xr[i][0][e] = fk * P[i][e][1][0]; xr[i][1][e] = fr * P[i][e][1][2];
-            if (real) {
-                Ssum[0] += (double)(fk * P[i][e][1][1]); Ssum[1] += (double)(fr * P[i][e][1][3]);
-                amax[0] = fmaxf(amax[0], fabsf(xr[i][0][e])); amax[1] = fmaxf(amax[1], fabsf(xr[i][1][e]));
-                if (qd * 4 + e >= g0 && qd * 4 + e < g1) a.xx_buf[qd * 4 + e] = xx;   // every workgroup publishes the channels it owns (not one straggler all of them)
-            }
-        }
-    }
-    cmax<2>(amax, red + 16, rc, phase, cw);
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = ct + i * NCT;
-        if (qd < S * 256) {
-            stage_quad(xq, qd, xr[i][0], inv_scale(amax[0]), qd < nqd);
-            stage_quad(xq + XVD, qd, xr[i][1], inv_scale(amax[1]), qd < nqd);
-        }
-    }
-    cbar(rc, phase);   // staged vectors visible to all consumers
-    tl_stamp(a.tl, 3);
-    const double sc[2] = {scale_of(amax[0]), scale_of(amax[1])};
-    bool first_ = true;
-
-    for (int gi = cw; gi < ng; gi += NC) {
-        const int slot = gi % NSLOT;
-        const unsigned gen = (unsigned)(gi / NSLOT) + 1u;
-        const unsigned rsum = a.rs[(g0 + gi) * 5 + (lane < 5 ? lane : 0)];
-        spin_ge(&rc->ready[slot], gen, &rc->err);
-        u32x4 w[5][S];
-        ring_fetch<5, S>(w, ring + (size_t)slot * gbytes, D, chunks, lane);
-        unsigned long long T[5];
-        group_dot<5, S, PAT_FFN_RK, false>(w, xq, lane, T, nullptr, 0, chunks, false);
-        // every lane's ring reads were consumed by the dots above: the slot may be refilled
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&rc->done[slot], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int r = 0; r < 5; r++)
-            if (lane == r) stash[gi * 5 + r] = row_value(T[r], rsum, sc[r < 4 ? 0 : 1]);
-        if (first_) { tl_stamp(a.tl, 4); first_ = false; }
-    }
-    csum<2>(Ssum, red + 32, rc, phase, cw);   // offset terms + barrier: all stashes written
-    tl_stamp(a.tl, 5);
-
-    double part[1] = {0.0};
-    float pmax[1] = {0.f};
-    for (int t = ct; t < 5 * ng; t += NCT) {
-        const int q = t % 5, i = g0 + t / 5;
-        const float val = stash[t] + (float)Ssum[q < 4 ? 0 : 1];
-        if (q < 4) {
-            float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
-            h = h * h;
-            const int kk = 4 * i + q;
-            const float hs = h * a.r_fv[kk];
-            a.hbuf[kk] = hs;
-            part[0] += (double)(h * a.o_fv[kk]);
-            pmax[0] = fmaxf(pmax[0], fabsf(hs));
-        } else {
-            a.rgate[i] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
-        }
-    }
-    csum<1>(part, red + 48, rc, phase, cw);
-    cmax<1>(pmax, red + 56, rc, phase, cw);
-    if (ct == 0) { a.partS[blockIdx.x] = part[0]; a.partM[blockIdx.x] = pmax[0]; }
-    tl_stamp(a.tl, 6);
+    tl_stamp(a.tl, 7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1033,15 +1014,20 @@ struct FfnVArgs {
     int n_part;
     const float *rgate;    // [D]
     double *x;             // residual stream (row-owned update)
-    const double *xx_buf;  // ln2 output -> new state dd
+    const double *lnw, *lnb;   // ln2 rows of this layer: the state dd written here is ln2's output
+    const double *lnstat;  // [2] mean, rstd of the ln2 site (published by k_ffn_rk)
     double *sdd;
+    SiteStatic st;         // the NEXT site: ln1 of layer l+1 (3 vectors) or ln_out -> head (1 vector)
+    SiteDyn dy;
+    const double *sprev;   // state xy of layer l+1 (prev of the next ln1 site); unused for the head site
     size_t slot_stride;
     const Ctl *ctl;
     int D;
+    unsigned long long *tl;
 };
 
-// ffn_v dequant-GEMV, x += v * sigmoid(r) (rwkv.cu:574-577)
-template <int S>
+// ffn_v dequant-GEMV, x += v * sigmoid(r) (rwkv.cu:574-577); commits state dd; opens the next site
+template <int S, int NVN>
 __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1051,70 +1037,55 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = D >> 4, nqd = D >> 2;
+    tl_stamp(a.tl, 0);
     const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
 
-    float hl[4][NQ][4];
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-            const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
-            const f32x4 t = reinterpret_cast<const f32x4 *>(a.hbuf + (size_t)q * D)[qc];
-            hl[q][i][0] = t[0]; hl[q][i][1] = t[1]; hl[q][i][2] = t[2]; hl[q][i][3] = t[3];
-        }
-    double Ssum[1] = {a.partS[(int)threadIdx.x < a.n_part ? threadIdx.x : 0]};
-    float amax[1] = {a.partM[(int)threadIdx.x < a.n_part ? threadIdx.x : 0]};   // one scale for the whole 4D vector
+    const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
-
     u32x4 w[4][S];
     int g = g0 + wave;
+    unsigned *gctr = group_counter(red);
+    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NW);   // visible behind the prologue's barriers
     const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 4 * D;
-    group_load<4, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
+    float Sf, amax;   // one scale for the whole 4D hidden vector
+    vec_open<4, 4, S, (RWKV_SPLIT & 8) != 0>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, w, wb, (size_t)D, Sf, amax, a.tl);
+    const double sc = scale_of(amax);
+    SiteAcc<NVN> acc;
+    acc.clear();
 
-    if ((int)threadIdx.x >= a.n_part) { Ssum[0] = 0.0; amax[0] = 0.f; }
-    {   // scale and offset from the producer's per-workgroup partials: one reduction round
-        float *redf = reinterpret_cast<float *>(red + RED_MAX);
-        const double ws = wave_sum(Ssum[0]);
-        const float wm = wave_max(amax[0]);
-        if (lane == 0) { red[RED_OFFS + wave] = ws; redf[wave] = wm; }
-        __syncthreads();
-        double ts = 0.0; float tm = 0.f;
-#pragma unroll
-        for (int i = 0; i < NW; i++) { ts += red[RED_OFFS + i]; tm = fmaxf(tm, redf[i]); }
-        Ssum[0] = ts; amax[0] = tm;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-            const int qd = threadIdx.x + i * NT;
-            if (qd < S * 256) stage_quad(xq + q * XVD, qd, hl[q][i], inv_scale(amax[0]), qd < nqd);
-        }
-    __syncthreads();   // staged vector visible
-    group_load<4, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
-    const float Sf = (float)Ssum[0];
-    const double sc = scale_of(amax[0]);
-
-    for (; g < g1; g += NW) {
+    int gn = next_group(gctr, g);   // the group whose rows refill the registers during the next dot
+    while (g < g1) {
         unsigned long long T[4];
-        const bool nv = g + NW < g1;
+        const bool nv = gn < g1;
+        const int gnn = nv ? next_group(gctr, gn) : g1;
         const unsigned rsum = a.rs[g];   // epilogue inputs before the refills (see k_att)
-        const double xold = a.x[g], xxn = a.xx_buf[g];
+        const double xold = a.x[g], lw = a.lnw[g], lb = a.lnb[g];
+        const double prevn = NVN == 3 ? a.sprev[so + g] : 0.0;
         const float rg = a.rgate[g];
-        group_dot<4, S, PAT_PER_ROW>(w, xq, lane, T, a.w + (size_t)(nv ? g + NW : 0) * 4 * D, (size_t)D, chunks, nv);
+        SitePre<NVN> pre;
+        site_prefetch<NVN>(a.st, g, pre);
+        group_dot<4, S, PAT_PER_ROW>(w, xq, lane, T, a.w + (size_t)(nv ? gn : 0) * 4 * D, (size_t)D, chunks, nv);
         if (lane == 0) {
             const float v = row_value((T[0] + T[1]) + (T[2] + T[3]), rsum, sc) + Sf;
-            a.x[g] = xold + (double)(v * rg);   // blockout, rwkv.cu:407 (f32 product)
-            a.sdd[so + g] = xxn;                 // mixffn's state write (:344), deferred
+            const double xnew = xold + (double)(v * rg);        // blockout, rwkv.cu:407 (f32 product)
+            a.x[g] = xnew;
+            a.sdd[so + g] = lw * ((xold - mean2) * rstd2) + lb;  // mixffn's state write (:344): ln2 output
+            site_emit<NVN>(pre, a.dy, D, g, xnew, prevn, acc);
         }
+        g = gn; gn = gnn;
     }
+    __syncthreads();   // every wave is past its last read of the reduction scratch
+    tl_stamp(a.tl, 6);
+    site_publish<NVN, 1>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
+    tl_stamp(a.tl, 7);
 }
 
 // ------------------------------------------------------------------------------------------
 struct HeadArgs {
     const double *x;
-    const f32x4 *pk;           // [4][D/4] packed {lnw, lnb, r, o} of ln_out / head, see k_pack_head
+    SiteStatic st;             // ln_out site (1 vector, no token shift)
+    SiteDyn dy;
     const uint8_t *w;          // [V][D] u8
     const unsigned *rs;        // [V] row sums
     float *logits;             // [max_ctx][V]
@@ -1124,7 +1095,7 @@ struct HeadArgs {
     int D;
 };
 
-// ln_out -> head dequant-GEMV -> logits (rwkv.cu:585-589); also per-workgroup argmax partials
+// ln_out site -> head dequant-GEMV -> logits (rwkv.cu:585-589); also per-workgroup argmax partials
 template <int S>
 __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
 {
@@ -1143,61 +1114,34 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
     const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
 
-    double xl[NQ][4];
-    f32x4 P[NQ][4];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
-        load_quad_f64(a.x, qc, xl[i]);
-#pragma unroll
-        for (int e = 0; e < 4; e++) P[i][e] = a.pk[e * nqd + qc];   // lane-contiguous
-    }
     u32x4 w[R][S];
     int g = g0 + wave;
+    unsigned *gctr = group_counter(red);
+    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NW);   // visible behind the prologue's barriers
     auto rowbase = [&](int gg) {
         int row = gg * R;
         if (row > V - R) row = V - R;
         return a.w + (size_t)row * D;
     };
     const uint8_t *wb = rowbase(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0));
-    group_load<R, S, 0, pre_steps<S>()>(w, wb, (size_t)D, chunks, lane);
-    double mean, rstd;
-    ln_stats<NQ>(xl, D, mean, rstd, red);
-    double Ssum[1] = {0.0};
-    float amax[1] = {0.f};
-    float xr[NQ][4];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const bool real = (int)(threadIdx.x + i * NT) < nqd;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const float f = (float)((double)P[i][e][0] * ((xl[i][e] - mean) * rstd) + (double)P[i][e][1]);
-            xr[i][e] = f * P[i][e][2];
-            if (real) { Ssum[0] += (double)(f * P[i][e][3]); amax[0] = fmaxf(amax[0], fabsf(xr[i][e])); }
-        }
-    }
-    block_max<1>(amax, red + RED_MAX);
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int qd = threadIdx.x + i * NT;
-        if (qd < S * 256) stage_quad(xq, qd, xr[i], inv_scale(amax[0]), qd < nqd);
-    }
-    block_sum<1>(Ssum, red + RED_OFFS);
-    group_load<R, S, pre_steps<S>(), S>(w, wb, (size_t)D, chunks, lane);   // bulk issue after the last barrier (see k_att)
-    const float Sf = (float)Ssum[0];
-    const double sc = scale_of(amax[0]);
+    SiteRed<1> sr;
+    site_open<1, R, S, (RWKV_SPLIT & 16) != 0>(a.st, a.dy, a.x, D, red, xq, w, wb, (size_t)D, sr, false, nullptr);
+    const float Sf = (float)sr.S[0];
+    const double sc = scale_of(sr.amax[0]);
     float *lg = a.logits + (size_t)a.ctl->out_row * V;
 
     float best = -INFINITY;
     unsigned besti = 0xffffffffu;
-    for (; g < g1; g += NW) {
+    int gn = next_group(gctr, g);   // the group whose rows refill the registers during the next dot
+    while (g < g1) {
         unsigned long long T[R];
-        const bool nv = g + NW < g1;
+        const bool nv = gn < g1;
+        const int gnn = nv ? next_group(gctr, gn) : g1;
         int row0 = g * R;
         const int shift = (row0 > V - R) ? row0 - (V - R) : 0;
         row0 -= shift;
         const u32x4 rs4 = {a.rs[row0], a.rs[row0 + 1], a.rs[row0 + 2], a.rs[row0 + 3]};   // before the refills (see k_att)
-        group_dot<R, S, PAT_SHARED>(w, xq, lane, T, rowbase(nv ? g + NW : 0), (size_t)D, chunks, nv);
+        group_dot<R, S, PAT_SHARED>(w, xq, lane, T, rowbase(nv ? gn : 0), (size_t)D, chunks, nv);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = row0 + r;
@@ -1205,6 +1149,7 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
             if (lane == r && r >= shift) lg[i] = val;
             if (i != 0 && (val > best || (val == best && (unsigned)i < besti))) { best = val; besti = (unsigned)i; }
         }
+        g = gn; gn = gnn;
     }
     if (lane == 0) { bval[wave] = best; bidx[wave] = besti; }
     __syncthreads();
@@ -1368,38 +1313,33 @@ __global__ void k_prep_wkv(const double *decay, const double *bonus, double *uw,
     if (i < n) { uw[i] = bonus[i] + decay[i]; ew[i] = exp(decay[i]); }
 }
 
-// Load-time packing of the static per-channel parameters into float4 tables.  A prologue thread
-// owns quads of 4 consecutive channels (quad qd = j/4, e = j%4), so the tables are laid out
-// [piece q][e][qd]: for a given (q, e) the 64 lanes of a wave read 64 consecutive float4 = one
-// fully coalesced 1 KiB load.  The f64 tensors involved (layernorm rows, time-mix vectors) hold
-// f32-representable values in converted checkpoints (converter: .double() of f32 tensors,
-// convert_model.py:44-56), so the narrowing is exact there.
-__global__ void k_pack_att(f32x4 *pk, const double *lnw, const double *lnb, const double *mk, const double *mv,
-                           const double *mr, const float *rk, const float *rv, const float *rr,
-                           const float *ok, const float *ov, const float *orr, int D)
+// Load-time tables of vector m of one LayerNorm site (see "LayerNorm sites" above): consumer side
+// C[m][j] = r mix lnw; producer side P[j][PW] holds BL = r mix lnb, BP = r (1 - mix) and the same
+// with the offset o in place of the scale r (Co, BoL, BoP) at [m*5 + 0..4].  mix == nullptr means
+// no token shift (ln_out -> head).  Products are formed in f64 and stored as f32.  TC[m] = sum of the
+// stored Co, maxC[m] = max |C|.  One workgroup per call.
+__global__ __launch_bounds__(NT) void k_site_static(const double *lnw, const double *lnb, const double *mix, const float *r, const float *o,
+                                                    float *C, float *P, double *TC, float *maxC, int m, int PW, int D)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= D) return;
-    const int nqd = D >> 2, qd = j >> 2, e = j & 3;
-    pk[(0 * 4 + e) * nqd + qd] = f32x4{(float)lnw[j], (float)lnb[j], (float)mk[j], (float)mv[j]};
-    pk[(1 * 4 + e) * nqd + qd] = f32x4{(float)mr[j], rk[j], rv[j], rr[j]};
-    pk[(2 * 4 + e) * nqd + qd] = f32x4{ok[j], ov[j], orr[j], 0.f};
-}
-__global__ void k_pack_ffn(f32x4 *pk, const double *lnw, const double *lnb, const double *mk, const double *mr,
-                           const float *rk, const float *ok, const float *rr, const float *orr, int D)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= D) return;
-    const int nqd = D >> 2, qd = j >> 2, e = j & 3;
-    pk[(0 * 4 + e) * nqd + qd] = f32x4{(float)lnw[j], (float)lnb[j], (float)mk[j], (float)mr[j]};
-    pk[(1 * 4 + e) * nqd + qd] = f32x4{rk[j], ok[j], rr[j], orr[j]};
-}
-__global__ void k_pack_head(f32x4 *pk, const double *lnw, const double *lnb, const float *r, const float *o, int D)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= D) return;
-    const int nqd = D >> 2, qd = j >> 2, e = j & 3;
-    pk[e * nqd + qd] = f32x4{(float)lnw[j], (float)lnb[j], r[j], o[j]};
+    __shared__ double red[RED_BYTES / 8];
+    double s[1] = {0.0};
+    float mx[1] = {0.f};
+    for (int j = threadIdx.x; j < D; j += NT) {
+        const double mk = mix ? mix[j] : 1.0, rr = (double)r[j], oo = (double)o[j];
+        const float c = (float)(rr * mk * lnw[j]), co = (float)(oo * mk * lnw[j]);
+        C[(size_t)m * D + j] = c;
+        float *pp = P + (size_t)j * PW + m * 5;
+        pp[0] = (float)(rr * mk * lnb[j]);
+        pp[1] = (float)(rr * (1.0 - mk));
+        pp[2] = co;
+        pp[3] = (float)(oo * mk * lnb[j]);
+        pp[4] = (float)(oo * (1.0 - mk));
+        s[0] += (double)co;
+        mx[0] = fmaxf(mx[0], fabsf(c));
+    }
+    block_sum<1>(s, red + RED_STATS);
+    block_max<1>(mx, red + RED_MAX);
+    if (threadIdx.x == 0) { TC[m] = s[0]; maxC[m] = mx[0]; }
 }
 
 } // namespace rwkvk
