@@ -83,8 +83,20 @@ def test_gpt_mode_chunk_equals_token_by_token(eng_mod, oracle):
         parity.check_logits(got[i], ref[i], f"pos {i}")
     m.reset_state()
     one = np.stack([m.forward(tk)[: mf.VOCAB].copy() for tk in toks])
-    assert np.array_equal(one, got)          # deterministic: chunked == token-by-token, bit for bit
-    om.close(); m.close()
+    for i in range(T):                       # chunk (MFMA path, seq.hip.h) vs token-by-token (GEMV path)
+        parity.check_logits(got[i], one[i], f"chunk vs single pos {i}")
+        parity.check_argmax(got[i], one[i], f"chunk vs single pos {i}")
+    m.close()
+    # with the chunked path switched off a GPT-mode call is the same kernels token by token: bit for bit
+    os.environ["RWKV_SEQ"] = "0"
+    try:
+        m2 = eng_mod.RWKV(resident=True)
+        m2.loadTensors(L, D, t, maxGPT=8)
+    finally:
+        del os.environ["RWKV_SEQ"]
+    got2 = m2.forward(toks, eng_mod.MODE_GPT)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+    assert np.array_equal(one, got2)
+    om.close(); m2.close()
 
 
 def test_parralel_mode_independent_slots(eng_mod, oracle):

@@ -22,3 +22,21 @@ for rep in range(2):
         if v.size:
             print(f"  {names[ph]:14s} min {v.min():7.2f}  mean {v.mean():7.2f}  max {v.max():7.2f}  (n={v.size})")
 m.close()
+# per-workgroup view of the last repetition: is the spread between workgroups systematic?
+m = engine.RWKV(resident=True); m.loadTensors(L, D, t)
+for tk in (5, 6, 7):
+    m.forward(tk)
+ends = []
+for rep in range(4):
+    buf = m.debug_timeline(9).reshape(-1, 8, 8)[:256].astype(np.int64)
+    t0 = buf[:, :, 0][buf[:, :, 0] > 0].min()
+    ends.append(((buf[:, :, 6] - t0) / 100.0).max(axis=1))      # loop+sync per workgroup
+ends = np.array(ends)                                            # [rep][block]
+print("loop-end per XCD (block %% 8), mean over reps:", np.round([ends[:, x::8].mean() for x in range(8)], 2))
+print("loop-end by block range of 32:", np.round([ends[:, i:i + 32].mean() for i in range(0, 256, 32)], 2))
+c = np.corrcoef(ends)
+print("rep-to-rep correlation of per-block end times:", np.round(c[0, 1:], 2))
+order = np.argsort(ends.mean(axis=0))
+print("fastest blocks", order[:10], np.round(ends.mean(axis=0)[order[:10]], 2))
+print("slowest blocks", order[-10:], np.round(ends.mean(axis=0)[order[-10:]], 2))
+m.close()
