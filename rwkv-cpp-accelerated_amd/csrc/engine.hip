@@ -124,9 +124,9 @@ struct rwkv_ctx {
     bool seq_ok = false;
     unsigned long long *sq_tokens = nullptr;      // device [SEQ_T]
     unsigned long long *h_sq_tokens = nullptr;    // pinned
-    double *sq_x[2] = {nullptr, nullptr};         // residual stream [SEQ_T][D], ping-pong
+    double *sq_x[1] = {nullptr};                  // residual stream [SEQ_T][D]
     double *sq_state = nullptr;                   // [D] LayerNorm output of the chunk's last token
-    float *sq_kvr = nullptr, *sq_att = nullptr, *sq_frk = nullptr, *sq_fv = nullptr, *sq_y = nullptr;   // GEMM outputs / wkv output
+    float *sq_kvr = nullptr, *sq_frk = nullptr, *sq_y = nullptr;   // GEMM outputs / wkv output
     unsigned *sq_img[3] = {nullptr, nullptr, nullptr}, *sq_imgh = nullptr;   // MFMA A-operand images (K = D; K = 4D)
     SeqVec *sq_rec = nullptr;                     // [3][SEQ_T]
     std::vector<void *> allocs;
@@ -485,12 +485,10 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         if (max_ctx > 1 && first && last && D % 64 == 0 && !(e && e[0] == '0')) {
             if ((rc = dalloc(c, &c->sq_tokens, (size_t)SEQ_T))) return rc;
             HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_sq_tokens), sizeof(unsigned long long) * SEQ_T, hipHostMallocDefault));
-            for (int k = 0; k < 2; k++) if ((rc = dalloc(c, &c->sq_x[k], (size_t)SEQ_T * D))) return rc;
+            if ((rc = dalloc(c, &c->sq_x[0], (size_t)SEQ_T * D))) return rc;
             if ((rc = dalloc(c, &c->sq_state, (size_t)D))) return rc;
             if ((rc = dalloc(c, &c->sq_kvr, (size_t)SEQ_T * 3 * D))) return rc;
-            if ((rc = dalloc(c, &c->sq_att, (size_t)SEQ_T * D))) return rc;
             if ((rc = dalloc(c, &c->sq_frk, (size_t)SEQ_T * 5 * D))) return rc;
-            if ((rc = dalloc(c, &c->sq_fv, (size_t)SEQ_T * D))) return rc;
             if ((rc = dalloc(c, &c->sq_y, (size_t)SEQ_T * D))) return rc;
             for (int k = 0; k < 3; k++) {
                 if ((rc = dalloc(c, &c->sq_img[k], a_image_bytes(D) / 4))) return rc;
@@ -523,68 +521,61 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0)
     HIPCHK(hipStreamSynchronize(st));   // the pinned token staging buffer is reused per chunk
     for (int t = 0; t < n; t++) c->h_sq_tokens[t] = tokens[t];
     HIPCHK(hipMemcpyAsync(c->sq_tokens, c->h_sq_tokens, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, st));
-    SeqEmbedArgs ea{c->embed, c->ln, c->sq_tokens, c->sq_x[0], D};
+    double *x = c->sq_x[0];
+    SeqEmbedArgs ea{c->embed, c->ln, c->sq_tokens, x, D};
     k_seq_embed<<<dim3(n), dim3(NT), 0, st>>>(ea);
-    int cur = 0;
-    auto gemm = [&](const uint8_t *w, const unsigned *rs, int N, int K, int Q, const int *voq, unsigned *const *img, float *out) {
+    auto gemm = [&](const uint8_t *w, const unsigned *rs, int N, int K, int Q, const int *voq, unsigned *const *img, float *out, int epi) {
         SeqGemmArgs g;
         g.w = w; g.rs = rs; g.N = N; g.K = K; g.Q = Q;
         for (int q = 0; q < 5; q++) g.vec_of_q[q] = q < Q ? voq[q] : 0;
         for (int k = 0; k < 3; k++) g.img[k] = reinterpret_cast<const u32x4 *>(img[k]);
-        g.rec = c->sq_rec; g.out = out; g.T = n;
-        k_mm8_seq<<<dim3(c->grid), dim3(NT), 0, st>>>(g);
+        g.rec = c->sq_rec; g.out = out; g.epi = epi; g.x = x; g.gate = c->sq_frk; g.T = n;
+        k_mm8_seq<<<dim3(c->grid), dim3(SEQ_NT), 0, st>>>(g);
+    };
+    auto site = [&](int nv, const double *lnw, const double *lnb, const double *const *mix, const float *const *r, const float *const *o,
+                    double *state) {
+        SeqSiteArgs s{};
+        s.x = x; s.lnw = lnw; s.lnb = lnb;
+        for (int k = 0; k < nv; k++) { s.mix[k] = mix ? mix[k] : nullptr; s.r[k] = r[k]; s.o[k] = o[k]; }
+        s.state = state; s.state_new = state ? c->sq_state : nullptr;
+        for (int k = 0; k < 3; k++) s.img[k] = c->sq_img[k];
+        s.rec = c->sq_rec; s.D = D; s.T = n;
+        if (nv == 3) k_seq_site<3><<<dim3(n), dim3(NT), 0, st>>>(s);
+        else if (nv == 2) k_seq_site<2><<<dim3(n), dim3(NT), 0, st>>>(s);
+        else k_seq_site<1><<<dim3(n), dim3(NT), 0, st>>>(s);
     };
     static const int v012[5] = {0, 1, 2, 0, 0}, v0[5] = {0, 0, 0, 0, 0}, v00001[5] = {0, 0, 0, 0, 1};
     for (uint64_t l = 0; l < L; l++) {
         const size_t lo = (size_t)l * D;
-        // ln1 site (+ the previous layer's ffn residual)
-        SeqSiteArgs s1{};
-        s1.xin = c->sq_x[cur]; s1.xout = c->sq_x[cur ^ 1]; s1.res_kind = l == 0 ? 0 : 2;
-        s1.add = c->sq_fv; s1.ld_add = D; s1.gate = c->sq_frk; s1.ld_gate = 5 * D;
-        s1.lnw = c->ln + (4 * l + 2) * D; s1.lnb = c->ln + (4 * l + 3) * D;
-        s1.mix[0] = c->mixk + lo; s1.mix[1] = c->mixv + lo; s1.mix[2] = c->mixr + lo;
-        s1.r[0] = c->kr + lo; s1.r[1] = c->vr + lo; s1.r[2] = c->rr + lo;
-        s1.o[0] = c->o1 + lo; s1.o[1] = c->o2 + lo; s1.o[2] = c->o3 + lo;
-        s1.state = c->state[0] + lo; s1.state_new = c->sq_state;
-        for (int k = 0; k < 3; k++) s1.img[k] = c->sq_img[k];
-        s1.rec = c->sq_rec; s1.D = D; s1.T = n;
-        k_seq_site<3><<<dim3(n), dim3(NT), 0, st>>>(s1);
-        cur ^= 1;
-        HIPCHK(hipMemcpyAsync(c->state[0] + lo, c->sq_state, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
-        gemm(c->w_kvr + l * 3 * (size_t)D * D, c->rs_kvr + l * 3 * (size_t)D, 3 * D, D, 3, v012, c->sq_img, c->sq_kvr);
-        SeqWkvArgs wa{c->sq_kvr, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, c->sq_y, D, n};
-        k_seq_wkv<<<dim3((D + 255) / 256), dim3(256), 0, st>>>(wa);
-        SeqStageArgs sa{c->sq_y, c->attr + lo, c->atto + lo, c->sq_img[0], c->sq_rec, D, n};
-        k_seq_stage<0><<<dim3(n), dim3(NT), 0, st>>>(sa);
-        gemm(c->w_att + l * (size_t)D * D, c->rs_att + l * (size_t)D, D, D, 1, v0, c->sq_img, c->sq_att);
-        // ln2 site (+ the attention residual)
-        SeqSiteArgs s2{};
-        s2.xin = c->sq_x[cur]; s2.xout = c->sq_x[cur ^ 1]; s2.res_kind = 1; s2.add = c->sq_att; s2.ld_add = D;
-        s2.lnw = c->ln + (4 * l + 4) * D; s2.lnb = c->ln + (4 * l + 5) * D;
-        s2.mix[0] = c->fmixk + lo; s2.mix[1] = c->fmixr + lo;
-        s2.r[0] = c->fkr + lo; s2.r[1] = c->frr + lo; s2.o[0] = c->fko + lo; s2.o[1] = c->fro + lo;
-        s2.state = c->state[4] + lo; s2.state_new = c->sq_state;
-        for (int k = 0; k < 3; k++) s2.img[k] = c->sq_img[k];
-        s2.rec = c->sq_rec; s2.D = D; s2.T = n;
-        k_seq_site<2><<<dim3(n), dim3(NT), 0, st>>>(s2);
-        cur ^= 1;
-        HIPCHK(hipMemcpyAsync(c->state[4] + lo, c->sq_state, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
-        gemm(c->w_frk + l * 5 * (size_t)D * D, c->rs_frk + l * 5 * (size_t)D, 5 * D, D, 5, v00001, c->sq_img, c->sq_frk);
-        SeqStageArgs sh{c->sq_frk, c->fvr + 4 * lo, c->fvo + 4 * lo, c->sq_imgh, c->sq_rec, 4 * D, n};
-        k_seq_stage<1><<<dim3(n), dim3(NT), 0, st>>>(sh);
-        unsigned *imgh[3] = {c->sq_imgh, c->sq_imgh, c->sq_imgh};
-        gemm(c->w_fv + l * 4 * (size_t)D * D, c->rs_fv + l * (size_t)D, D, 4 * D, 1, v0, imgh, c->sq_fv);
+        {   // time mix
+            const double *mix[3] = {c->mixk + lo, c->mixv + lo, c->mixr + lo};
+            const float *r[3] = {c->kr + lo, c->vr + lo, c->rr + lo}, *o[3] = {c->o1 + lo, c->o2 + lo, c->o3 + lo};
+            site(3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D, mix, r, o, c->state[0] + lo);
+            HIPCHK(hipMemcpyAsync(c->state[0] + lo, c->sq_state, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
+            gemm(c->w_kvr + l * 3 * (size_t)D * D, c->rs_kvr + l * 3 * (size_t)D, 3 * D, D, 3, v012, c->sq_img, c->sq_kvr, 0);
+            SeqWkvArgs wa{c->sq_kvr, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, c->sq_y, D, n};
+            k_seq_wkv<<<dim3((D + WKV_CH - 1) / WKV_CH), dim3(256), 0, st>>>(wa);
+            SeqStageArgs sa{c->sq_y, c->attr + lo, c->atto + lo, c->sq_img[0], c->sq_rec, D, n};
+            k_seq_stage<0><<<dim3(n), dim3(NT), 0, st>>>(sa);
+            gemm(c->w_att + l * (size_t)D * D, c->rs_att + l * (size_t)D, D, D, 1, v0, c->sq_img, nullptr, 1);
+        }
+        {   // channel mix
+            const double *mix[3] = {c->fmixk + lo, c->fmixr + lo, nullptr};
+            const float *r[3] = {c->fkr + lo, c->frr + lo, nullptr}, *o[3] = {c->fko + lo, c->fro + lo, nullptr};
+            site(2, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D, mix, r, o, c->state[4] + lo);
+            HIPCHK(hipMemcpyAsync(c->state[4] + lo, c->sq_state, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
+            gemm(c->w_frk + l * 5 * (size_t)D * D, c->rs_frk + l * 5 * (size_t)D, 5 * D, D, 5, v00001, c->sq_img, c->sq_frk, 0);
+            SeqStageArgs sh{c->sq_frk, c->fvr + 4 * lo, c->fvo + 4 * lo, c->sq_imgh, c->sq_rec, 4 * D, n};
+            k_seq_stage<1><<<dim3(n), dim3(NT), 0, st>>>(sh);
+            unsigned *imgh[3] = {c->sq_imgh, c->sq_imgh, c->sq_imgh};
+            gemm(c->w_fv + l * 4 * (size_t)D * D, c->rs_fv + l * (size_t)D, D, 4 * D, 1, v0, imgh, nullptr, 2);
+        }
     }
-    // ln_out site (+ the last ffn residual) and the head
-    SeqSiteArgs so{};
-    so.xin = c->sq_x[cur]; so.xout = c->sq_x[cur ^ 1]; so.res_kind = 2;
-    so.add = c->sq_fv; so.ld_add = D; so.gate = c->sq_frk; so.ld_gate = 5 * D;
-    so.lnw = c->ln + (4 * L + 2) * D; so.lnb = c->ln + (4 * L + 3) * D;
-    so.r[0] = c->headr; so.o[0] = c->heado;
-    for (int k = 0; k < 3; k++) so.img[k] = c->sq_img[k];
-    so.rec = c->sq_rec; so.D = D; so.T = n;
-    k_seq_site<1><<<dim3(n), dim3(NT), 0, st>>>(so);
-    gemm(c->w_head, c->rs_head, (int)V, D, 1, v0, c->sq_img, c->logits + row0 * V);
+    {   // ln_out and the head
+        const float *r[3] = {c->headr, nullptr, nullptr}, *o[3] = {c->heado, nullptr, nullptr};
+        site(1, c->ln + (4 * L + 2) * D, c->ln + (4 * L + 3) * D, nullptr, r, o, nullptr);
+        gemm(c->w_head, c->rs_head, (int)V, D, 1, v0, c->sq_img, c->logits + row0 * V, 0);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -12,10 +12,10 @@
 //     sum_k u_k l_k = MFMA(u - 128, l - 128) + 128 * rowsum(u) + 128 * sum_k (l_k - 128).
 //
 //   k_seq_embed   rwkv.cu:513-524   embedding rows + ln0 for the chunk
-//   k_seq_site    :412-465,:313-392 residual of the previous GEMM + LayerNorm + token-shift mix (the
-//                                   shift runs along the chunk; token 0 takes the recurrent state) +
-//                                   quantisation into the MFMA A-operand image
-//   k_mm8_seq     :58-142,:267-311  [T x K] x [K x N] uint8 GEMM on MFMA, one launch per matrix group
+//   k_seq_site    :412-465,:313-392 LayerNorm + token-shift mix (the shift runs along the chunk; token 0
+//                                   takes the recurrent state) + quantisation into the MFMA A-operand image
+//   k_mm8_seq     :58-142,:267-311  [T x K] x [K x N] uint8 GEMM on MFMA, one launch per matrix group;
+//                 :548-553,:574-577 the residual updates are its epilogues
 //   k_seq_wkv     :221-259          WKV recurrence, sequential over the chunk per channel
 //   k_seq_stage   :144-219          relu^2 / cast + scale + quantisation for att_out and ffn_v inputs
 #pragma once
@@ -112,13 +112,7 @@ __global__ __launch_bounds__(NT) void k_seq_embed(SeqEmbedArgs a)
 
 // ------------------------------------------------------------------------------------------
 struct SeqSiteArgs {
-    const double *xin;           // [T][D] residual stream before the pending residual update
-    double *xout;                // [T][D] after it (a different buffer: neighbours read xin[t-1])
-    int res_kind;                // 0 none; 1 x = f32(x) + add (att_out, rwkv.cu:548-553); 2 x += add * sigmoid(gate) (:574-577,:407)
-    const float *add;            // GEMM output [T][ld_add], element [t][j]
-    int ld_add;
-    const float *gate;           // kind 2: ffn_r GEMM output, element [t][5 j + 4]
-    int ld_gate;
+    const double *x;             // [T][D] residual stream (the GEMM epilogues keep it up to date)
     const double *lnw, *lnb;     // this site's LayerNorm rows
     const double *mix[3];        // token-shift mix per vector (nullptr: no shift, ln_out -> head)
     const float *r[3], *o[3];    // scale / offset of the matrices the vectors feed
@@ -138,15 +132,6 @@ __global__ __launch_bounds__(NT) void k_seq_site(SeqSiteArgs a)
     __shared__ unsigned lds_sums[12];
     const int D = a.D, t = blockIdx.x, nqd = D >> 2;
     const bool shift = a.mix[0] != nullptr;
-    auto load_x = [&](int tt, int j) -> double {
-        const double x0 = a.xin[(size_t)tt * D + j];
-        if (a.res_kind == 1) return (double)((float)x0 + a.add[(size_t)tt * a.ld_add + j]);
-        if (a.res_kind == 2) {
-            const float g = (float)(1.0 / (1.0 + exp(-(double)a.gate[(size_t)tt * a.ld_gate + 5 * j + 4])));   // rwkv.cu:212
-            return x0 + (double)(a.add[(size_t)tt * a.ld_add + j] * g);                                         // :407
-        }
-        return x0;
-    };
     double xt[SEQ_NQ][4], xp[SEQ_NQ][4];
     double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -157,11 +142,10 @@ __global__ __launch_bounds__(NT) void k_seq_site(SeqSiteArgs a)
             xt[i][e] = 0.0; xp[i][e] = 0.0;
             if (qd < nqd) {
                 const int j = qd * 4 + e;
-                xt[i][e] = load_x(t, j);
-                a.xout[(size_t)t * D + j] = xt[i][e];
+                xt[i][e] = a.x[(size_t)t * D + j];
                 s[0] += xt[i][e]; s[1] += xt[i][e] * xt[i][e];
                 if (shift) {
-                    if (t > 0) { xp[i][e] = load_x(t - 1, j); s[2] += xp[i][e]; s[3] += xp[i][e] * xp[i][e]; }
+                    if (t > 0) { xp[i][e] = a.x[(size_t)(t - 1) * D + j]; s[2] += xp[i][e]; s[3] += xp[i][e] * xp[i][e]; }
                     else xp[i][e] = a.state[j];
                 }
             }
@@ -275,26 +259,36 @@ struct SeqWkvArgs {
     float *y;                    // [T][D] gated wkv, cast to f32 as the att_out GEMV does (rwkv.cu:290)
     int D, T;
 };
-// one thread per channel, sequential over the chunk (rwkv.cu:242-255 with the GPT-mode state slot 0)
-__global__ void k_seq_wkv(SeqWkvArgs a)
+constexpr int WKV_CH = 8;        // channels per workgroup (256 threads = 8 channels x 32 tokens)
+// rwkv.cu:242-255 with the GPT-mode state slot 0.  The exponentials do not depend on the state, so
+// one thread per (token, channel) evaluates them; then one thread per channel runs the recurrence
+// along the chunk (a division and a few fma per step).
+__global__ __launch_bounds__(256) void k_seq_wkv(SeqWkvArgs a)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.D) return;
-    double aa = a.saa[i], bb = a.sbb[i];
-    const double uw = a.uw[i], ew = a.ew[i];
-    for (int t = 0; t < a.T; t++) {
+    __shared__ double e1s[SEQ_T][WKV_CH], eks[SEQ_T][WKV_CH], vs[SEQ_T][WKV_CH], sgs[SEQ_T][WKV_CH];
+    const int ch = threadIdx.x & (WKV_CH - 1), t = threadIdx.x / WKV_CH;
+    const int i = blockIdx.x * WKV_CH + ch;
+    if (i < a.D && t < a.T) {
         const float *p = a.kvr + (size_t)t * 3 * a.D + 3 * i;
         const float k = p[0], v = p[1], r = p[2];
-        const double vv = (double)v;
-        const double e1 = exp(uw + (double)k);
-        double y = (aa + e1 * vv) / (bb + e1);
-        y = (1.0 / (1.0 + (double)expf(-r))) * y;
-        const double ek = exp((double)k);
-        aa = (aa + ek * vv) * ew;
-        bb = (bb + ek) * ew;
-        a.y[(size_t)t * a.D + i] = (float)y;
+        e1s[t][ch] = exp(a.uw[i] + (double)k);
+        eks[t][ch] = exp((double)k);
+        vs[t][ch] = (double)v;
+        sgs[t][ch] = 1.0 / (1.0 + (double)expf(-r));       // rwkv.cu:250: exp of a float argument
     }
-    a.saa[i] = aa; a.sbb[i] = bb;
+    __syncthreads();
+    if (threadIdx.x < WKV_CH && i < a.D) {
+        double aa = a.saa[i], bb = a.sbb[i];
+        const double ew = a.ew[i];
+        for (int tt = 0; tt < a.T; tt++) {
+            const double e1 = e1s[tt][ch], ek = eks[tt][ch], vv = vs[tt][ch];
+            const double y = sgs[tt][ch] * ((aa + e1 * vv) / (bb + e1));
+            aa = (aa + ek * vv) * ew;
+            bb = (bb + ek) * ew;
+            a.y[(size_t)tt * a.D + i] = (float)y;
+        }
+        a.saa[i] = aa; a.sbb[i] = bb;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -306,17 +300,117 @@ struct SeqGemmArgs {
     int vec_of_q[5];             // activation vector each class multiplies
     const u32x4 *img[3];         // A-operand images of the vectors
     const SeqVec *rec;           // [NV][SEQ_T]
-    float *out;                  // [T][N]
+    float *out;                  // epi 0: [T][N] f32
+    int epi;                     // 0 store; 1 x = f32(x) + v (att_out residual, rwkv.cu:548-553); 2 x += v * sigmoid(gate) (:574-577,:407,:212)
+    double *x;                   // epi 1, 2: residual stream [T][N], updated in place (one owner per element)
+    const float *gate;           // epi 2: ffn k/r GEMM output [T][5N], the r value of channel j at [t][5 j + 4]
     int T;
 };
 constexpr int SEQ_TB = 5;        // weight tiles (16 rows each) per workgroup pass
+#ifndef RWKV_SEQ_NT
+#define RWKV_SEQ_NT 256
+#endif
+#ifndef RWKV_SEQ_NTLOAD
+#define RWKV_SEQ_NTLOAD 0
+#endif
+#ifndef RWKV_SEQ_DEPTH
+#define RWKV_SEQ_DEPTH 4
+#endif
+constexpr int SEQ_NT = RWKV_SEQ_NT;   // GEMM workgroup: 4 waves, one per SIMD, so each may use the full 512-register budget
+constexpr int SEQ_NW = SEQ_NT / 64;
 
-// One workgroup owns a contiguous range of (class-major) 16-row tiles; the 8 waves split K; the
-// integer partial sums meet in LDS (exact: order does not matter), then the workgroup applies scale,
-// offsets and corrections and writes f32.  Weight bytes are read once, with 16 B per lane
-// non-temporal loads: lane (g, c) reads bytes [64 kb + 16 g, +16) of row c of the tile, which is the
-// register image of the B operand.
-__global__ __launch_bounds__(NT) void k_mm8_seq(SeqGemmArgs a)
+// operands of one k-block: B fragments of NTL tiles and the A fragments of the pass's vector
+template <int NTL> struct SeqFrag { u32x4 bw[NTL]; u32x4 af[2][3]; };
+template <int NTL>
+__device__ __forceinline__ void seq_frag_load(SeqFrag<NTL> &f, const uint8_t *const (&wrow)[SEQ_TB], const u32x4 *img, int kb, int lane)
+{
+#pragma unroll
+#ifdef RWKV_SEQ_EXP_NOB      // timing experiment only (wrong results)
+    for (int i = 0; i < NTL; i++) f.bw[i] = u32x4{(unsigned)kb, (unsigned)lane, (unsigned)i, 4u};
+#elif RWKV_SEQ_NTLOAD
+    for (int i = 0; i < NTL; i++) f.bw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow[i] + (size_t)kb * 64));
+#else
+    for (int i = 0; i < NTL; i++) f.bw[i] = *reinterpret_cast<const u32x4 *>(wrow[i] + (size_t)kb * 64);
+#endif
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+#ifdef RWKV_SEQ_EXP_NOA      // timing experiment only (wrong results)
+            f.af[mt][b] = u32x4{(unsigned)kb, (unsigned)lane, 3u, 4u};
+#else
+            f.af[mt][b] = img[a_unit(kb, mt, b, lane)];
+#endif
+        }
+}
+template <int NTL>
+__device__ __forceinline__ void seq_frag_mfma(const SeqFrag<NTL> &f, i32x4 (&acc)[SEQ_TB][2][3], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < NTL; i++) {
+        // the weights were fetched with lane 4 c + g <- bytes [16 g, +16) of row c (adjacent lanes read adjacent
+        // bytes: 64 B per row coalesce); the B operand wants them in lane 16 g + c: one crossbar transposition
+        const int src = (4 * (lane & 15) + (lane >> 4)) << 2;
+        i32x4 bf;
+#pragma unroll
+        for (int d = 0; d < 4; d++) bf[d] = __builtin_amdgcn_ds_bpermute(src, (int)(f.bw[i][d] ^ 0x80808080u));   // uint8 weight -> signed operand
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const i32x4 af = i32x4{(int)f.af[mt][b][0], (int)f.af[mt][b][1], (int)f.af[mt][b][2], (int)f.af[mt][b][3]};
+                acc[i][mt][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[i][mt][b], 0, 0, 0);
+            }
+    }
+}
+// K loop of one pass over NTL tiles.  The waves take k-blocks round-robin (wave w: kb = w, w + 4, ...):
+// at any moment the workgroup reads 4 adjacent 64-byte pieces of each weight row, and with the two
+// k-blocks requested ahead 768 contiguous bytes per row are in flight -- HBM page locality; a wave
+// owning a contiguous K slice instead reads 64-byte pieces 1 KiB apart and ran at a quarter of the rate.
+template <int NTL>
+__device__ __forceinline__ void seq_pass(i32x4 (&acc)[SEQ_TB][2][3], const uint8_t *const (&wrow)[SEQ_TB], const u32x4 *img, int KB, int wave, int lane)
+{
+    const int n = (KB - wave + SEQ_NW - 1) / SEQ_NW;      // k-blocks of this wave
+    if (n <= 0) return;
+    // Weight rows are a power of two apart, so the 16 rows of a tile -- and the same k-block of every
+    // workgroup's tiles -- sit on the same L2 / HBM channel.  Each workgroup therefore walks K from its
+    // own starting k-block (the sums are exact integers: order is free): the 32 workgroups of an XCD
+    // start on 32 different 64-byte offsets of a 2 KiB window.  Measured: 2.4 -> see DESIGN.md.
+    const int rot = (KB % SEQ_NW == 0) ? (int)((blockIdx.x / 8) % 32) % KB : 0;
+    auto kbi = [&](int it) {                       // past the end: re-read the last (branch-free loop)
+        int kb = wave + SEQ_NW * (it < n - 1 ? it : n - 1) + rot;
+        return kb >= KB ? kb - KB : kb;
+    };
+    // ring of DEPTH operand sets: DEPTH - 1 k-blocks are requested ahead of the one being multiplied
+    constexpr int DEPTH = RWKV_SEQ_DEPTH;
+    SeqFrag<NTL> f[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; j++) seq_frag_load<NTL>(f[j], wrow, img, kbi(j), lane);
+    int it = 0;
+    for (; it + DEPTH <= n; it += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            seq_frag_load<NTL>(f[(j + DEPTH - 1) % DEPTH], wrow, img, kbi(it + j + DEPTH - 1), lane);
+            seq_frag_mfma<NTL>(f[j], acc, lane);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; j++)
+        if (it + j < n) seq_frag_mfma<NTL>(f[j], acc, lane);
+}
+
+// One workgroup owns a contiguous range of (class-major) 16-row tiles and works through it in passes
+// of up to SEQ_TB tiles that share an activation vector; its 4 waves split K; operands of the next
+// two k-blocks are requested before the MFMAs of the current one issue (120 accumulator registers +
+// three operand sets need more than 256 registers, hence one wave per SIMD); the integer partial
+// sums meet in LDS (exact: order does not matter), then the workgroup applies scale, offsets and
+// corrections.  Weight bytes are read once, 16 B per lane: lane 4 c + g reads bytes [64 kb + 16 g, +16)
+// of row c of the tile (coalesced), and a ds_bpermute per dword moves them into the B operand's lane 16 g + c.
+#if RWKV_SEQ_NT == 256
+__global__ __launch_bounds__(SEQ_NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mm8_seq(SeqGemmArgs a)
+#else
+__global__ __launch_bounds__(SEQ_NT) void k_mm8_seq(SeqGemmArgs a)
+#endif
 {
     __shared__ double accl[SEQ_TB][2][4][64];   // [tile][token tile][reg][lane], 20 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -325,17 +419,18 @@ __global__ __launch_bounds__(NT) void k_mm8_seq(SeqGemmArgs a)
     const int CB = (nch + 15) >> 4;                     // 16-channel blocks per class
     const int ntiles = Q * CB;
     const int tb0 = (int)(((long long)blockIdx.x * ntiles) / gridDim.x), tb1 = (int)(((long long)(blockIdx.x + 1) * ntiles) / gridDim.x);
-    const int kb0 = (wave * KB) / NW, kb1 = ((wave + 1) * KB) / NW;
-    const int g = lane >> 4, c = lane & 15;
+    const int g = lane & 3, c = lane >> 2;   // load mapping: 4 adjacent lanes cover 64 contiguous bytes of a row
 
-    for (int tg = tb0; tg < tb1; tg += SEQ_TB) {
-        const int nt = tb1 - tg < SEQ_TB ? tb1 - tg : SEQ_TB;
-        for (int e = threadIdx.x; e < SEQ_TB * 2 * 4 * 64; e += NT) (&accl[0][0][0][0])[e] = 0.0;
+    int tg = tb0;
+    while (tg < tb1) {
+        // tiles of this pass: same activation vector
+        const int v0 = a.vec_of_q[tg / CB];
+        int nt = 1;
+        while (nt < SEQ_TB && tg + nt < tb1 && a.vec_of_q[(tg + nt) / CB] == v0) nt++;
+        for (int e = threadIdx.x; e < SEQ_TB * 2 * 4 * 64; e += SEQ_NT) (&accl[0][0][0][0])[e] = 0.0;
         __syncthreads();
 
-        // per tile: weight row of this lane's column, and the activation vector
         const uint8_t *wrow[SEQ_TB];
-        int vec[SEQ_TB];
 #pragma unroll
         for (int i = 0; i < SEQ_TB; i++) {
             const int id = tg + (i < nt ? i : 0);
@@ -343,8 +438,8 @@ __global__ __launch_bounds__(NT) void k_mm8_seq(SeqGemmArgs a)
             int row = Q * (16 * cb + c) + q;
             row = row < N ? row : N - 1;
             wrow[i] = a.w + (size_t)row * K + 16 * g;
-            vec[i] = a.vec_of_q[q];
         }
+        const u32x4 *img = a.img[v0];
         i32x4 acc[SEQ_TB][2][3];
 #pragma unroll
         for (int i = 0; i < SEQ_TB; i++)
@@ -352,35 +447,12 @@ __global__ __launch_bounds__(NT) void k_mm8_seq(SeqGemmArgs a)
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                 for (int b = 0; b < 3; b++) acc[i][mt][b] = i32x4{0, 0, 0, 0};
-
-        for (int kb = kb0; kb < kb1; kb++) {
-            u32x4 bw[SEQ_TB];
-#pragma unroll
-            for (int i = 0; i < SEQ_TB; i++) bw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow[i] + (size_t)kb * 64));
-            i32x4 af[2][3];
-            int cur = -1;
-#pragma unroll
-            for (int i = 0; i < SEQ_TB; i++) {
-                if (i < nt) {
-                    if (vec[i] != cur) {   // wave-uniform: tiles of one class are contiguous
-                        cur = vec[i];
-#pragma unroll
-                        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                            for (int b = 0; b < 3; b++) {
-                                const u32x4 t4 = a.img[cur][a_unit(kb, mt, b, lane)];
-                                af[mt][b] = i32x4{(int)t4[0], (int)t4[1], (int)t4[2], (int)t4[3]};
-                            }
-                    }
-                    const u32x4 x4 = bw[i] ^ 0x80808080u;
-                    const i32x4 bf = i32x4{(int)x4[0], (int)x4[1], (int)x4[2], (int)x4[3]};
-#pragma unroll
-                    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                        for (int b = 0; b < 3; b++)
-                            acc[i][mt][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[mt][b], bf, acc[i][mt][b], 0, 0, 0);
-                }
-            }
+        switch (nt) {
+        case 1: seq_pass<1>(acc, wrow, img, KB, wave, lane); break;
+        case 2: seq_pass<2>(acc, wrow, img, KB, wave, lane); break;
+        case 3: seq_pass<3>(acc, wrow, img, KB, wave, lane); break;
+        case 4: seq_pass<4>(acc, wrow, img, KB, wave, lane); break;
+        default: seq_pass<5>(acc, wrow, img, KB, wave, lane); break;
         }
         // fold limbs (exact in f64) and meet the other waves' K slices in LDS
 #pragma unroll
@@ -395,18 +467,26 @@ __global__ __launch_bounds__(NT) void k_mm8_seq(SeqGemmArgs a)
                     }
         __syncthreads();
         // epilogue: D[m][n] with n = lane & 15 (weight row of the tile), m = 4 * (lane >> 4) + reg (token in the tile)
-        for (int e = threadIdx.x; e < nt * 2 * 4 * 64; e += NT) {
+        for (int e = threadIdx.x; e < nt * 2 * 4 * 64; e += SEQ_NT) {
             const int ln = e & 63, r = (e >> 6) & 3, mt = (e >> 8) & 1, i = e >> 9;
             const int t = mt * 16 + 4 * (ln >> 4) + r;
             const int id = tg + i, q = id / CB, cb = id % CB;
             const int row = Q * (16 * cb + (ln & 15)) + q;
             if (t < a.T && row < N) {
-                const SeqVec rc = a.rec[a.vec_of_q[q] * SEQ_T + t];
+                const SeqVec rc = a.rec[v0 * SEQ_T + t];
                 const double M = accl[i][mt][r][ln];
-                a.out[(size_t)t * N + row] = (float)(rc.scale * (M + rc.cA + SEQ_CU * (double)a.rs[row])) + rc.So;
+                const float v = (float)(rc.scale * (M + rc.cA + SEQ_CU * (double)a.rs[row])) + rc.So;
+                const size_t o = (size_t)t * N + row;
+                if (a.epi == 0) a.out[o] = v;
+                else if (a.epi == 1) a.x[o] = (double)((float)a.x[o] + v);
+                else {
+                    const float gt = (float)(1.0 / (1.0 + exp(-(double)a.gate[(size_t)t * 5 * N + 5 * row + 4])));
+                    a.x[o] = a.x[o] + (double)(v * gt);
+                }
             }
         }
         __syncthreads();
+        tg += nt;
     }
 }
 
