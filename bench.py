@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
     ap.add_argument("--profile-reps", type=int, default=16)
+    ap.add_argument("--prefill-chunks", type=int, default=4, help="32-token prompt chunks timed for the prefill report (0 = skip)")
     ap.add_argument("--parallel", choices=["pipeline", "replicas"], default=os.environ.get("RWKV_BENCH_PARALLEL", "pipeline"),
                     help="N > 1: layer pipeline over RCCL send/recv with N streams in flight (default), or N independent replicas")
     args = ap.parse_args()
@@ -75,7 +76,7 @@ def main():
     torch.cuda.synchronize()
     m = engine.RWKV(device=local_rank, resident=True)
     t0 = time.time()
-    m.loadTensors(L, D, tensors, maxGPT=1)
+    m.loadTensors(L, D, tensors, maxGPT=32 if args.prefill_chunks > 0 else 1)
     load_s = time.time() - t0
 
     rng = np.random.default_rng(1)
@@ -136,7 +137,7 @@ def main():
         d["us"] = p["us"]
         d["gbps"] = (d["bytes"] / (p["us"] * 1e-6) / 1e9) if p["us"] > 0 else 0.0
     # dominant kernel = the class with the most device time per token
-    dom = max((k for k in per_launch if per_launch[k]["bytes"] > 0 and k != "embed_ln0"),
+    dom = max((k for k in per_launch if per_launch[k]["bytes"] > 0 and k != "first"),
               key=lambda k: per_launch[k]["us"] * per_launch[k]["launches_per_token"])
     roof = dict(bound="hbm", kernel=dom, achieved=round(per_launch[dom]["gbps"], 1), peak=HBM_PEAK_GBPS,
                 unit="GB/s", frac=round(per_launch[dom]["gbps"] / HBM_PEAK_GBPS, 4),
@@ -156,7 +157,7 @@ def main():
         metric="tokens/sec single-stream RWKV-4 uint8 greedy decode",
         value=round(tok_s, 2), unit="tokens/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
         ms_per_step=round(1e3 * dt / args.steps, 5), higher_is_better=True, scaling="weak",
-        vs_baseline=None, dtype="u8 weights x 24-bit fixed-point activations, exact u32 accumulate (v_dot4_u32_u8); f32/f64 epilogues, f64 state", data="synthetic",
+        vs_baseline=None, dtype="u8 weights x 23-bit fixed-point activations, exact u32 accumulate (v_dot4_u32_u8); f32/f64 epilogues, f64 state", data="synthetic",
         config=dict(workload=f"RWKV-4-Raven-{args.model} uint8 single-stream greedy decode "
                              f"(L={L}, D={D}, V={mf.VOCAB}), 32-token prompt then {args.steps}-token continuation, "
                              "device-resident state",
@@ -172,6 +173,20 @@ def main():
 
     if drop_in is not None:
         line["drop_in_mode"] = drop_in
+
+    # ---- BASELINE config 5 beside it: 32-token prompt chunks through mm8_seq (int8 MFMA), weights read once per chunk ----
+    if rank == 0 and args.prefill_chunks > 0:
+        m.forward(prompt, engine.MODE_GPT)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.prefill_chunks):
+            m.forward(prompt, engine.MODE_GPT)
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - t0) / args.prefill_chunks
+        wbytes = 13 * L * D * D + mf.VOCAB * D
+        line["prefill"] = dict(tokens_per_chunk=len(prompt), ms_per_chunk=round(dtc * 1e3, 3), tokens_per_s=round(len(prompt) / dtc, 1),
+                               weight_GBps=round(wbytes / dtc / 1e9, 1), int8_mfma_TOPS=round(2 * 3 * wbytes * len(prompt) / dtc / 1e12, 1),
+                               note="GPT-mode chunk (RWKV::loadContext path): v_mfma_i32_16x16x64_i8 over three activation limbs; includes logits for all 32 positions")
 
     # ---- CPU baseline: the oracle (CPU restatement of rwkv.cu:493-593) on this box's host cores ----
     if rank == 0 and not args.no_cpu_baseline:
@@ -217,7 +232,7 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
             metric="tokens/sec single-stream RWKV-4 uint8 greedy decode", value=round(tok_s, 2), unit="tokens/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 5),
             higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype="u8 weights x 24-bit fixed-point activations, exact u32 accumulate (v_dot4_u32_u8); f32/f64 epilogues, f64 state",
+            dtype="u8 weights x 23-bit fixed-point activations, exact u32 accumulate (v_dot4_u32_u8); f32/f64 epilogues, f64 state",
             data="synthetic",
             config=dict(workload=f"RWKV-4-Raven-{args.model} uint8 greedy decode (L={L}, D={D}), layers pipelined over {world} GPUs, "
                                  f"{world} independent streams in flight (one per stage), {args.steps} tokens per stream",

@@ -372,15 +372,7 @@ __device__ __forceinline__ void seq_pass(i32x4 (&acc)[SEQ_TB][2][3], const uint8
 {
     const int n = (KB - wave + SEQ_NW - 1) / SEQ_NW;      // k-blocks of this wave
     if (n <= 0) return;
-    // Weight rows are a power of two apart, so the 16 rows of a tile -- and the same k-block of every
-    // workgroup's tiles -- sit on the same L2 / HBM channel.  Each workgroup therefore walks K from its
-    // own starting k-block (the sums are exact integers: order is free): the 32 workgroups of an XCD
-    // start on 32 different 64-byte offsets of a 2 KiB window.  Measured: 2.4 -> see DESIGN.md.
-    const int rot = (KB % SEQ_NW == 0) ? (int)((blockIdx.x / 8) % 32) % KB : 0;
-    auto kbi = [&](int it) {                       // past the end: re-read the last (branch-free loop)
-        int kb = wave + SEQ_NW * (it < n - 1 ? it : n - 1) + rot;
-        return kb >= KB ? kb - KB : kb;
-    };
+    auto kbi = [&](int it) { return wave + SEQ_NW * (it < n - 1 ? it : n - 1); };   // past the end: re-read the last (branch-free loop)
     // ring of DEPTH operand sets: DEPTH - 1 k-blocks are requested ahead of the one being multiplied
     constexpr int DEPTH = RWKV_SEQ_DEPTH;
     SeqFrag<NTL> f[DEPTH];

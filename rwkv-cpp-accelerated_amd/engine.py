@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("RWKV_LIB") or os.path.join(_HERE, "csrc", "librwkv_mi
 
 MODE_PARRALEL, MODE_GPT = 0, 1   # reference enums/enum.h:2-5
 N_KCLASS = 7
-KCLASS_NAMES = ["embed_ln0", "att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head", "argmax"]
+KCLASS_NAMES = ["first", "att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head", "argmax"]
 
 # every entry point declared in include/rwkv_mi355x.h (tests check the library exports all of them)
 ABI_SYMBOLS = [

@@ -1,26 +1,47 @@
 #!/bin/bash
-# one GPU-box session: full GPU tests, golden fixtures from the reference kernel, bench, rocprof summaries
+# One GPU-box session that produces everything profiles/rNN/ holds: GPU tests, the full bench line
+# (CPU baseline leg included), rocprofv3 kernel-trace stats of the bench command, a separate PMC pass
+# (FETCH_SIZE only, no trace domains), and the prefill report.  usage: tools/gpu_round.sh [r01]
 cd "$(dirname "$0")/.."
-mkdir -p gpurun_out/golden gpurun_out/prof
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^loading\|^n_layers\|^n_embed" | tail -4 > gpurun_out/pytest_gpu.log; cat gpurun_out/pytest_gpu.log
-timeout 300 python tools/make_golden.py gpurun_out/golden 2>&1 | grep -v "^loading\|^n_layers\|^n_embed" | tail -6
-timeout 600 python bench.py > gpurun_out/bench_full.log 2>gpurun_out/bench_full.err; tail -c 3000 gpurun_out/bench_full.log
-R=$PWD
+R=$PWD; TAG=${1:-r01}; O=$R/gpurun_out/$TAG
+mkdir -p $O
+if [ -z "$SKIP_TESTS" ]; then
+  timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^loading\|^n_layers\|^n_embed" | tail -4 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
+fi
+timeout 600 python bench.py 2>$O/bench7b_full.err | tail -1 > $O/bench7b_full.json; cut -c1-400 $O/bench7b_full.json
+timeout 300 python tools/prefill_bench.py 2>/dev/null | tail -1 > $O/prefill7b.json; cat $O/prefill7b.json
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/kt -- python $R/bench.py --steps 128 --warmup 8 --no-cpu-baseline > $R/gpurun_out/prof/bench_under_rocprof.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_fetch -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --profile-reps 4 > $R/gpurun_out/prof/bench_under_pmc.log 2>&1
+rm -rf $O/kt $O/pmc
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 128 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench7b_under_rocprof.json
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --profile-reps 4 --prefill-chunks 0 > /dev/null 2>&1
 cd $R
-find gpurun_out/prof -name "*.csv" | head -20
-python - <<'PY'
-import csv, glob, collections
-for f in glob.glob("gpurun_out/prof/kt/**/*kernel_stats.csv", recursive=True):
-    print(f); [print(r[:8]) for r in list(csv.reader(open(f)))[:12]]
-for f in glob.glob("gpurun_out/prof/pmc_fetch/**/*counter_collection.csv", recursive=True):
-    rows = list(csv.DictReader(open(f)))
-    print(f, len(rows), list(rows[0].keys()) if rows else None)
-    agg = collections.defaultdict(list)
-    for r in rows:
-        agg[r.get("Kernel_Name", "?")[:40]].append(float(r.get("Counter_Value", 0)))
-    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:8]:
-        print(f"  {k:40s} n={len(v)} mean={sum(v)/len(v):.1f}")
+python - "$O" <<'PY'
+import csv, glob, json, sys, collections, shutil, os
+O = sys.argv[1]
+for f in glob.glob(O + "/kt/**/*kernel_stats.csv", recursive=True): shutil.copy(f, O + "/bench7b_kernel_stats.csv")
+for f in glob.glob(O + "/kt/**/*domain_stats.csv", recursive=True): shutil.copy(f, O + "/bench7b_domain_stats.csv")
+rows = list(csv.reader(open(O + "/bench7b_kernel_stats.csv")))
+for r in rows[:10]: print([c[:60] for c in r[:6]])
+alg = dict(att_kvr_wkv=3, att_out=1, ffn_rk=5, ffn_v=4)
+names = {"k_att<": "att_kvr_wkv", "k_attout<": "att_out", "k_ffn_rk<": "ffn_rk", "k_ffnv<": "ffn_v", "k_head<": "head"}
+agg = collections.defaultdict(list)
+for f in glob.glob(O + "/pmc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != "FETCH_SIZE": continue
+        for k, v in names.items():
+            if k in r["Kernel_Name"]: agg[v].append(float(r["Counter_Value"]))
+D, V = 4096, 50277
+traffic = {}
+with open(O + "/bench7b_pmc_fetch_size_summary.csv", "w") as fo:
+    fo.write("kernel,dispatches,mean_FETCH_SIZE_KB,hbm_read_bytes_per_launch_corrected_x2,algorithmic_weight_bytes,ratio\n")
+    for k, v in agg.items():
+        mean = sum(v) / len(v); b = int(mean * 1024 * 2)
+        a = V * D if k == "head" else alg[k] * D * D
+        traffic[k] = b
+        fo.write(f"{k},{len(v)},{mean:.1f},{b},{a},{b / a:.4f}\n")
+print(open(O + "/bench7b_pmc_fetch_size_summary.csv").read())
+json.dump({"7B": traffic, "_note": "HBM read bytes per launch = mean FETCH_SIZE [KB] x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section); "
+           "own rocprofv3 --pmc FETCH_SIZE pass of `bench.py --steps 8 --warmup 2` (tools/gpu_round.sh)"}, open(O + "/hbm_traffic.json", "w"), indent=1)
 PY
+rm -rf $O/kt $O/pmc
+ls $O
