@@ -187,6 +187,17 @@ def main():
         line["prefill"] = dict(tokens_per_chunk=len(prompt), ms_per_chunk=round(dtc * 1e3, 3), tokens_per_s=round(len(prompt) / dtc, 1),
                                weight_GBps=round(wbytes / dtc / 1e9, 1), int8_mfma_TOPS=round(2 * 3 * wbytes * len(prompt) / dtc / 1e12, 1),
                                note="GPT-mode chunk (RWKV::loadContext path): v_mfma_i32_16x16x64_i8 over three activation limbs; includes logits for all 32 positions")
+        # the same kernels as a batched decode step: 32 independent streams (MODE PARRALEL, state slot per stream)
+        m.reset_state()
+        m.forward(prompt, engine.MODE_PARRALEL)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.prefill_chunks):
+            m.forward(prompt, engine.MODE_PARRALEL)
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t0) / args.prefill_chunks
+        line["batched_decode"] = dict(streams=len(prompt), ms_per_step=round(dtb * 1e3, 3), aggregate_tokens_per_s=round(len(prompt) / dtb, 1),
+                                      note="MODE PARRALEL: one token of each of 32 independent sequences per step, weights read once per step")
 
     # ---- CPU baseline: the oracle (CPU restatement of rwkv.cu:493-593) on this box's host cores ----
     if rank == 0 and not args.no_cpu_baseline:

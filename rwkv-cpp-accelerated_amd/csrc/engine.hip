@@ -511,9 +511,11 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     return 0;
 }
 
-// One chunk (n <= SEQ_T tokens) of one sequence through the MFMA path (seq.hip.h); logits rows
-// [row0, row0 + n).  GPT-mode semantics of rwkv.cu:493-593: state slot 0, token shift along the chunk.
-int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0)
+// One chunk (n <= SEQ_T rows) through the MFMA path (seq.hip.h); logits rows [row0, row0 + n).
+// par == false: GPT-mode semantics of rwkv.cu:493-593 -- n tokens of one sequence, state slot 0, token
+// shift along the chunk.  par == true: PARRALEL mode (rwkv.cu:236-240) -- n independent sequences, one
+// token each, row t uses state slot row0 + t: the batched decode step, weights read once for all.
+int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, bool par)
 {
     const int D = (int)c->D;
     const uint64_t L = c->L, V = RWKV_VOCAB;
@@ -537,7 +539,8 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0)
         SeqSiteArgs s{};
         s.x = x; s.lnw = lnw; s.lnb = lnb;
         for (int k = 0; k < nv; k++) { s.mix[k] = mix ? mix[k] : nullptr; s.r[k] = r[k]; s.o[k] = o[k]; }
-        s.state = state; s.state_new = state ? c->sq_state : nullptr;
+        s.state = state; s.state_new = (state && !par) ? c->sq_state : nullptr;
+        s.par = par && state; s.state_par = state; s.slot_stride = (size_t)L * D; s.slot0 = (int)row0;
         for (int k = 0; k < 3; k++) s.img[k] = c->sq_img[k];
         s.rec = c->sq_rec; s.D = D; s.T = n;
         if (nv == 3) k_seq_site<3><<<dim3(n), dim3(NT), 0, st>>>(s);
@@ -551,9 +554,9 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0)
             const double *mix[3] = {c->mixk + lo, c->mixv + lo, c->mixr + lo};
             const float *r[3] = {c->kr + lo, c->vr + lo, c->rr + lo}, *o[3] = {c->o1 + lo, c->o2 + lo, c->o3 + lo};
             site(3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D, mix, r, o, c->state[0] + lo);
-            HIPCHK(hipMemcpyAsync(c->state[0] + lo, c->sq_state, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
+            if (!par) HIPCHK(hipMemcpyAsync(c->state[0] + lo, c->sq_state, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
             gemm(c->w_kvr + l * 3 * (size_t)D * D, c->rs_kvr + l * 3 * (size_t)D, 3 * D, D, 3, v012, c->sq_img, c->sq_kvr, 0);
-            SeqWkvArgs wa{c->sq_kvr, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, c->sq_y, D, n};
+            SeqWkvArgs wa{c->sq_kvr, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, c->sq_y, D, n, par ? 1 : 0, (size_t)L * D, (int)row0};
             k_seq_wkv<<<dim3((D + WKV_CH - 1) / WKV_CH), dim3(256), 0, st>>>(wa);
             SeqStageArgs sa{c->sq_y, c->attr + lo, c->atto + lo, c->sq_img[0], c->sq_rec, D, n};
             k_seq_stage<0><<<dim3(n), dim3(NT), 0, st>>>(sa);
@@ -563,7 +566,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0)
             const double *mix[3] = {c->fmixk + lo, c->fmixr + lo, nullptr};
             const float *r[3] = {c->fkr + lo, c->frr + lo, nullptr}, *o[3] = {c->fko + lo, c->fro + lo, nullptr};
             site(2, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D, mix, r, o, c->state[4] + lo);
-            HIPCHK(hipMemcpyAsync(c->state[4] + lo, c->sq_state, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
+            if (!par) HIPCHK(hipMemcpyAsync(c->state[4] + lo, c->sq_state, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
             gemm(c->w_frk + l * 5 * (size_t)D * D, c->rs_frk + l * 5 * (size_t)D, 5 * D, D, 5, v00001, c->sq_img, c->sq_frk, 0);
             SeqStageArgs sh{c->sq_frk, c->fvr + 4 * lo, c->fvo + 4 * lo, c->sq_imgh, c->sq_rec, 4 * D, n};
             k_seq_stage<1><<<dim3(n), dim3(NT), 0, st>>>(sh);
@@ -666,10 +669,10 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
     for (uint64_t t = 0; t < T; t++)
         if (tokens[t] >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id %llu out of range", (unsigned long long)tokens[t]);
     HIPCHK(hipSetDevice(c->device));
-    if (mode == RWKV_MODE_GPT && T >= 2 && c->seq_ok) {   // prompt chunks: weights read once per <= 32 tokens
+    if (T >= 2 && c->seq_ok) {   // prompt chunks (GPT) / batched decode step of T streams (PARRALEL): weights read once per <= 32 rows
         for (uint64_t t0 = 0; t0 < T; t0 += SEQ_T) {
             const int n = (int)(T - t0 < (uint64_t)SEQ_T ? T - t0 : (uint64_t)SEQ_T);
-            int rc = enqueue_chunk(c, tokens + t0, n, t0);
+            int rc = enqueue_chunk(c, tokens + t0, n, t0, mode == RWKV_MODE_PARRALEL);
             if (rc) return rc;
         }
         HIPCHK(hipStreamSynchronize(c->stream));

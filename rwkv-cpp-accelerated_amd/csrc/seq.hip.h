@@ -116,8 +116,12 @@ struct SeqSiteArgs {
     const double *lnw, *lnb;     // this site's LayerNorm rows
     const double *mix[3];        // token-shift mix per vector (nullptr: no shift, ln_out -> head)
     const float *r[3], *o[3];    // scale / offset of the matrices the vectors feed
-    const double *state;         // previous LayerNorm output (state xy / dd, slot 0): token 0's shift input
-    double *state_new;           // [D] LayerNorm output of the last token (copied over the state afterwards)
+    const double *state;         // previous LayerNorm output (state xy / dd of this layer, slot 0): token 0's shift input
+    double *state_new;           // GPT: [D] LayerNorm output of the last token (copied over the state afterwards)
+    int par;                     // PARRALEL mode (rwkv.cu:236-240): row t is an independent sequence with state slot slot0 + t --
+    double *state_par;           //   shift input and state write both go to that slot of this array (same base as `state`)
+    size_t slot_stride;          //   L * D
+    int slot0;
     unsigned *img[3];            // A-operand images
     SeqVec *rec;                 // [NV][SEQ_T]
     int D, T;
@@ -145,7 +149,8 @@ __global__ __launch_bounds__(NT) void k_seq_site(SeqSiteArgs a)
                 xt[i][e] = a.x[(size_t)t * D + j];
                 s[0] += xt[i][e]; s[1] += xt[i][e] * xt[i][e];
                 if (shift) {
-                    if (t > 0) { xp[i][e] = a.x[(size_t)(t - 1) * D + j]; s[2] += xp[i][e]; s[3] += xp[i][e] * xp[i][e]; }
+                    if (a.par) xp[i][e] = a.state_par[(size_t)(a.slot0 + t) * a.slot_stride + j];
+                    else if (t > 0) { xp[i][e] = a.x[(size_t)(t - 1) * D + j]; s[2] += xp[i][e]; s[3] += xp[i][e] * xp[i][e]; }
                     else xp[i][e] = a.state[j];
                 }
             }
@@ -153,7 +158,8 @@ __global__ __launch_bounds__(NT) void k_seq_site(SeqSiteArgs a)
     }
     block_sum<4>(s, red + RED_STATS);
     const double mean = s[0] / (double)D, rstd = 1.0 / sqrt((s[1] - s[0] * mean) / (double)(D - 1));
-    const double meanp = s[2] / (double)D, rstdp = (shift && t > 0) ? 1.0 / sqrt((s[3] - s[2] * meanp) / (double)(D - 1)) : 1.0;
+    const bool lnprev = shift && t > 0 && !a.par;   // the shift input is a LayerNorm output: of the previous row (GPT) or already stored (state)
+    const double meanp = s[2] / (double)D, rstdp = lnprev ? 1.0 / sqrt((s[3] - s[2] * meanp) / (double)(D - 1)) : 1.0;
 
     float xr[NV][SEQ_NQ][4];
     double So[NV];
@@ -170,8 +176,9 @@ __global__ __launch_bounds__(NT) void k_seq_site(SeqSiteArgs a)
             const int jc = real ? j : 0;
             const double xx = a.lnw[jc] * ((xt[i][e] - mean) * rstd) + a.lnb[jc];
             double xprev = xp[i][e];
-            if (shift && t > 0) xprev = a.lnw[jc] * ((xp[i][e] - meanp) * rstdp) + a.lnb[jc];
-            if (real && a.state_new && t == a.T - 1) a.state_new[j] = xx;          // mixatt / mixffn state write (:344,:385)
+            if (lnprev) xprev = a.lnw[jc] * ((xp[i][e] - meanp) * rstdp) + a.lnb[jc];
+            if (real && a.par) a.state_par[(size_t)(a.slot0 + t) * a.slot_stride + j] = xx;   // own slot: read above by this thread only
+            else if (real && a.state_new && t == a.T - 1) a.state_new[j] = xx;          // mixatt / mixffn state write (:344,:385)
 #pragma unroll
             for (int m = 0; m < NV; m++) {
                 float f = (float)xx;
@@ -258,6 +265,9 @@ struct SeqWkvArgs {
     double *saa, *sbb;           // state of this layer, slot 0
     float *y;                    // [T][D] gated wkv, cast to f32 as the att_out GEMV does (rwkv.cu:290)
     int D, T;
+    int par;                     // PARRALEL mode: row t uses state slot slot0 + t (no recurrence along the rows)
+    size_t slot_stride;
+    int slot0;
 };
 constexpr int WKV_CH = 8;        // channels per workgroup (256 threads = 8 channels x 32 tokens)
 // rwkv.cu:242-255 with the GPT-mode state slot 0.  The exponentials do not depend on the state, so
@@ -277,6 +287,17 @@ __global__ __launch_bounds__(256) void k_seq_wkv(SeqWkvArgs a)
         sgs[t][ch] = 1.0 / (1.0 + (double)expf(-r));       // rwkv.cu:250: exp of a float argument
     }
     __syncthreads();
+    if (a.par) {
+        if (i < a.D && t < a.T) {
+            const size_t so = (size_t)(a.slot0 + t) * a.slot_stride + i;
+            const double aa = a.saa[so], bb = a.sbb[so], ew = a.ew[i];
+            const double e1 = e1s[t][ch], ek = eks[t][ch], vv = vs[t][ch];
+            a.y[(size_t)t * a.D + i] = (float)(sgs[t][ch] * ((aa + e1 * vv) / (bb + e1)));
+            a.saa[so] = (aa + ek * vv) * ew;
+            a.sbb[so] = (bb + ek) * ew;
+        }
+        return;
+    }
     if (threadIdx.x < WKV_CH && i < a.D) {
         double aa = a.saa[i], bb = a.sbb[i];
         const double ew = a.ew[i];

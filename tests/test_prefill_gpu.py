@@ -59,3 +59,25 @@ def test_chunk_is_deterministic(eng_mod):
     b = m.forward(toks, eng_mod.MODE_GPT)[: T * mf.VOCAB].copy()
     assert np.array_equal(a, b)      # integer contraction + exact LDS sums: no order dependence
     m.close()
+
+
+@pytest.mark.parametrize("L,D,T", [(2, 768, 3), (2, 1024, 32), (1, 4096, 17), (2, 256, 40)])
+def test_parralel_batch_vs_oracle(eng_mod, oracle, L, D, T):
+    """PARRALEL mode (rwkv.cu:236-240): T independent sequences advance one token per call, state slot t;
+    the engine runs the batch through the MFMA path (weights read once for all streams)."""
+    t = mf.synthetic_tensors(L, D, seed=500 + D + T)
+    m = eng_mod.RWKV(resident=True)
+    m.loadTensors(L, D, t, maxGPT=T)
+    om = oracle.from_tensors(L, D, t)
+    sp = om.new_state(slots=T)
+    for rnd in range(3):                     # the state of every slot carries over between rounds
+        toks = _toks(T, 1000 * rnd + T)
+        ref = om.forward(toks, sp, mode=0)
+        got = m.forward(toks, eng_mod.MODE_PARRALEL)[: T * mf.VOCAB].reshape(T, mf.VOCAB)
+        for i in range(T):
+            parity.check_logits(got[i], ref[i], f"L{L} D{D} round {rnd} slot {i}")
+            parity.check_argmax(got[i], ref[i], f"L{L} D{D} round {rnd} slot {i}")
+    m.pull_state(T)
+    for name, g, r in zip("xy aa bb pp dd".split(), m.state.arrays(), sp):
+        assert np.abs(g[: T * L * D] - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), name
+    om.close(); m.close()
