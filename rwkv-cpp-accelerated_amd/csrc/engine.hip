@@ -526,12 +526,13 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
     double *x = c->sq_x[0];
     SeqEmbedArgs ea{c->embed, c->ln, c->sq_tokens, x, D};
     k_seq_embed<<<dim3(n), dim3(NT), 0, st>>>(ea);
-    auto gemm = [&](const uint8_t *w, const unsigned *rs, int N, int K, int Q, const int *voq, unsigned *const *img, float *out, int epi) {
+    auto gemm = [&](const uint8_t *w, const unsigned *rs, int N, int K, int Q, const int *voq, unsigned *const *img, float *out, int epi, double *state_dst = nullptr) {
         SeqGemmArgs g;
         g.w = w; g.rs = rs; g.N = N; g.K = K; g.Q = Q;
         for (int q = 0; q < 5; q++) g.vec_of_q[q] = q < Q ? voq[q] : 0;
         for (int k = 0; k < 3; k++) g.img[k] = reinterpret_cast<const u32x4 *>(img[k]);
         g.rec = c->sq_rec; g.out = out; g.epi = epi; g.x = x; g.gate = c->sq_frk; g.T = n;
+        g.cp_src = c->sq_state; g.cp_dst = state_dst; g.cp_n = (state_dst && !par) ? D : 0;   // GPT: commit the site's state behind it
         k_mm8_seq<<<dim3(c->grid), dim3(SEQ_NT), 0, st>>>(g);
     };
     auto site = [&](int nv, const double *lnw, const double *lnb, const double *const *mix, const float *const *r, const float *const *o,
@@ -554,8 +555,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
             const double *mix[3] = {c->mixk + lo, c->mixv + lo, c->mixr + lo};
             const float *r[3] = {c->kr + lo, c->vr + lo, c->rr + lo}, *o[3] = {c->o1 + lo, c->o2 + lo, c->o3 + lo};
             site(3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D, mix, r, o, c->state[0] + lo);
-            if (!par) HIPCHK(hipMemcpyAsync(c->state[0] + lo, c->sq_state, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
-            gemm(c->w_kvr + l * 3 * (size_t)D * D, c->rs_kvr + l * 3 * (size_t)D, 3 * D, D, 3, v012, c->sq_img, c->sq_kvr, 0);
+            gemm(c->w_kvr + l * 3 * (size_t)D * D, c->rs_kvr + l * 3 * (size_t)D, 3 * D, D, 3, v012, c->sq_img, c->sq_kvr, 0, c->state[0] + lo);
             SeqWkvArgs wa{c->sq_kvr, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, c->sq_y, D, n, par ? 1 : 0, (size_t)L * D, (int)row0};
             k_seq_wkv<<<dim3((D + WKV_CH - 1) / WKV_CH), dim3(256), 0, st>>>(wa);
             SeqStageArgs sa{c->sq_y, c->attr + lo, c->atto + lo, c->sq_img[0], c->sq_rec, D, n};
@@ -566,8 +566,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
             const double *mix[3] = {c->fmixk + lo, c->fmixr + lo, nullptr};
             const float *r[3] = {c->fkr + lo, c->frr + lo, nullptr}, *o[3] = {c->fko + lo, c->fro + lo, nullptr};
             site(2, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D, mix, r, o, c->state[4] + lo);
-            if (!par) HIPCHK(hipMemcpyAsync(c->state[4] + lo, c->sq_state, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
-            gemm(c->w_frk + l * 5 * (size_t)D * D, c->rs_frk + l * 5 * (size_t)D, 5 * D, D, 5, v00001, c->sq_img, c->sq_frk, 0);
+            gemm(c->w_frk + l * 5 * (size_t)D * D, c->rs_frk + l * 5 * (size_t)D, 5 * D, D, 5, v00001, c->sq_img, c->sq_frk, 0, c->state[4] + lo);
             SeqStageArgs sh{c->sq_frk, c->fvr + 4 * lo, c->fvo + 4 * lo, c->sq_imgh, c->sq_rec, 4 * D, n};
             k_seq_stage<1><<<dim3(n), dim3(NT), 0, st>>>(sh);
             unsigned *imgh[3] = {c->sq_imgh, c->sq_imgh, c->sq_imgh};

@@ -326,6 +326,9 @@ struct SeqGemmArgs {
     double *x;                   // epi 1, 2: residual stream [T][N], updated in place (one owner per element)
     const float *gate;           // epi 2: ffn k/r GEMM output [T][5N], the r value of channel j at [t][5 j + 4]
     int T;
+    const double *cp_src;        // piggy-back copy (stream-ordered behind the site kernel that produced it): the chunk's
+    double *cp_dst;              // last LayerNorm output -> recurrent state; cp_n == 0: none
+    int cp_n;
 };
 constexpr int SEQ_TB = 5;        // weight tiles (16 rows each) per workgroup pass
 #ifndef RWKV_SEQ_NT
@@ -433,6 +436,8 @@ __global__ __launch_bounds__(SEQ_NT) void k_mm8_seq(SeqGemmArgs a)
     const int ntiles = Q * CB;
     const int tb0 = (int)(((long long)blockIdx.x * ntiles) / gridDim.x), tb1 = (int)(((long long)(blockIdx.x + 1) * ntiles) / gridDim.x);
     const int g = lane & 3, c = lane >> 2;   // load mapping: 4 adjacent lanes cover 64 contiguous bytes of a row
+    if (blockIdx.x == gridDim.x - 1)
+        for (int j = threadIdx.x; j < a.cp_n; j += SEQ_NT) a.cp_dst[j] = a.cp_src[j];
 
     int tg = tb0;
     while (tg < tb1) {
