@@ -81,3 +81,48 @@ def test_parralel_batch_vs_oracle(eng_mod, oracle, L, D, T):
     for name, g, r in zip("xy aa bb pp dd".split(), m.state.arrays(), sp):
         assert np.abs(g[: T * L * D] - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), name
     om.close(); m.close()
+
+
+def _adversarial(L, D, seed):
+    """synthetic model with the statistics that stress the fixed-point paths: embedding rows with a mean far
+    from zero, LayerNorm weights / biases with outlier channels, token-shift mixes pinned at 0 and 1, scale
+    vectors spanning two decades, extreme decays"""
+    t = mf.synthetic_tensors(L, D, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    t[mf.EMBED] = (t[mf.EMBED].reshape(mf.VOCAB, D) * 5.0 + 20.0).astype(np.float32).reshape(-1)
+    ln = t[mf.LAYERNORMS].reshape(-1, D).copy()
+    hot = rng.random(ln.shape) < 0.01
+    ln[0::2][hot[0::2]] *= 20.0
+    ln[1::2][hot[1::2]] += 10.0 * rng.choice([-1.0, 1.0], size=int(hot[1::2].sum()))
+    t[mf.LAYERNORMS] = ln.reshape(-1)
+    for s in (mf.MIXK, mf.MIXV, mf.MIXR, mf.FFNMIXK, mf.FFNMIXV):
+        v = t[s].copy(); u = rng.random(v.shape)
+        v[u < 0.05] = 0.0; v[u > 0.95] = 1.0
+        t[s] = v
+    for s in (mf.KR, mf.VR, mf.RR, mf.ATTOUTR, mf.FFNKR, mf.FFNVR, mf.FFNRR):
+        t[s] = (t[s] * np.exp(rng.uniform(np.log(0.3), np.log(3.0), t[s].shape))).astype(np.float32)
+    d = t[mf.DECAY].copy(); u = rng.random(d.shape)
+    d[u < 0.02] = -20.0; d[u > 0.98] = -1e-4
+    t[mf.DECAY] = d
+    return t
+
+
+@pytest.mark.parametrize("L,D", [(2, 1024), (1, 4096)])
+def test_adversarial_statistics_decode_and_chunk(eng_mod, oracle, L, D):
+    t = _adversarial(L, D, seed=900 + D)
+    m = eng_mod.RWKV(resident=True)
+    m.loadTensors(L, D, t, maxGPT=16)
+    om = oracle.from_tensors(L, D, t)
+    st = om.new_state()
+    for step, tk in enumerate(_toks(6, D)):                 # single-token kernels (bound-based scales, site tables)
+        ref = om.forward([tk], st)[0]
+        parity.check_logits(m.forward(tk)[: mf.VOCAB], ref, f"adversarial D{D} decode {step}")
+    toks = _toks(16, D + 1)                                 # then a chunk from that state (per-token exact scales)
+    ref = om.forward(toks, st)
+    got = m.forward(toks, eng_mod.MODE_GPT)[: 16 * mf.VOCAB].reshape(16, mf.VOCAB)
+    for i in range(16):
+        parity.check_logits(got[i], ref[i], f"adversarial D{D} chunk pos {i}")
+    m.pull_state(1)
+    for name, g, r in zip("xy aa bb pp dd".split(), m.state.arrays(), st):
+        assert np.abs(g[: L * D] - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), name
+    om.close(); m.close()
