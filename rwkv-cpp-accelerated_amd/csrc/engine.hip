@@ -150,7 +150,10 @@ size_t smem_frk(int S, int gpb) { return RED_BYTES + 2 * (size_t)S * 3072 + (siz
 size_t smem_fv(int S) { return RED_BYTES + 4 * (size_t)S * 3072; }
 size_t smem_head(int S) { return RED_BYTES + (size_t)S * 3072 + NW * 8; }
 
-constexpr int ATTOUT_R = 2;
+#ifndef RWKV_ATTOUT_R
+#define RWKV_ATTOUT_R 2
+#endif
+constexpr int ATTOUT_R = RWKV_ATTOUT_R;
 constexpr int SITE_NV[3] = {3, 2, 1};
 constexpr int SITE_PW[3] = {site_pw<3>(), site_pw<2>(), site_pw<1>()};
 

@@ -771,7 +771,6 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int XVD = xvd<S>();
-    constexpr int NQ = nquads<S>();
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     float *stash = reinterpret_cast<float *>(xq + 3 * XVD);
@@ -863,7 +862,6 @@ template <int S, int R>
 __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NQ = nquads<S>();
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -947,7 +945,6 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int XVD = xvd<S>();
-    constexpr int NQ = nquads<S>();
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     float *stash = reinterpret_cast<float *>(xq + 2 * XVD);
@@ -1032,7 +1029,6 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int XVD = xvd<S>();
-    constexpr int NQ = nquads<S>();
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1101,7 +1097,6 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int XVD = xvd<S>();
-    constexpr int NQ = nquads<S>();
     constexpr int R = 4;
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
