@@ -558,6 +558,9 @@ constexpr int RED_BC = 96;     // doubles: scalars published by the prologue wav
 #ifndef RWKV_DYN
 #define RWKV_DYN 1
 #endif
+#ifndef RWKV_HEAD_R
+#define RWKV_HEAD_R 2      // rows per group in k_head (measured: 2 -> 35.8, 3 -> 36.2, 4 -> 36.8, 5 -> 38.0 us at 7B)
+#endif
 __device__ __forceinline__ unsigned *group_counter(double *red) { return reinterpret_cast<unsigned *>(red + RED_BC) + 9; }
 __device__ __forceinline__ int next_group(unsigned *ctr, int after)
 {
@@ -1097,7 +1100,7 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int XVD = xvd<S>();
-    constexpr int R = 4;
+    constexpr int R = RWKV_HEAD_R;
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     float *bval = reinterpret_cast<float *>(xq + XVD);
@@ -1135,12 +1138,14 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
         int row0 = g * R;
         const int shift = (row0 > V - R) ? row0 - (V - R) : 0;
         row0 -= shift;
-        const u32x4 rs4 = {a.rs[row0], a.rs[row0 + 1], a.rs[row0 + 2], a.rs[row0 + 3]};   // before the refills (see k_att)
+        unsigned rsr[R];   // before the refills (see k_att)
+#pragma unroll
+        for (int r = 0; r < R; r++) rsr[r] = a.rs[row0 + r];
         group_dot<R, S, PAT_SHARED>(w, xq, lane, T, rowbase(nv ? gn : 0), (size_t)D, chunks, nv);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = row0 + r;
-            const float val = row_value(T[r], rs4[r], sc) + Sf;
+            const float val = row_value(T[r], rsr[r], sc) + Sf;
             if (lane == r && r >= shift) lg[i] = val;
             if (i != 0 && (val > best || (val == best && (unsigned)i < besti))) { best = val; besti = (unsigned)i; }
         }
