@@ -201,7 +201,7 @@ def main():
 
     # ---- CPU baseline: the oracle (CPU restatement of rwkv.cu:493-593) on this box's host cores ----
     if rank == 0 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(pkg, mf, tensors, L, D, prompt, args.cpu_seconds)
+        line["cpu_baseline"] = cpu_baseline(pkg, mf, tensors, L, D, prompt, args.cpu_seconds, engine_model=m)
 
     m.close()
     if rank == 0:
@@ -256,8 +256,9 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     dist.destroy_process_group()
 
 
-def cpu_baseline(pkg, mf, tensors, L, D, prompt, budget_s):
-    """rank 0, N=1 leg: time the oracle on a bounded sample of the same workload."""
+def cpu_baseline(pkg, mf, tensors, L, D, prompt, budget_s, engine_model=None):
+    """rank 0, N=1 leg: time the oracle on a bounded sample of the same workload -- and, since the oracle's
+    logits of the FULL-SIZE model are at hand, use them as the checker of the engine (teacher-forced)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     pkg.build.build_oracle()
@@ -274,14 +275,27 @@ def cpu_baseline(pkg, mf, tensors, L, D, prompt, budget_s):
     n = int(max(1, min(31, (budget_s - one) // max(one, 1e-3))))
     t0 = time.perf_counter()
     tk = int(np.argmax(lg[0][1:])) + 1
+    fed, refs = [prompt[0]], [lg[0].copy()]
     for i in range(n):
+        fed.append(tk)
         lg = om.forward([tk], st)
+        refs.append(lg[0].copy())
         tk = int(np.argmax(lg[0][1:])) + 1
     dt = time.perf_counter() - t0
     om.close()
-    return dict(value=round(n / dt, 4), unit="tokens/s", cores=cores, kind="port",
-                sample=f"{n} greedy tokens of the same synthetic model after a 1-token warm-up "
-                       f"(oracle/rwkv_oracle.c, OpenMP over output columns; weights copied to host in {copy_s:.1f}s)")
+    out = dict(value=round(n / dt, 4), unit="tokens/s", cores=cores, kind="port",
+               sample=f"{n} greedy tokens of the same synthetic model after a 1-token warm-up "
+                      f"(oracle/rwkv_oracle.c, OpenMP over output columns; weights copied to host in {copy_s:.1f}s)")
+    if engine_model is not None:      # full-size parity: same tokens through the engine, logits vs the oracle's
+        engine_model.reset_state()
+        worst, same = 0.0, True
+        for tkn, ref in zip(fed, refs):
+            got = engine_model.forward(int(tkn))[: mf.VOCAB]
+            worst = max(worst, float(np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max()))
+            same = same and (int(np.argmax(got[1:])) == int(np.argmax(ref[1:])))
+        out["parity_vs_engine"] = dict(steps=len(fed), max_rel_logit_err=float(f"{worst:.3e}"), greedy_ids_identical=bool(same),
+                                       tolerance=1e-3, note="full-size model, teacher-forced with the oracle's greedy ids")
+    return out
 
 
 if __name__ == "__main__":
