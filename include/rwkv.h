@@ -227,6 +227,24 @@ public:
         rwkv_detail::check(rwkv_decode_greedy(ctx_, first, n, ids.data()));
         return std::vector<unsigned long long>(ids.begin(), ids.end());
     }
+    // typical sampling on the device from the logits of the last forward (no 201 KB download, no host sort);
+    // u in [0, 1) is the caller's uniform, the draw is the inverse CDF in token order (rwkv_sampler.h typical_u)
+    int sampleTypical(float temp, float tau, double u, bool ban0 = false, unsigned long long row = 0)
+    {
+        if (!ready) throw std::runtime_error("RWKV not loaded");
+        uint64_t tok = 0;
+        rwkv_detail::check(rwkv_sample_typical(ctx_, row, temp, tau, u, ban0 ? 1 : 0, &tok));
+        return (int)tok;
+    }
+    // device-side sampled continuation: storygen's loop (examples/storygen/storygen.cpp:63-69) without host round trips
+    std::vector<unsigned long long> decodeTypical(unsigned long long first, unsigned long long n, float temp = 0.9f, float tau = 0.8f,
+                                                  unsigned long long seed = 0)
+    {
+        if (!ready) throw std::runtime_error("RWKV not loaded");
+        std::vector<uint64_t> ids(n);
+        rwkv_detail::check(rwkv_decode_typical(ctx_, first, n, temp, tau, seed, ids.data()));
+        return std::vector<unsigned long long>(ids.begin(), ids.end());
+    }
     rwkv_ctx *handle() { return ctx_; }
 
     ~RWKV()

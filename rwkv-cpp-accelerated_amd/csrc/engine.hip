@@ -6,6 +6,7 @@
 // device, and one token is a replay of a captured hipGraph (4 launches per layer + 2).
 #include "kernels.hip.h"
 #include "seq.hip.h"
+#include "sampler.hip.h"
 #include "../../include/rwkv_mi355x.h"
 
 #include <algorithm>
@@ -115,6 +116,10 @@ struct rwkv_ctx {
     Ctl *ctl = nullptr;
     Ctl *h_ctl = nullptr;    // pinned staging, maxT entries
     unsigned long long *gen = nullptr;
+    unsigned long long *pick = nullptr;      // device: id drawn by the sampler
+    double *ts_part = nullptr;               // sampler scratch (sampler.hip.h)
+    float *ts_p = nullptr;
+    unsigned *ts_key = nullptr;
     unsigned gen_cap = 0;
     hipGraphExec_t g_fwd = nullptr, g_greedy = nullptr;
     unsigned long long *tl = nullptr;   // phase-timeline buffer (debug), [grid][NW][8]
@@ -481,6 +486,10 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_ctl), sizeof(Ctl) * max_ctx, hipHostMallocDefault));
     c->gen_cap = 1u << 16;
     if ((rc = dalloc(c, &c->gen, (size_t)c->gen_cap))) return rc;
+    if ((rc = dalloc(c, &c->pick, 1))) return rc;
+    if ((rc = dalloc(c, &c->ts_part, (size_t)TS_G * 3))) return rc;
+    if ((rc = dalloc(c, &c->ts_p, (size_t)TS_NT * TS_PER))) return rc;
+    if ((rc = dalloc(c, &c->ts_key, (size_t)TS_NT * TS_PER))) return rc;
 
     // chunked path scratch
     {
@@ -765,6 +774,57 @@ int rwkv_decode_greedy(rwkv_ctx *c, uint64_t first_token, uint64_t n, uint64_t *
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     for (uint64_t i = 0; i < n; i++) {
         int rc = run_token(c, true);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(out_tokens, c->gen, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+namespace {
+int launch_typical(rwkv_ctx *c, int row, float temp, float tau, double u, uint64_t seed, bool use_seed, bool ban0, bool feedback)
+{
+    TypicalArgs a;
+    a.logits = c->logits; a.row = row; a.ctl = c->ctl; a.gen = c->gen; a.gen_cap = c->gen_cap;
+    a.temp = temp; a.tau = tau; a.u = u; a.seed = seed; a.use_seed = use_seed ? 1 : 0; a.ban0 = ban0 ? 1 : 0;
+    a.feedback = feedback ? 1 : 0; a.pick = c->pick; a.part = c->ts_part; a.p = c->ts_p; a.key = c->ts_key;
+    k_typical_stats<<<dim3(TS_G), dim3(TS_GT), 0, c->stream>>>(a);
+    k_typical_keys<<<dim3(TS_G), dim3(TS_GT), 0, c->stream>>>(a);
+    k_typical<<<dim3(1), dim3(TS_NT), 0, c->stream>>>(a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+} // namespace
+
+int rwkv_sample_typical(rwkv_ctx *c, uint64_t row, float temp, float tau, double u, int ban0, uint64_t *token)
+{
+    if (!c || !token) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (c->l1 != c->L) return fail(RWKV_E_STATE, "this pipeline stage does not hold the head");
+    if (row >= c->maxT) return fail(RWKV_E_ARG, "logits row %llu out of range (max context %llu)", (unsigned long long)row, (unsigned long long)c->maxT);
+    if (!(temp > 0.f) || !(u >= 0.0 && u < 1.0)) return fail(RWKV_E_ARG, "need temp > 0 and 0 <= u < 1");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = launch_typical(c, (int)row, temp, tau, u, 0, false, ban0 != 0, false);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(token, c->pick, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rwkv_decode_typical(rwkv_ctx *c, uint64_t first_token, uint64_t n, float temp, float tau, uint64_t seed, uint64_t *out_tokens)
+{
+    if (!c || !out_tokens) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (c->l0 != 0 || c->l1 != c->L) return fail(RWKV_E_STATE, "needs a whole-model context");
+    if (first_token >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
+    if (n == 0 || n > c->gen_cap) return fail(RWKV_E_ARG, "n_tokens must be in 1..%u", c->gen_cap);
+    if (!(temp > 0.f)) return fail(RWKV_E_ARG, "need temp > 0");
+    HIPCHK(hipSetDevice(c->device));
+    c->h_ctl[0].token = first_token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
+    HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+    for (uint64_t i = 0; i < n; i++) {
+        int rc = run_token(c, false);                                   // the token graph without the argmax node
+        if (!rc) rc = launch_typical(c, -1, temp, tau, 0.0, seed, true, true, true);
         if (rc) return rc;
     }
     HIPCHK(hipMemcpyAsync(out_tokens, c->gen, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "rwkv_create", "rwkv_load_file", "rwkv_load_tensors", "rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx",
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
-    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device",
+    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
 ]
 
 _lib = None
@@ -67,6 +67,8 @@ def lib():
     L.rwkv_x_device.argtypes = [vp]; L.rwkv_x_device.restype = vp
     L.rwkv_profile_batched.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]; L.rwkv_profile_batched.restype = i32
     L.rwkv_debug_timeline.argtypes = [vp, u64, vp, u64]; L.rwkv_debug_timeline.restype = i32
+    L.rwkv_sample_typical.argtypes = [vp, u64, C.c_float, C.c_float, C.c_double, i32, C.POINTER(u64)]; L.rwkv_sample_typical.restype = i32
+    L.rwkv_decode_typical.argtypes = [vp, u64, u64, C.c_float, C.c_float, u64, C.POINTER(u64)]; L.rwkv_decode_typical.restype = i32
     _lib = L
     return L
 
@@ -229,6 +231,19 @@ class RWKV:
             raise RuntimeError("RWKV not loaded")
         out = (C.c_uint64 * n_tokens)()
         _chk(lib().rwkv_decode_greedy(self._h, int(first_token), n_tokens, out))
+        return np.frombuffer(out, dtype=np.uint64).copy()
+
+    def sample_typical(self, temp: float = 0.9, tau: float = 0.8, u: float = 0.5, row: int = 0, ban0: bool = False) -> int:
+        """typical sampling ON THE DEVICE from the logits of the last forward (reference typical.h:20-58);
+        u in [0, 1) is the caller's uniform -- the draw is the inverse CDF in token order."""
+        tok = C.c_uint64(0)
+        _chk(lib().rwkv_sample_typical(self._h, int(row), float(temp), float(tau), float(u), 1 if ban0 else 0, C.byref(tok)))
+        return int(tok.value)
+
+    def decode_typical(self, first_token: int, n_tokens: int, temp: float = 0.9, tau: float = 0.8, seed: int = 0) -> np.ndarray:
+        """device-side sampled continuation (storygen's loop with the device sampler; logit 0 banned)"""
+        out = (C.c_uint64 * n_tokens)()
+        _chk(lib().rwkv_decode_typical(self._h, int(first_token), n_tokens, float(temp), float(tau), int(seed), out))
         return np.frombuffer(out, dtype=np.uint64).copy()
 
     def logits(self, n_tokens: int = 1) -> np.ndarray:
