@@ -118,7 +118,7 @@ struct rwkv_ctx {
     unsigned long long *gen = nullptr;
     unsigned long long *pick = nullptr;      // device: id drawn by the sampler
     double *ts_part = nullptr;               // sampler scratch (sampler.hip.h)
-    float *ts_p = nullptr;
+    float *ts_p = nullptr, *ts_pw = nullptr;
     unsigned *ts_key = nullptr;
     unsigned gen_cap = 0;
     hipGraphExec_t g_fwd = nullptr, g_greedy = nullptr;
@@ -489,6 +489,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if ((rc = dalloc(c, &c->pick, 1))) return rc;
     if ((rc = dalloc(c, &c->ts_part, (size_t)TS_G * 3))) return rc;
     if ((rc = dalloc(c, &c->ts_p, (size_t)TS_NT * TS_PER))) return rc;
+    if ((rc = dalloc(c, &c->ts_pw, (size_t)TS_NT * TS_PER))) return rc;
     if ((rc = dalloc(c, &c->ts_key, (size_t)TS_NT * TS_PER))) return rc;
 
     // chunked path scratch
@@ -787,7 +788,7 @@ int launch_typical(rwkv_ctx *c, int row, float temp, float tau, double u, uint64
     TypicalArgs a;
     a.logits = c->logits; a.row = row; a.ctl = c->ctl; a.gen = c->gen; a.gen_cap = c->gen_cap;
     a.temp = temp; a.tau = tau; a.u = u; a.seed = seed; a.use_seed = use_seed ? 1 : 0; a.ban0 = ban0 ? 1 : 0;
-    a.feedback = feedback ? 1 : 0; a.pick = c->pick; a.part = c->ts_part; a.p = c->ts_p; a.key = c->ts_key;
+    a.feedback = feedback ? 1 : 0; a.pick = c->pick; a.part = c->ts_part; a.p = c->ts_p; a.pw = c->ts_pw; a.key = c->ts_key;
     k_typical_stats<<<dim3(TS_G), dim3(TS_GT), 0, c->stream>>>(a);
     k_typical_keys<<<dim3(TS_G), dim3(TS_GT), 0, c->stream>>>(a);
     k_typical<<<dim3(1), dim3(TS_NT), 0, c->stream>>>(a);

@@ -40,6 +40,7 @@ struct TypicalArgs {
     double *part;                 // [TS_G][3] per-workgroup (max, sum exp(l - max), sum exp(l - max) (l - max))
     float *p;                     // [TS_NT * TS_PER] probabilities, position (i % TS_PER) * TS_NT + i / TS_PER for token i
     unsigned *key;                // same layout: bit patterns of |-log p - H|
+    float *pw;                    // same layout: p^(1/temp) (typical.h:49-52), zeroed for the tokens that are cut
 };
 
 __device__ __forceinline__ const float *ts_row(const TypicalArgs &a) { return a.logits + (size_t)(a.row >= 0 ? (unsigned)a.row : a.ctl->out_row) * VOCAB; }
@@ -101,16 +102,18 @@ __global__ __launch_bounds__(TS_GT) void k_typical_keys(TypicalArgs a)
     const float *lg = ts_row(a);
     double M, logZ, H;
     ts_combine(a, M, logZ, H);
+    const double it = 1.0 / (double)a.temp;
     for (int i = i0 + threadIdx.x; i < i1; i += TS_GT) {
         const double nl = (M - (double)ts_logit(a, lg, i)) + logZ;          // -log p_i
         const int pos = (i % TS_PER) * TS_NT + i / TS_PER;
         a.p[pos] = (float)exp(-nl);
+        a.pw[pos] = a.temp == 1.0f ? (float)exp(-nl) : (float)exp(-nl * it);   // p^(1/temp), here: 64 workgroups share the exponentials
         a.key[pos] = __float_as_uint((float)fabs(nl - H));                  // typical.h:32
     }
     if (blockIdx.x == 0)       // padding positions: tokens V .. TS_NT * TS_PER - 1 carry no mass and the largest key
         for (int i = V + threadIdx.x; i < TS_NT * TS_PER; i += TS_GT) {
             const int pos = (i % TS_PER) * TS_NT + i / TS_PER;
-            a.p[pos] = 0.f; a.key[pos] = 0x7f800000u;
+            a.p[pos] = 0.f; a.pw[pos] = 0.f; a.key[pos] = 0x7f800000u;
         }
 }
 
@@ -152,6 +155,8 @@ __global__ __launch_bounds__(TS_NT) void k_typical(TypicalArgs a)
         const int shift = pass == 0 ? 20 : pass == 1 ? 8 : 0, bits = pass == 2 ? 8 : 12, nb = 1 << bits;
         for (int b = t; b < TS_HIST; b += TS_NT) hist[b] = 0.0;
         __syncthreads();
+        // unrolled by 10: twenty loads in flight per thread (one load per trip would expose an L2 latency per token)
+#pragma unroll 10
         for (int k = 0; k < TS_PER; k++) {
             const unsigned kb = a.key[k * TS_NT + t];
             const float pk = a.p[k * TS_NT + t];
@@ -189,13 +194,12 @@ __global__ __launch_bounds__(TS_NT) void k_typical(TypicalArgs a)
         __syncthreads();
     }
     const unsigned thr = open_end ? 0x7f800000u : prefix;
-    // p^(1/temp) on the kept set (typical.h:49-52) and the inverse-CDF draw in token order
+    // weights of the kept set (already raised to 1/temp) and the inverse-CDF draw in token order
     double wsum = 0.0;
-    const double it = 1.0 / (double)a.temp;
+#pragma unroll 10
     for (int k = 0; k < TS_PER; k++) {
-        float w = a.key[k * TS_NT + t] <= thr ? a.p[k * TS_NT + t] : 0.f;
-        if (w > 0.f && a.temp != 1.0f) w = (float)pow((double)w, it);
-        a.p[k * TS_NT + t] = w;                        // own positions only
+        const float w = a.key[k * TS_NT + t] <= thr ? a.pw[k * TS_NT + t] : 0.f;
+        a.pw[k * TS_NT + t] = w;                       // own positions only
         wsum += (double)w;
     }
     scan[t] = wsum;
@@ -222,8 +226,9 @@ __global__ __launch_bounds__(TS_NT) void k_typical(TypicalArgs a)
     if (wsum > 0.0 && target >= before && target < before + wsum) {
         double c = before;
         int sel = -1, lastkept = -1;
+#pragma unroll 10
         for (int k = 0; k < TS_PER; k++) {
-            const float w = a.p[k * TS_NT + t];
+            const float w = a.pw[k * TS_NT + t];
             if (w > 0.f) { c += (double)w; lastkept = i0 + k; if (sel < 0 && target < c) sel = i0 + k; }
         }
         if (sel < 0) sel = lastkept;               // rounding at the upper edge of this thread's range
