@@ -174,6 +174,17 @@ def main():
     if drop_in is not None:
         line["drop_in_mode"] = drop_in
 
+    # ---- the reference's own generation loop (storygen: out[0] = -99; typical(out, 0.9, 0.8)) with the DEVICE sampler ----
+    if rank == 0:
+        n_s = min(256, args.steps)
+        m.decode_typical(int(ids[-1]), 8, temp=0.9, tau=0.8, seed=7)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.decode_typical(int(ids[-1]), n_s, temp=0.9, tau=0.8, seed=8)
+        dts = time.perf_counter() - t0
+        line["sampled_decode"] = dict(tokens_per_s=round(n_s / dts, 2), steps=n_s,
+                                      note="typical sampling (temp 0.9, tau 0.8) on the device after every token, no host round trip (csrc/sampler.hip.h)")
+
     # ---- BASELINE config 5 beside it: 32-token prompt chunks through mm8_seq (int8 MFMA), weights read once per chunk ----
     if rank == 0 and args.prefill_chunks > 0:
         m.forward(prompt, engine.MODE_GPT)
