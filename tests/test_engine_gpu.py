@@ -228,3 +228,41 @@ def test_pipeline_virtual_stages_equal_full_model(eng_mod):
     for s in stages:
         s.m.close()
     full.close()
+
+
+def test_long_decode_is_stable_and_deterministic(eng_mod):
+    """thousands of device-side steps: ids reproducible run to run, state and logits stay finite"""
+    L, D, n = 4, 2048, 3000
+    t = mf.synthetic_tensors(L, D, seed=21)
+    m = eng_mod.RWKV(resident=True)
+    m.loadTensors(L, D, t)
+    a = m.decode_greedy(17, n)
+    la = m.logits(1).copy()
+    m.reset_state()
+    b = m.decode_greedy(17, n)
+    assert np.array_equal(a, b) and np.array_equal(la, m.logits(1))
+    assert np.isfinite(la).all() and a.max() < mf.VOCAB and (a != 0).all()      # token 0 is banned
+    m.pull_state(1)
+    for arr in m.state.arrays():
+        assert np.isfinite(arr[: L * D]).all()
+    with pytest.raises(eng_mod.RWKVError):
+        m.decode_greedy(17, (1 << 16) + 1)                                      # beyond the generated-id buffer
+    m.close()
+
+
+def test_graph_replay_equals_eager_launches(eng_mod):
+    """the captured hipGraph and plain stream launches run the same kernels: bit-identical logits"""
+    L, D = 2, 1024
+    t = mf.synthetic_tensors(L, D, seed=22)
+    m = eng_mod.RWKV(resident=True)
+    m.loadTensors(L, D, t)
+    os.environ["RWKV_NO_GRAPH"] = "1"
+    try:
+        e = eng_mod.RWKV(resident=True)
+        e.loadTensors(L, D, t)
+    finally:
+        del os.environ["RWKV_NO_GRAPH"]
+    for tk in (3, 50000, 77, 3):
+        assert np.array_equal(m.forward(tk)[: mf.VOCAB], e.forward(tk)[: mf.VOCAB])
+    assert np.array_equal(m.decode_greedy(5, 40), e.decode_greedy(5, 40))
+    m.close(); e.close()
