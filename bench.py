@@ -58,8 +58,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180),
-                                device_id=torch.device("cuda", local_rank))
+        # RWKV_BENCH_BACKEND=gloo + RWKV_BENCH_ONE_DEVICE=1: dry run of the N > 1 path on a single-GPU box (all ranks on
+        # cuda:0, the hop staged through host memory); the driver's multi-GPU run uses RCCL with one rank per GPU
+        backend = os.environ.get("RWKV_BENCH_BACKEND", "nccl")
+        if os.environ.get("RWKV_BENCH_ONE_DEVICE") == "1":
+            local_rank = 0
+        kw = dict(device_id=torch.device("cuda", local_rank)) if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180), **kw)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)

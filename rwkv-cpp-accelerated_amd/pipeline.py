@@ -80,9 +80,14 @@ def run_pipeline(stage, dist, rank, world, first_tokens, n_steps, device=None):
     n_items = S * n_steps
     has_work = lambda r, t: 0 <= t - r < n_items
     picks = np.zeros((S, n_steps), dtype=np.int64) if rank == S - 1 else None
-    tok_recv = torch.zeros(1, dtype=torch.int64, device=device)
-    tok_send = torch.zeros(1, dtype=torch.int64, device=device)
-    x_send = torch.empty_like(stage.x)
+    # a backend that cannot move device tensors point to point (gloo: the single-GPU test of this very code path)
+    # gets the hop staged through host memory; RCCL moves stage.x directly
+    host_staging = bool(getattr(stage.x, "is_cuda", False)) and dist.get_backend() == "gloo"
+    cdev = "cpu" if host_staging else device
+    tok_recv = torch.zeros(1, dtype=torch.int64, device=cdev)
+    tok_send = torch.zeros(1, dtype=torch.int64, device=cdev)
+    x_send = torch.empty_like(stage.x, device=cdev)
+    x_recv = torch.empty_like(stage.x, device=cdev) if host_staging else stage.x
     for tick in range(n_items + S - 1):
         ops = []
         feedback = S <= tick < n_items
@@ -92,12 +97,14 @@ def run_pipeline(stage, dist, rank, world, first_tokens, n_steps, device=None):
         if rank == S - 1 and feedback:
             ops.append(dist.P2POp(dist.isend, tok_send, 0))
         if rank > 0 and has_work(rank, tick):
-            ops.append(dist.P2POp(dist.irecv, stage.x, rank - 1))
+            ops.append(dist.P2POp(dist.irecv, x_recv, rank - 1))
         if rank == 0 and feedback:
             ops.append(dist.P2POp(dist.irecv, tok_recv, S - 1))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+            if host_staging and rank > 0 and has_work(rank, tick):
+                stage.x.copy_(x_recv)
             if device is not None and str(device).startswith("cuda"):
                 torch.cuda.synchronize()                            # the engine runs on its own stream
         if not has_work(rank, tick):

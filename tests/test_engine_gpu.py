@@ -2,6 +2,7 @@
 seeded inputs.  Run on the MI355X box with `-m gpu`."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -266,3 +267,51 @@ def test_graph_replay_equals_eager_launches(eng_mod):
         assert np.array_equal(m.forward(tk)[: mf.VOCAB], e.forward(tk)[: mf.VOCAB])
     assert np.array_equal(m.decode_greedy(5, 40), e.decode_greedy(5, 40))
     m.close(); e.close()
+
+
+def _pipe_worker(rank, world, port, first_tokens, L, D, seed, steps, q):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from rwkv_cpp_accelerated_amd import pipeline
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    l0, l1 = pipeline.partition_layers(L, world, D)[rank]
+    st = pipeline.EngineStage(mf.synthetic_tensors(L, D, seed=seed), L, D, l0, l1, n_slots=world, device=0)
+    picks = pipeline.run_pipeline(st, dist, rank, world, first_tokens, steps, device="cuda:0")
+    if rank == world - 1:
+        q.put(picks)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipeline_processes_with_engine_stages(eng_mod, world):
+    """bench.py's N > 1 path end to end, minus RCCL: `world` processes, each an EngineStage on its layer range
+    (all on this box's one GPU), the residual hop through gloo.  Must equal single-context greedy decoding of
+    every stream."""
+    import socket
+    import torch.multiprocessing as mp
+    L, D, seed, steps = 6, 768, 77, 6
+    first = [11, 222, 3333][:world]
+    t = mf.synthetic_tensors(L, D, seed=seed)
+    m = eng_mod.RWKV(resident=True)
+    m.loadTensors(L, D, t)
+    want = np.zeros((world, steps), np.int64)
+    for k, tk in enumerate(first):
+        ids = []
+        m.reset_state()
+        cur = tk
+        for _ in range(steps):
+            cur = parity.argmax_ban0(m.forward(cur)[: mf.VOCAB]); ids.append(cur)
+        want[k] = ids
+    m.close()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, first, L, D, seed, steps, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = q.get(timeout=240)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert np.array_equal(got, want)
