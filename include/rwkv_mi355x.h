@@ -66,6 +66,10 @@ uint64_t rwkv_max_ctx(const rwkv_ctx *ctx);
  * tokens.  GPT mode: consecutive tokens of one sequence on state slot 0.  PARRALEL mode: one
  * step of n_tokens independent sequences on state slots 0..n_tokens-1.  Logits for every
  * position land in the device logits buffer ([n_tokens][50277] f32); state stays on the device.
+ * n_tokens == 1 runs the decode kernels (uint8 x fixed-point dot products on the VALU); n_tokens >= 2
+ * on a whole-model context with max_ctx > 1 runs chunks of up to 32 rows through mm8_seq on the int8
+ * matrix cores, reading every weight byte once per chunk (env RWKV_SEQ=0 at load time keeps the
+ * token-by-token path).  Both agree with the reference within its own tolerance; see DESIGN.md.
  * Synchronous on return (the reference ends with cudaDeviceSynchronize, rwkv.cu:590). */
 int rwkv_forward(rwkv_ctx *ctx, const uint64_t *tokens, uint64_t n_tokens, int mode);
 
