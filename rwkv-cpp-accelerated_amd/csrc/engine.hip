@@ -557,9 +557,10 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         s.par = par && state; s.state_par = state; s.slot_stride = (size_t)L * D; s.slot0 = (int)row0;
         for (int k = 0; k < 3; k++) s.img[k] = c->sq_img[k];
         s.rec = c->sq_rec; s.D = D; s.T = n;
-        if (nv == 3) k_seq_site<3><<<dim3(n), dim3(NT), 0, st>>>(s);
-        else if (nv == 2) k_seq_site<2><<<dim3(n), dim3(NT), 0, st>>>(s);
-        else k_seq_site<1><<<dim3(n), dim3(NT), 0, st>>>(s);
+        const bool two = D <= 8 * SEQ_SNT;   // quads per thread of the site workgroup: 2 up to D = 4096, else 3
+        if (nv == 3) { if (two) k_seq_site<3, 2><<<dim3(n), dim3(SEQ_SNT), 0, st>>>(s); else k_seq_site<3, 3><<<dim3(n), dim3(SEQ_SNT), 0, st>>>(s); }
+        else if (nv == 2) { if (two) k_seq_site<2, 2><<<dim3(n), dim3(SEQ_SNT), 0, st>>>(s); else k_seq_site<2, 3><<<dim3(n), dim3(SEQ_SNT), 0, st>>>(s); }
+        else { if (two) k_seq_site<1, 2><<<dim3(n), dim3(SEQ_SNT), 0, st>>>(s); else k_seq_site<1, 3><<<dim3(n), dim3(SEQ_SNT), 0, st>>>(s); }
     };
     static const int v012[5] = {0, 1, 2, 0, 0}, v0[5] = {0, 0, 0, 0, 0}, v00001[5] = {0, 0, 0, 0, 1};
     for (uint64_t l = 0; l < L; l++) {

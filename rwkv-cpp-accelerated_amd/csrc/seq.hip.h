@@ -127,78 +127,130 @@ struct SeqSiteArgs {
     int D, T;
 };
 
-constexpr int SEQ_NQ = 3;        // quads per thread: D <= 5120 -> 1280 quads over 512 threads
+constexpr int SEQ_SNT = 512;     // threads of a site workgroup (one workgroup per row)
+constexpr int SEQ_SNW = SEQ_SNT / 64;
 
-template <int NV>
-__global__ __launch_bounds__(NT) void k_seq_site(SeqSiteArgs a)
+// workgroup reductions for SEQ_SNT threads (kernels.hip.h's block_sum / block_max are sized for NT)
+template <int K>
+__device__ __forceinline__ void sblock_sum(double (&v)[K], double *red)
 {
-    __shared__ double red[RED_BYTES / 8];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[w * K + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < SEQ_SNW; i++) t += red[i * K + k];
+        v[k] = t;
+    }
+}
+template <int K>
+__device__ __forceinline__ void sblock_max(float (&v)[K], double *redd)
+{
+    float *red = reinterpret_cast<float *>(redd);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = wave_max(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[w * K + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < SEQ_SNW; i++) t = fmaxf(t, red[i * K + k]);
+        v[k] = t;
+    }
+}
+
+// NQ quads per thread: 2 for D <= 4096, 3 up to 6144.  Every input -- the two rows of x and all parameter
+// vectors -- is requested with 16-byte loads before the first reduction: one workgroup per row is latency
+// bound, and element-wise scalar loads of the ~11 parameter vectors cost 10 of its 22 us.
+template <int NV, int NQ>
+__global__ __launch_bounds__(SEQ_SNT) void k_seq_site(SeqSiteArgs a)
+{
+    __shared__ double red[SEQ_SNW * 4];
     __shared__ unsigned lds_sums[12];
     const int D = a.D, t = blockIdx.x, nqd = D >> 2;
     const bool shift = a.mix[0] != nullptr;
-    double xt[SEQ_NQ][4], xp[SEQ_NQ][4];
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool lnprev = shift && t > 0 && !a.par;   // the shift input is a LayerNorm output: of the previous row (GPT) or already stored (state)
+    const double *xprow = !shift ? a.x : a.par ? a.state_par + (size_t)(a.slot0 + t) * a.slot_stride : (t > 0 ? a.x + (size_t)(t - 1) * D : a.state);
+    double xt[NQ][4], xp[NQ][4], lw[NQ][4], lb[NQ][4], mk[NQ][NV][4];
+    f32x4 rr[NQ][NV], oo[NQ][NV];
 #pragma unroll
-    for (int i = 0; i < SEQ_NQ; i++) {
-        const int qd = threadIdx.x + i * NT;
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * SEQ_SNT, qc = qd < nqd ? qd : nqd - 1;
+        load_quad_f64(a.x + (size_t)t * D, qc, xt[i]);
+        load_quad_f64(xprow, qc, xp[i]);
+        load_quad_f64(a.lnw, qc, lw[i]);
+        load_quad_f64(a.lnb, qc, lb[i]);
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            xt[i][e] = 0.0; xp[i][e] = 0.0;
-            if (qd < nqd) {
-                const int j = qd * 4 + e;
-                xt[i][e] = a.x[(size_t)t * D + j];
-                s[0] += xt[i][e]; s[1] += xt[i][e] * xt[i][e];
-                if (shift) {
-                    if (a.par) xp[i][e] = a.state_par[(size_t)(a.slot0 + t) * a.slot_stride + j];
-                    else if (t > 0) { xp[i][e] = a.x[(size_t)(t - 1) * D + j]; s[2] += xp[i][e]; s[3] += xp[i][e] * xp[i][e]; }
-                    else xp[i][e] = a.state[j];
-                }
-            }
+        for (int m = 0; m < NV; m++) {
+            if (shift) load_quad_f64(a.mix[m], qc, mk[i][m]);
+            rr[i][m] = reinterpret_cast<const f32x4 *>(a.r[m])[qc];
+            oo[i][m] = reinterpret_cast<const f32x4 *>(a.o[m])[qc];
         }
     }
-    block_sum<4>(s, red + RED_STATS);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NQ; i++)
+        if ((int)(threadIdx.x + i * SEQ_SNT) < nqd)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                s[0] += xt[i][e]; s[1] += xt[i][e] * xt[i][e];
+                if (lnprev) { s[2] += xp[i][e]; s[3] += xp[i][e] * xp[i][e]; }
+            }
+    sblock_sum<4>(s, red);
     const double mean = s[0] / (double)D, rstd = 1.0 / sqrt((s[1] - s[0] * mean) / (double)(D - 1));
-    const bool lnprev = shift && t > 0 && !a.par;   // the shift input is a LayerNorm output: of the previous row (GPT) or already stored (state)
     const double meanp = s[2] / (double)D, rstdp = lnprev ? 1.0 / sqrt((s[3] - s[2] * meanp) / (double)(D - 1)) : 1.0;
 
-    float xr[NV][SEQ_NQ][4];
+    float xr[NV][NQ][4];
     double So[NV];
     float amax[NV];
 #pragma unroll
     for (int m = 0; m < NV; m++) { So[m] = 0.0; amax[m] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < SEQ_NQ; i++) {
-        const int qd = threadIdx.x + i * NT;
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * SEQ_SNT;
+        const bool real = qd < nqd;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int j = qd * 4 + e;
-            const bool real = qd < nqd;
-            const int jc = real ? j : 0;
-            const double xx = a.lnw[jc] * ((xt[i][e] - mean) * rstd) + a.lnb[jc];
+            const double xx = lw[i][e] * ((xt[i][e] - mean) * rstd) + lb[i][e];
             double xprev = xp[i][e];
-            if (lnprev) xprev = a.lnw[jc] * ((xp[i][e] - meanp) * rstdp) + a.lnb[jc];
+            if (lnprev) xprev = lw[i][e] * ((xp[i][e] - meanp) * rstdp) + lb[i][e];
             if (real && a.par) a.state_par[(size_t)(a.slot0 + t) * a.slot_stride + j] = xx;   // own slot: read above by this thread only
             else if (real && a.state_new && t == a.T - 1) a.state_new[j] = xx;          // mixatt / mixffn state write (:344,:385)
 #pragma unroll
             for (int m = 0; m < NV; m++) {
                 float f = (float)xx;
-                if (shift) { const double mk = a.mix[m][jc]; f = (float)(xx * mk + xprev * (1.0 - mk)); }   // :339-343,:377-384
-                const float v = real ? f * a.r[m][jc] : 0.f;
+                if (shift) f = (float)(xx * mk[i][m][e] + xprev * (1.0 - mk[i][m][e]));   // :339-343,:377-384
+                const float v = real ? f * rr[i][m][e] : 0.f;
                 xr[m][i][e] = v;
-                if (real) { So[m] += (double)(f * a.o[m][jc]); amax[m] = fmaxf(amax[m], fabsf(v)); }
+                if (real) { So[m] += (double)(f * oo[i][m][e]); amax[m] = fmaxf(amax[m], fabsf(v)); }
             }
         }
     }
-    block_sum<NV>(So, red + RED_OFFS);
-    block_max<NV>(amax, red + RED_MAX);
+    sblock_sum<NV>(So, red);
+    sblock_max<NV>(amax, red);
     unsigned ls[NV][3];
 #pragma unroll
     for (int m = 0; m < NV; m++) {
         ls[m][0] = ls[m][1] = ls[m][2] = 0u;
         const float inv_s = inv_scale(amax[m]);
 #pragma unroll
-        for (int i = 0; i < SEQ_NQ; i++) {
-            const int qd = threadIdx.x + i * NT;
+        for (int i = 0; i < NQ; i++) {
+            const int qd = threadIdx.x + i * SEQ_SNT;
             if (qd < nqd) seq_store_quad(a.img[m], qd, t, xr[m][i], inv_s, ls[m]);
         }
     }
@@ -222,6 +274,16 @@ __global__ __launch_bounds__(NT) void k_seq_stage(SeqStageArgs a)
     __shared__ double red[RED_BYTES / 8];
     __shared__ unsigned lds_sums[12];
     const int K = a.K, t = blockIdx.x, nqd = K >> 2;
+    // all inputs of the thread's quads are requested first, 16 bytes at a time (one workgroup per row is latency bound)
+    f32x4 sv[SEQ_NQS], rv[SEQ_NQS], ov[SEQ_NQS];
+#pragma unroll
+    for (int i = 0; i < SEQ_NQS; i++) {
+        const int qd = threadIdx.x + i * NT, qc = qd < nqd ? qd : nqd - 1;
+        if (KIND == 0) sv[i] = reinterpret_cast<const f32x4 *>(a.src + (size_t)t * K)[qc];
+        else __builtin_memcpy(&sv[i], a.src + (size_t)t * (K / 4 * 5) + (size_t)qc * 5, 16);   // k0..k3 of channel qc: 4-byte aligned only
+        rv[i] = reinterpret_cast<const f32x4 *>(a.r)[qc];
+        ov[i] = reinterpret_cast<const f32x4 *>(a.o)[qc];
+    }
     float xr[SEQ_NQS][4];
     double So[1] = {0.0};
     float amax[1] = {0.f};
@@ -232,16 +294,10 @@ __global__ __launch_bounds__(NT) void k_seq_stage(SeqStageArgs a)
         for (int e = 0; e < 4; e++) {
             xr[i][e] = 0.f;
             if (qd < nqd) {
-                const int kk = qd * 4 + e;
-                float f;
-                if (KIND == 0) f = a.src[(size_t)t * K + kk];
-                else {
-                    const float v = a.src[(size_t)t * (K / 4 * 5) + (kk >> 2) * 5 + (kk & 3)];
-                    f = v * (float)(v > 0.f);
-                    f = f * f;
-                }
-                xr[i][e] = f * a.r[kk];
-                So[0] += (double)(f * a.o[kk]);
+                float f = sv[i][e];
+                if (KIND == 1) { f = f * (float)(f > 0.f); f = f * f; }     // relu(k)^2, rwkv.cu:189-190
+                xr[i][e] = f * rv[i][e];
+                So[0] += (double)(f * ov[i][e]);
                 amax[0] = fmaxf(amax[0], fabsf(xr[i][e]));
             }
         }
