@@ -784,6 +784,11 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
 
     tl_stamp(a.tl, 0);
+    // the epilogue's per-channel inputs (state, decay, att_out scale / offset) are requested now: asked for after
+    // the last row they would add a full cold-miss latency to the kernel's tail
+    const int ic = g0 + ((int)threadIdx.x < g1 - g0 ? (int)threadIdx.x : 0);
+    const double e_aa = a.saa[so + ic], e_bb = a.sbb[so + ic], e_uw = a.uw[ic], e_ew = a.ew[ic];
+    const float e_ra = a.r_att[ic], e_oa = a.o_att[ic];
     u32x4 w[3][S];
     int g = g0 + wave;
     unsigned *gctr = group_counter(red);
@@ -818,18 +823,18 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     if ((int)threadIdx.x < g1 - g0) {
         const int i = g0 + threadIdx.x;
         const float k = stash[threadIdx.x * 3 + 0], v = stash[threadIdx.x * 3 + 1], r = stash[threadIdx.x * 3 + 2];
-        const double aa = a.saa[so + i], bb = a.sbb[so + i];
+        const double aa = e_aa, bb = e_bb;
         const double vv = (double)v;
-        const double e1 = exp(a.uw[i] + (double)k);
+        const double e1 = exp(e_uw + (double)k);
         double y = (aa + e1 * vv) / (bb + e1);
         y = (1.0 / (1.0 + (double)expf(-r))) * y;       // rwkv.cu:250: exp of a float argument
-        const double ek = exp((double)k), ew = a.ew[i];
+        const double ek = exp((double)k), ew = e_ew;
         a.saa[so + i] = (aa + ek * vv) * ew;
         a.sbb[so + i] = (bb + ek) * ew;
         const float yf = (float)y;                       // att_out GEMV casts its input to f32 (rwkv.cu:290)
-        const float ys = yf * a.r_att[i];
+        const float ys = yf * e_ra;
         a.ybuf[i] = ys;
-        part[0] = (double)(yf * a.o_att[i]);
+        part[0] = (double)(yf * e_oa);
         pmax[0] = fabsf(ys);
     }
     block_sum<1>(part, red + RED_PART);
@@ -956,6 +961,9 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
     tl_stamp(a.tl, 0);
+    // epilogue item of this thread (thread t finishes stash[t]): its ffn_v scale / offset are requested now (see k_att)
+    const int eq = threadIdx.x % 5, ei = g0 + ((int)threadIdx.x < 5 * (g1 - g0) ? (int)threadIdx.x / 5 : 0);
+    const float e_r = a.r_fv[4 * ei + (eq < 4 ? eq : 0)], e_o = a.o_fv[4 * ei + (eq < 4 ? eq : 0)];
 
     u32x4 w[5][S];
     int g = g0 + wave;
@@ -990,9 +998,10 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
             float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
             h = h * h;
             const int kk = 4 * i + q;
-            const float hs = h * a.r_fv[kk];
+            const bool pre = t == (int)threadIdx.x;                      // the first (normally only) trip uses the prefetched pair
+            const float hs = h * (pre ? e_r : a.r_fv[kk]);
             a.hbuf[kk] = hs;
-            part[0] += (double)(h * a.o_fv[kk]);
+            part[0] += (double)(h * (pre ? e_o : a.o_fv[kk]));
             pmax[0] = fmaxf(pmax[0], fabsf(hs));
         } else {
             a.rgate[i] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
