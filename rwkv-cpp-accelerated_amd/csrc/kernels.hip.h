@@ -448,7 +448,7 @@ __device__ __forceinline__ void site_tuple_load(const SiteDyn &dy, SiteTuple &t)
 // remaining waves of the workgroup need not take part.
 template <int NV, int NWR = NW>
 __device__ __forceinline__ void site_reduce(const SiteStatic &st, const SiteDyn &dy, const SiteTuple &t, int D, double *red, SiteRed<NV> &out,
-                                            unsigned long long *tl = nullptr, unsigned *spin = nullptr)
+                                            const double (&tc)[NV], const float (&mc)[NV], unsigned long long *tl = nullptr, unsigned *spin = nullptr)
 {
     float *redf = reinterpret_cast<float *>(red + NW * 8);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -499,8 +499,8 @@ __device__ __forceinline__ void site_reduce(const SiteStatic &st, const SiteDyn 
     const double mrs = out.mean * out.rstd;
 #pragma unroll
     for (int m = 0; m < NV; m++) {
-        out.S[m] = out.rstd * d[2 + m] - mrs * st.TC[m] + d[5 + m];
-        out.amax[m] = (st.maxC[m] * (float)(((double)f[0] + fabs(out.mean)) * out.rstd) + f[1 + m]) * 1.0001f;
+        out.S[m] = out.rstd * d[2 + m] - mrs * tc[m] + d[5 + m];
+        out.amax[m] = (mc[m] * (float)(((double)f[0] + fabs(out.mean)) * out.rstd) + f[1 + m]) * 1.0001f;
     }
 }
 __device__ __forceinline__ void load_quad_f64(const double *p, int qd, double (&out)[4])
@@ -591,6 +591,12 @@ __device__ __forceinline__ void site_open(const SiteStatic &st, const SiteDyn &d
         tl_stamp(tl, 2);
         __syncthreads();   // staged
     } else {
+        // the site's static scalars are read here, not where they are used: behind the reduction's barrier the
+        // compiler may not hoist them, and a cold scalar load there sits on the prologue's critical path
+        double tc[NV];
+        float mc[NV];
+#pragma unroll
+        for (int m = 0; m < NV; m++) { tc[m] = st.TC[m]; mc[m] = st.maxC[m]; }
         SiteTuple tup;
         site_tuple_load(dy, tup);
         double xl[NQP][4];
@@ -609,12 +615,12 @@ __device__ __forceinline__ void site_open(const SiteStatic &st, const SiteDyn &d
         if (SPLIT) {
             if (threadIdx.x == 0) *spin = 0u;
             __syncthreads();   // order (see the loader role)
-            site_reduce<NV, NWP>(st, dy, tup, D, red, sr, tl, spin);
+            site_reduce<NV, NWP>(st, dy, tup, D, red, sr, tc, mc, tl, spin);
         } else {
             // a small pre-issue of the weight stream; more would block this wave's prologue
             group_load<R, S, 0, pre_steps<S>()>(w, wb, stride, chunks, lane);
             tl_stamp(tl, 2);
-            site_reduce<NV, NWP>(st, dy, tup, D, red, sr, tl);
+            site_reduce<NV, NWP>(st, dy, tup, D, red, sr, tc, mc, tl);
         }
         if (publish_stats && blockIdx.x == 0 && threadIdx.x == 0) { dy.lnstat[0] = sr.mean; dy.lnstat[1] = sr.rstd; }
         tl_stamp(tl, 4);
