@@ -1126,6 +1126,7 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
     const int G = (V + R - 1) / R;
     const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
+    float *lg = a.logits + (size_t)a.ctl->out_row * V;   // read at entry: behind the prologue's barriers it is a cold scalar load
 
     u32x4 w[R][S];
     int g = g0 + wave;
@@ -1141,7 +1142,6 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
     site_open<1, R, S, (RWKV_SPLIT & 16) != 0>(a.st, a.dy, a.x, D, red, xq, w, wb, (size_t)D, sr, false, nullptr);
     const float Sf = (float)sr.S[0];
     const double sc = scale_of(sr.amax[0]);
-    float *lg = a.logits + (size_t)a.ctl->out_row * V;
 
     float best = -INFINITY;
     unsigned besti = 0xffffffffu;
