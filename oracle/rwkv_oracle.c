@@ -10,7 +10,7 @@
  * Parity pin: the reference ships no golden vectors, so this
  * restatement is pinned against the reference's own kernel file compiled
  * unmodified with hipcc (oracle/_ref, see oracle/Makefile) -- live on the GPU
- * box (tests/test_ref_parity.py) and through the fixtures that run produced
+ * box (tests/test_ref_parity_gpu.py) and through the fixtures that run produced
  * (tests/golden/, generator: tools/make_golden.py).
  *
  * Each function cites the reference lines it restates.  Where the reference's
