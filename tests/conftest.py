@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm bundles its own libamdhip64; librwkv_mi355x.so links the system one (same SONAME).  Whichever is
+# loaded first serves the whole process, and torch's device initialisation only works on its own copy -- so
+# torch is imported before any test can load the engine, whatever subset of files is collected.
+try:
+    import torch  # noqa: F401
+except Exception:  # the CPU suite does not need it everywhere
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
