@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--ref-steps", type=int, default=1024, help="greedy steps of the reference's own kernel (oracle/_ref/libref.so) "
+                    "timed on this GPU and used as the parity gate of the engine (north_star: 1024); 0 = skip")
+    ap.add_argument("--ref-seconds", type=float, default=150.0, help="wall-time bound of the reference-kernel leg")
     ap.add_argument("--profile-reps", type=int, default=16)
     ap.add_argument("--prefill-chunks", type=int, default=4, help="32-token prompt chunks timed for the prefill report (0 = skip)")
     ap.add_argument("--parallel", choices=["pipeline", "replicas"], default=os.environ.get("RWKV_BENCH_PARALLEL", "pipeline"),
@@ -150,7 +153,8 @@ def main():
                 traffic=None,
                 method="algorithmic uint8 weight bytes of one launch / average launch duration; duration = one hipEvent pair "
                        "around a batch of back-to-back launches of the kernel (all layers x reps) on the engine stream, "
-                       "right after the timed region")
+                       "right after the timed region; `traffic` is NOT a counter of this run: it is the committed figure of the "
+                       "separate rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction) in profiles/hbm_traffic.json")
     traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # filled from rocprofv3 --pmc passes (see profiles/)
     if os.path.exists(traffic_file):
         try:
@@ -215,6 +219,10 @@ def main():
         line["batched_decode"] = dict(streams=len(prompt), ms_per_step=round(dtb * 1e3, 3), aggregate_tokens_per_s=round(len(prompt) / dtb, 1),
                                       note="MODE PARRALEL: one token of each of 32 independent sequences per step, weights read once per step")
 
+    # ---- the reference's OWN kernel on this GPU, same tensors, same prompt: parity gate + baseline ----
+    if rank == 0 and args.ref_steps > 0:
+        line.update(ref_kernel_leg(mf, tensors, L, D, prompt, m, args.ref_steps, args.ref_seconds, B_tok))
+
     # ---- CPU baseline: the oracle (CPU restatement of rwkv.cu:493-593) on this box's host cores ----
     if rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(pkg, mf, tensors, L, D, prompt, args.cpu_seconds, engine_model=m)
@@ -270,6 +278,35 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
             per_stream_tokens_per_s=round(args.steps / dt, 2))), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def ref_kernel_leg(mf, tensors, L, D, prompt, engine_model, steps, budget_s, B_tok):
+    """rank 0, N=1: the reference's own kernel file (rwkv.cu:493-593, hipcc'd unmodified into oracle/_ref/libref.so --
+    test infrastructure, built in the authoring container) decodes `steps` greedy tokens after the same 32-token prompt
+    on the same device-resident tensors; the engine is teacher-forced with the reference's ids and its logits are checked
+    at every step (north_star: within 1e-3 relative, identical greedy ids).  The reference loop is timed the way its own
+    callers run it (RWKV::forward: state upload, kernels, state + logits download, rwkv.h:339-376)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import refgate
+    if not os.path.exists(oracle_lib.REF_SO):
+        return dict(ref_kernel_baseline=None, parity_vs_reference_kernel=dict(skipped="oracle/_ref/libref.so not built"))
+    ref = oracle_lib.Ref()
+    rm = refgate.ref_model_from_torch(ref, mf, tensors, L, D, 1)
+    was = engine_model.resident
+    engine_model.resident = True
+    g = refgate.run_gate(rm, engine_model, mf, prompt, steps, budget_s=budget_s)
+    engine_model.resident = was
+    tps = g["steps"] / g["ref_seconds"]
+    return dict(
+        ref_kernel_baseline=dict(tokens_per_s=round(tps, 2), GBps=round(B_tok * tps / 1e9, 1), frac_of_8TBps=round(B_tok * tps / 1e9 / HBM_PEAK_GBPS, 4),
+                                 steps=g["steps"], kind="reference",
+                                 note="reference include/rwkv/cuda/rwkv.cu built unmodified with hipcc for gfx950, driven through the reference's "
+                                      "RWKV::forward (host-authoritative state up/down + logits down per token), same tensors, same prompt"),
+        parity_vs_reference_kernel=dict(steps=g["steps"], max_rel=float(f"{g['max_rel']:.3e}"), ids_identical=g["ids_identical"],
+                                        first_divergence=g["first_divergence"], steps_outside_tolerance=g["steps_outside_tolerance"],
+                                        tolerance=1e-3, note="engine teacher-forced with the reference kernel's greedy ids; logits compared at every step "
+                                                             "(max|d| <= 1e-3 max|ref| and |d| <= 1e-3|ref| + 1e-3 rms)"))
 
 
 def cpu_baseline(pkg, mf, tensors, L, D, prompt, budget_s, engine_model=None):

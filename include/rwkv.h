@@ -12,9 +12,14 @@
 //   * `residentState = true` keeps the state on the device between calls (the reference re-uploads
 //     and re-downloads 5 x L x D doubles around every forward, rwkv.h:353,372); the default keeps
 //     the reference's host-authoritative semantics.
-//   * the tokenizer (GPT-NeoX BPE) is outside this engine's scope: loadContext() takes token ids;
-//     the std::string overload exists when a `GPT2Tokenizer` with encode() is supplied by the
-//     application (define RWKV_HAVE_TOKENIZER before including this header).
+//   * like the reference's umbrella include/rwkv.h:1-3 this header also brings in the sampler (`typical`,
+//     include/rwkv_sampler.h) and the tokenizer.  The tokenizer (GPT-NeoX BPE) is outside this engine's
+//     scope and is NOT re-implemented: when the reference's own include/rwkv/tokenizer/tokenizer.h is on
+//     the include path (-I<reference>/include) it is pulled in as it is and `RWKV::loadTokenizer` /
+//     `loadContext(std::string)` (rwkv.h:312-319,395-413) forward to it; without it those two members do
+//     not exist and loadContext() takes token ids.  Define RWKV_NO_TOKENIZER to keep it out.
+//   * decodeGreedy()/decodeTypical() run on the device state.  In the default host-authoritative mode they
+//     upload `state` first and download it afterwards, so a following forward() continues the sequence.
 #ifndef RWKV_H
 #define RWKV_H
 
@@ -25,6 +30,13 @@
 #include <vector>
 
 #include "rwkv_mi355x.h"
+#include "rwkv_sampler.h"
+#if !defined(RWKV_NO_TOKENIZER) && !defined(RWKV_HAVE_TOKENIZER) && defined(__has_include)
+#if __has_include("rwkv/tokenizer/tokenizer.h")
+#include "rwkv/tokenizer/tokenizer.h"   // the reference's GPT2Tokenizer, compiled from where it lies
+#define RWKV_HAVE_TOKENIZER 1
+#endif
+#endif
 
 enum MODE { PARRALEL, GPT };   // reference enums/enum.h:2-5
 
@@ -128,7 +140,7 @@ private:
     }
 };
 
-class GPT2Tokenizer;   // supplied by the application (see header comment)
+class GPT2Tokenizer;   // the reference's tokenizer (see header comment); only ever used through a pointer here
 
 // reference rwkv.h:245-429
 class RWKV
@@ -212,7 +224,24 @@ public:
         return initial.back();
     }
 #ifdef RWKV_HAVE_TOKENIZER
-    long long loadContext(std::string input, bool progress = false) { return loadContext(tokenizer->encode(input), progress); }
+    // reference rwkv.h:312-319
+    void loadTokenizer(std::string vocabPath)
+    {
+        auto _tokenizer = GPT2Tokenizer::load(vocabPath + "/vocab.json", vocabPath + "/merges.txt");
+        if (!_tokenizer.has_value()) {
+            std::cerr << "Failed to load tokenizer" << std::endl;
+            return;
+        }
+        tokenizer = new GPT2Tokenizer(_tokenizer.value());
+    }
+    // reference rwkv.h:395-413 (prints "<first id>:token" like the reference does)
+    long long loadContext(std::string input, bool progress = false)
+    {
+        if (!tokenizer) throw std::runtime_error("tokenizer not loaded");
+        const std::vector<long long> initial = widen(tokenizer->encode(input));
+        if (!initial.empty()) std::cout << initial[0] << ":token";
+        return loadContext(initial, progress);
+    }
 #endif
 
     // engine extensions -------------------------------------------------------------------
@@ -224,25 +253,29 @@ public:
     {
         if (!ready) throw std::runtime_error("RWKV not loaded");
         std::vector<uint64_t> ids(n);
+        if (!residentState) pushState();      // host state is authoritative: continue from it ...
         rwkv_detail::check(rwkv_decode_greedy(ctx_, first, n, ids.data()));
+        if (!residentState) pullState();      // ... and leave it where the generated tokens ended
         return std::vector<unsigned long long>(ids.begin(), ids.end());
     }
     // typical sampling on the device from the logits of the last forward (no 201 KB download, no host sort);
     // u in [0, 1) is the caller's uniform, the draw is the inverse CDF in token order (rwkv_sampler.h typical_u)
-    int sampleTypical(float temp, float tau, double u, bool ban0 = false, unsigned long long row = 0)
+    int sampleTypical(float temp, float tau, double u, bool ban0 = false, unsigned long long row = 0, bool recipe = RWKV_TYPICAL_RECIPE != 0)
     {
         if (!ready) throw std::runtime_error("RWKV not loaded");
         uint64_t tok = 0;
-        rwkv_detail::check(rwkv_sample_typical(ctx_, row, temp, tau, u, ban0 ? 1 : 0, &tok));
+        rwkv_detail::check(rwkv_sample_typical(ctx_, row, temp, tau, u, (ban0 ? RWKV_SAMPLE_BAN0 : 0) | (recipe ? RWKV_SAMPLE_RECIPE : 0), &tok));
         return (int)tok;
     }
     // device-side sampled continuation: storygen's loop (examples/storygen/storygen.cpp:63-69) without host round trips
     std::vector<unsigned long long> decodeTypical(unsigned long long first, unsigned long long n, float temp = 0.9f, float tau = 0.8f,
-                                                  unsigned long long seed = 0)
+                                                  unsigned long long seed = 0, bool recipe = RWKV_TYPICAL_RECIPE != 0)
     {
         if (!ready) throw std::runtime_error("RWKV not loaded");
         std::vector<uint64_t> ids(n);
-        rwkv_detail::check(rwkv_decode_typical(ctx_, first, n, temp, tau, seed, ids.data()));
+        if (!residentState) pushState();
+        rwkv_detail::check(rwkv_decode_typical(ctx_, first, n, temp, tau, seed, recipe ? RWKV_SAMPLE_RECIPE : 0, ids.data()));
+        if (!residentState) pullState();
         return std::vector<unsigned long long>(ids.begin(), ids.end());
     }
     rwkv_ctx *handle() { return ctx_; }
@@ -257,6 +290,7 @@ public:
 private:
     rwkv_ctx *ctx_ = nullptr;
     int device_ = 0;
+    template <typename T> static std::vector<long long> widen(const std::vector<T> &v) { return std::vector<long long>(v.begin(), v.end()); }
     void ensure_ctx()
     {
         if (!ctx_) rwkv_detail::check(rwkv_create(&ctx_, device_));

@@ -92,18 +92,24 @@ int rwkv_reset_state(rwkv_ctx *ctx);
  * the LAST step remain in the device logits buffer (row 0). */
 int rwkv_decode_greedy(rwkv_ctx *ctx, uint64_t first_token, uint64_t n_tokens, uint64_t *out_tokens);
 
-/* Typical sampling on the device (reference include/rwkv/sampler/typical.h:20-58: softmax, entropy,
- * |-log p - H| ordering, smallest prefix with cumulative probability >= tau, p^(1/temp), draw) from the
- * logits row `row` of the LAST forward, without downloading them.  The draw is the inverse CDF in token
- * order for the caller's uniform u in [0, 1) (include/rwkv_sampler.h typical_u() is the same draw on
- * the host).  ban0 != 0 first sets logit 0 to -99 as storygen does (examples/storygen/storygen.cpp:66). */
-int rwkv_sample_typical(rwkv_ctx *ctx, uint64_t row, float temp, float tau, double u, int ban0, uint64_t *token);
+/* The reference's sampler typical() (include/rwkv/sampler/typical.h:20-58) on the device, from the logits row
+ * `row` of the LAST forward, without downloading them.  The draw is the inverse CDF in token order for the
+ * caller's uniform u in [0, 1) (include/rwkv_sampler.h typical_u() is the same draw on the host).
+ * Default = what typical.h COMPUTES (pinned by tests/test_sampler_ref_cpu.py against 20 000 draws of the
+ * reference's own function per case): a draw from softmax(logits)^n with n = uint8(1/temp) -- its typical-set cut
+ * at tau assigns into a temporary and has no effect (typical.h:50) and nc::power takes an integer exponent
+ * (typical.h:52); n = 0 (temp > 1) is the uniform distribution.  RWKV_SAMPLE_RECIPE instead applies the recipe its
+ * header comment documents (entropy, |-log p - H| ordering, smallest prefix with cumulative probability >= tau,
+ * p^(1/temp)).  RWKV_SAMPLE_BAN0 first sets logit 0 to -99 as storygen does (examples/storygen/storygen.cpp:66). */
+#define RWKV_SAMPLE_BAN0 1
+#define RWKV_SAMPLE_RECIPE 2
+int rwkv_sample_typical(rwkv_ctx *ctx, uint64_t row, float temp, float tau, double u, int flags, uint64_t *token);
 
-/* Device-side sampled continuation: storygen's loop (examples/storygen/storygen.cpp:63-69) with the
- * sampler above in place of the host typical(); u of step k = uniform(splitmix64(seed + k)).  Same
- * contract as rwkv_decode_greedy otherwise. */
+/* Device-side sampled continuation: storygen's loop (examples/storygen/storygen.cpp:63-69: forward, out[0] = -99,
+ * typical) with the sampler above in place of the host typical(); u of step k = uniform(splitmix64(seed + k));
+ * flags: RWKV_SAMPLE_RECIPE (logit 0 is always banned here).  Same contract as rwkv_decode_greedy otherwise. */
 int rwkv_decode_typical(rwkv_ctx *ctx, uint64_t first_token, uint64_t n_tokens, float temp, float tau,
-                        uint64_t seed, uint64_t *out_tokens);
+                        uint64_t seed, int flags, uint64_t *out_tokens);
 
 /* ---- layer pipeline (no reference counterpart: the reference is single-device) ----
  * A context may own a contiguous layer range [l0, l1) of the model: call rwkv_set_layer_range()

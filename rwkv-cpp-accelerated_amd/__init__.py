@@ -5,11 +5,13 @@ This Python package only holds what the hot path needs on the host side:
   build      -- compile the HIP extension (+ the pybind module) for gfx950
   modelfile  -- the converter's model.bin format + seeded synthetic models
   engine     -- ctypes binding and a mirror of the reference's `RWKV` / `RWKVState` classes
-  binding    -- the reference pybind module surface (`rwkv` module functions, ModelWrapper)
+  converter  -- .pth / state-dict -> model.bin (numpy only)
+  pipeline   -- layer pipeline across the GPUs of one node
+(the reference's pybind module `rwkv` is csrc/pybind_module.cpp, built next to the engine)
 
 The directory name has a hyphen (it mirrors the reference repo's name); import it through the
 `rwkv_cpp_accelerated_amd` shim at the repository root.
 """
 from . import build, modelfile  # noqa: F401
 
-__all__ = ["build", "modelfile", "engine", "binding"]
+__all__ = ["build", "modelfile", "engine", "converter", "pipeline"]

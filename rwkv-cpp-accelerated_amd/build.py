@@ -11,13 +11,41 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 ARCH = "gfx950"
+ENGINE_LIBS = []   # extra link flags of librwkv_mi355x.so
 
 
-def _stale(target: str, sources) -> bool:
+def _digest(sources, extra="") -> str:
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for s in sources:
+        if os.path.exists(s):
+            h.update(s.encode()[-64:])
+            with open(s, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target: str, sources, extra="") -> bool:
+    """content-based: `<target>.stamp` holds the digest of the sources the target was built from (mtimes do not survive
+    the copy to the GPU box, and a rebuild there would lose what only the authoring container can compile in)"""
     if not os.path.exists(target):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+    stamp = target + ".stamp"
+    if not os.path.exists(stamp):
+        t = os.path.getmtime(target)
+        return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+    with open(stamp) as f:
+        return f.read().strip() != _digest(sources, extra)
+
+
+def _stamp(target: str, sources, extra=""):
+    with open(target + ".stamp", "w") as f:
+        f.write(_digest(sources, extra))
+
+
+def reference_root():
+    r = os.environ.get("RWKV_REFERENCE", "/root/reference")
+    return r if os.path.isdir(os.path.join(r, "include", "rwkv")) else None
 
 
 def _run(cmd, cwd=None):
@@ -35,7 +63,8 @@ def build_engine(force: bool = False) -> str:
             os.path.join(ROOT, "include", "rwkv_mi355x.h")]
     if force or _stale(out, srcs):
         _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-Wno-unused-result", os.path.join(CSRC, "engine.hip"), "-o", out])
+              "-Wno-unused-result", os.path.join(CSRC, "engine.hip"), "-o", out] + ENGINE_LIBS)
+        _stamp(out, srcs)
     return out
 
 
@@ -50,11 +79,17 @@ def build_pybind(force: bool = False):
     import pybind11
     ext = sysconfig.get_config_var("EXT_SUFFIX")
     out = os.path.join(CSRC, "rwkv" + ext)
-    hdrs = [os.path.join(ROOT, "include", f) for f in ("rwkv.h", "rwkv_mi355x.h")]
-    if force or _stale(out, [src] + hdrs):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
-              "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src, "-o", out,
+    hdrs = [os.path.join(ROOT, "include", f) for f in ("rwkv.h", "rwkv_mi355x.h", "rwkv_sampler.h")]
+    # with the reference's include directory on the path include/rwkv.h pulls in the reference's own tokenizer and the
+    # module gains initTokenizer / tokenizerEncode / tokenizerDecode; a box without the reference keeps the module it was
+    # shipped (a rebuild there would silently drop the three functions)
+    ref = reference_root()
+    if force or (_stale(out, [src] + hdrs) and (ref or not os.path.exists(out))):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + os.path.join(ROOT, "include")] +
+             (["-I" + os.path.join(ref, "include")] if ref else []) +
+             ["-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src, "-o", out,
               "-L" + CSRC, "-lrwkv_mi355x", "-Wl,-rpath,$ORIGIN"])
+        _stamp(out, [src] + hdrs)
     return out
 
 
@@ -64,11 +99,14 @@ def build_oracle(force: bool = False):
     so = os.path.join(odir, "librwkv_oracle.so")
     if force or _stale(so, [os.path.join(odir, "rwkv_oracle.c")]):
         _run(["make", "-C", odir, "-B", "librwkv_oracle.so"])
-    ref_root = os.environ.get("RWKV_REFERENCE", "/root/reference")
+    ref_root = reference_root()
     ref_so = os.path.join(odir, "_ref", "libref.so")
-    if os.path.isdir(os.path.join(ref_root, "include", "rwkv")):
+    if ref_root:
         if force or _stale(ref_so, [os.path.join(odir, "ref_driver.cpp")]):
             _run(["make", "-C", odir, "ref", f"REF={ref_root}"])
+        # the reference's sampler and the reference's own caller (storygen) built against the drop-in: checkers / evidence
+        # that only the authoring container can compile (they read /root/reference at BUILD time, never at run time)
+        _run(["make", "-C", odir, "typical", "storygen", "storygen_l2", f"REF={ref_root}", f"ROOT={ROOT}"])
     return so, (ref_so if os.path.exists(ref_so) else None)
 
 

@@ -347,6 +347,11 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         return fail(RWKV_E_ARG, "unsupported model shape n_layers=%llu n_embed=%llu (n_embed must be a multiple of 16, <= 5120)",
                     (unsigned long long)L, (unsigned long long)D);
     if (max_ctx == 0) max_ctx = 1;
+    // k_att / k_ffn_rk finish the channels a workgroup owns with one thread per channel (k_att) after the last row:
+    // a grid so small that a workgroup owns more than NT channels would silently skip some
+    if ((D + (uint64_t)c->grid - 1) / (uint64_t)c->grid > (uint64_t)NT)
+        return fail(RWKV_E_ARG, "grid of %d workgroups is too small for n_embed=%llu (needs >= %llu; RWKV_GRID)", c->grid,
+                    (unsigned long long)D, (unsigned long long)((D + NT - 1) / NT));
     HIPCHK(hipSetDevice(c->device));
     c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
     if (c->l1 == UINT64_MAX) c->l1 = L;
@@ -486,6 +491,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_ctl), sizeof(Ctl) * max_ctx, hipHostMallocDefault));
     c->gen_cap = 1u << 16;
     if ((rc = dalloc(c, &c->gen, (size_t)c->gen_cap))) return rc;
+    HIPCHK(hipMemsetAsync(c->gen, 0, (size_t)c->gen_cap * sizeof(unsigned long long), c->stream));
     if ((rc = dalloc(c, &c->pick, 1))) return rc;
     if ((rc = dalloc(c, &c->ts_part, (size_t)TS_G * 3))) return rc;
     if ((rc = dalloc(c, &c->ts_p, (size_t)TS_NT * TS_PER))) return rc;
@@ -769,6 +775,7 @@ int rwkv_decode_greedy(rwkv_ctx *c, uint64_t first_token, uint64_t n, uint64_t *
 {
     if (!c || !out_tokens) return fail(RWKV_E_ARG, "NULL argument");
     if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (c->l0 != 0 || c->l1 != c->L) return fail(RWKV_E_STATE, "needs a whole-model context (a pipeline stage has no embedding / head of its own)");
     if (first_token >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
     if (n == 0 || n > c->gen_cap) return fail(RWKV_E_ARG, "n_tokens must be in 1..%u", c->gen_cap);
     HIPCHK(hipSetDevice(c->device));
@@ -784,9 +791,15 @@ int rwkv_decode_greedy(rwkv_ctx *c, uint64_t first_token, uint64_t n, uint64_t *
 }
 
 namespace {
-int launch_typical(rwkv_ctx *c, int row, float temp, float tau, double u, uint64_t seed, bool use_seed, bool ban0, bool feedback)
+int launch_typical(rwkv_ctx *c, int row, float temp, float tau, double u, uint64_t seed, bool use_seed, int flags, bool feedback)
 {
+    const bool ban0 = (flags & RWKV_SAMPLE_BAN0) != 0;
     TypicalArgs a;
+    // default: what typical.h computes -- no cut (typical.h:50 assigns into a temporary), integer exponent
+    // uint8(1/temp) (nc::power, typical.h:52); RWKV_SAMPLE_RECIPE: the documented recipe
+    a.recipe = (flags & RWKV_SAMPLE_RECIPE) ? 1 : 0;
+    if (a.recipe) a.expo = temp == 1.0f ? 1.0 : 1.0 / (double)temp;
+    else { const double e = 1.0 / (double)temp; a.expo = temp == 1.0f ? 1.0 : (e >= 255.0 ? 255.0 : (double)(unsigned char)e); }
     a.logits = c->logits; a.row = row; a.ctl = c->ctl; a.gen = c->gen; a.gen_cap = c->gen_cap;
     a.temp = temp; a.tau = tau; a.u = u; a.seed = seed; a.use_seed = use_seed ? 1 : 0; a.ban0 = ban0 ? 1 : 0;
     a.feedback = feedback ? 1 : 0; a.pick = c->pick; a.part = c->ts_part; a.p = c->ts_p; a.pw = c->ts_pw; a.key = c->ts_key;
@@ -798,7 +811,7 @@ int launch_typical(rwkv_ctx *c, int row, float temp, float tau, double u, uint64
 }
 } // namespace
 
-int rwkv_sample_typical(rwkv_ctx *c, uint64_t row, float temp, float tau, double u, int ban0, uint64_t *token)
+int rwkv_sample_typical(rwkv_ctx *c, uint64_t row, float temp, float tau, double u, int flags, uint64_t *token)
 {
     if (!c || !token) return fail(RWKV_E_ARG, "NULL argument");
     if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
@@ -806,14 +819,14 @@ int rwkv_sample_typical(rwkv_ctx *c, uint64_t row, float temp, float tau, double
     if (row >= c->maxT) return fail(RWKV_E_ARG, "logits row %llu out of range (max context %llu)", (unsigned long long)row, (unsigned long long)c->maxT);
     if (!(temp > 0.f) || !(u >= 0.0 && u < 1.0)) return fail(RWKV_E_ARG, "need temp > 0 and 0 <= u < 1");
     HIPCHK(hipSetDevice(c->device));
-    int rc = launch_typical(c, (int)row, temp, tau, u, 0, false, ban0 != 0, false);
+    int rc = launch_typical(c, (int)row, temp, tau, u, 0, false, flags, false);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(token, c->pick, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
-int rwkv_decode_typical(rwkv_ctx *c, uint64_t first_token, uint64_t n, float temp, float tau, uint64_t seed, uint64_t *out_tokens)
+int rwkv_decode_typical(rwkv_ctx *c, uint64_t first_token, uint64_t n, float temp, float tau, uint64_t seed, int flags, uint64_t *out_tokens)
 {
     if (!c || !out_tokens) return fail(RWKV_E_ARG, "NULL argument");
     if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
@@ -826,7 +839,7 @@ int rwkv_decode_typical(rwkv_ctx *c, uint64_t first_token, uint64_t n, float tem
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     for (uint64_t i = 0; i < n; i++) {
         int rc = run_token(c, false);                                   // the token graph without the argmax node
-        if (!rc) rc = launch_typical(c, -1, temp, tau, 0.0, seed, true, true, true);
+        if (!rc) rc = launch_typical(c, -1, temp, tau, 0.0, seed, true, flags | RWKV_SAMPLE_BAN0, true);
         if (rc) return rc;
     }
     HIPCHK(hipMemcpyAsync(out_tokens, c->gen, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));

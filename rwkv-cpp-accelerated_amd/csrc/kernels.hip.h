@@ -1195,6 +1195,9 @@ __global__ void k_argmax_finish(const float *blk_val, const unsigned *blk_idx, i
         if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
     }
     if (threadIdx.x == 0) {
+        // all-NaN / all -inf logits leave no winner (the reference's un-stabilised WKV can overflow with unusual
+        // weights): feed token 0 like the sampler's fallback instead of indexing the embedding out of bounds
+        if (besti >= VOCAB) besti = 0u;
         const unsigned st = ctl->step;
         if (st < gen_cap) gen[st] = besti;
         ctl->token = besti;

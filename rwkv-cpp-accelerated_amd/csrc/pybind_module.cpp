@@ -10,8 +10,11 @@
 //   * initState really zeroes the state forward() uses (the reference re-allocates only the
 //     deprecated alias pointers, c_binding.cpp:41-60); getState returns the L*D state (the
 //     reference copies 50277 elements from those aliases, c_binding.cpp:104-110).
-//   * the tokenizer entry points (initTokenizer / tokenizerEncode / tokenizerDecode) are not part
-//     of the forward pass and are provided by the host application's tokenizer, not by this module.
+//   * initTokenizer / tokenizerEncode / tokenizerDecode (c_binding.cpp:17-28,122-135) are three forwarding shims to the
+//     reference's own GPT2Tokenizer: they exist when the module is built with the reference's include directory on the
+//     path (include/rwkv.h pulls in rwkv/tokenizer/tokenizer.h through __has_include); the tokenizer itself is outside
+//     this engine's scope and is not re-implemented here.  tokenizerEncode converts vector<long long> -> vector<int64_t>
+//     explicitly (the reference's own line c_binding.cpp:126 does not compile on LP64 Linux).
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -60,6 +63,23 @@ PYBIND11_MODULE(rwkv, m)
     }, "getRwkvOutput");
     m.def("typicalSample", [](std::uintptr_t h, float temp, float tau) { return typical(M(h)->out, temp, tau); },
           "typicalSample", py::arg("rwkvp"), py::arg("temp") = 0.9f, py::arg("tau") = 0.8f);
+#ifdef RWKV_HAVE_TOKENIZER
+    m.def("initTokenizer", [](const std::string &vocab_filename, const std::string &merges_filename) {
+        std::optional<GPT2Tokenizer> t = GPT2Tokenizer::load(vocab_filename, merges_filename);
+        if (!t.has_value()) {
+            std::cerr << "Failed to load tokenizer" << std::endl;
+            throw py::value_error("Failed to load tokenizer");
+        }
+        return reinterpret_cast<std::uintptr_t>(new GPT2Tokenizer(t.value()));
+    }, "initTokenizer");
+    m.def("tokenizerEncode", [](std::uintptr_t tp, std::string s) {
+        const auto ids = reinterpret_cast<GPT2Tokenizer *>(tp)->encode(s);
+        return std::vector<int64_t>(ids.begin(), ids.end());
+    }, "tokenizerEncode");
+    m.def("tokenizerDecode", [](std::uintptr_t tp, int token) {
+        return reinterpret_cast<GPT2Tokenizer *>(tp)->decode({(long int)token});
+    }, "tokenizerDecode");
+#endif
     m.def("setResident", [](std::uintptr_t h, bool on) { M(h)->residentState = on; }, "keep state on the device (engine extension)");
     m.def("decodeGreedy", [](std::uintptr_t h, int64_t first, int64_t n) { return M(h)->decodeGreedy(first, n); },
           "device-side greedy continuation (engine extension)");

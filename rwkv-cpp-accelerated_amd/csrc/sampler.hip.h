@@ -2,9 +2,11 @@
 // generation loop (examples/storygen/storygen.cpp:63-69: out[0] = -99; typical(out, temp, tau)) needs no
 // 201 KB logits download and no host sort per token.
 //
-// Behavioural mirror of reference include/rwkv/sampler/typical.h:20-58 (softmax, entropy H, sort by
-// |-log p - H|, keep the smallest prefix whose cumulative probability reaches tau, p^(1/temp), draw).
-// The sort is not needed: with s_i = |-log p_i - H| the cut-off value is
+// Behavioural mirror of reference include/rwkv/sampler/typical.h:20-58.  Two modes (include/rwkv_sampler.h has the
+// findings): recipe = 0 (default) is what the reference COMPUTES -- a draw from softmax^n, n = uint8(1/temp), its cut at
+// tau being a no-op -- and needs no selection at all; recipe = 1 is the recipe its header comment documents (softmax,
+// entropy H, sort by |-log p - H|, keep the smallest prefix whose cumulative probability reaches tau, p^(1/temp), draw).
+// For the latter the sort is not needed: with s_i = |-log p_i - H| the cut-off value is
 //     thr = min { v in {s_i} : sum_{s_i <= v} p_i >= tau }
 // (the sorted prefix crosses tau exactly at the first element of that value), found as a 32-bit float
 // pattern by a three-pass radix select over probability-mass histograms in LDS.  Three launches:
@@ -31,6 +33,8 @@ struct TypicalArgs {
     unsigned long long *gen;      // generated ids, gen[step]
     unsigned gen_cap;
     float temp, tau;
+    int recipe;                   // 1: the recipe typical.h documents (cut at tau, p^(1/temp)); 0: what it computes (no cut, p^uint8(1/temp))
+    double expo;                  // the exponent applied to p
     double u;                     // uniform in [0, 1) when use_seed == 0
     unsigned long long seed;      // else u = uniform(splitmix64(seed + step))
     int use_seed;
@@ -102,12 +106,12 @@ __global__ __launch_bounds__(TS_GT) void k_typical_keys(TypicalArgs a)
     const float *lg = ts_row(a);
     double M, logZ, H;
     ts_combine(a, M, logZ, H);
-    const double it = 1.0 / (double)a.temp;
+    const double it = a.expo;
     for (int i = i0 + threadIdx.x; i < i1; i += TS_GT) {
         const double nl = (M - (double)ts_logit(a, lg, i)) + logZ;          // -log p_i
         const int pos = (i % TS_PER) * TS_NT + i / TS_PER;
         a.p[pos] = (float)exp(-nl);
-        a.pw[pos] = a.temp == 1.0f ? (float)exp(-nl) : (float)exp(-nl * it);   // p^(1/temp), here: 64 workgroups share the exponentials
+        a.pw[pos] = it == 1.0 ? (float)exp(-nl) : it == 0.0 ? 1.0f : (float)exp(-nl * it);   // p^expo (p^0 = 1 even for p = 0, as nc::power), here: 64 workgroups share the exponentials
         a.key[pos] = __float_as_uint((float)fabs(nl - H));                  // typical.h:32
     }
     if (blockIdx.x == 0)       // padding positions: tokens V .. TS_NT * TS_PER - 1 carry no mass and the largest key
@@ -149,9 +153,9 @@ __global__ __launch_bounds__(TS_NT) void k_typical(TypicalArgs a)
     const double tau = fmax((double)a.tau, 1e-300);   // tau <= 0 keeps the smallest key, as the reference's cutoff = 0 does
     unsigned prefix = 0u;
     double acc = 0.0;                                  // mass of all keys below the current prefix range
-    bool open_end = false;
+    bool open_end = !a.recipe;                         // as compiled the reference cuts nothing (typical.h:50): no selection
 #pragma unroll 1
-    for (int pass = 0; pass < 3; pass++) {
+    for (int pass = 0; pass < (a.recipe ? 3 : 0); pass++) {
         const int shift = pass == 0 ? 20 : pass == 1 ? 8 : 0, bits = pass == 2 ? 8 : 12, nb = 1 << bits;
         for (int b = t; b < TS_HIST; b += TS_NT) hist[b] = 0.0;
         __syncthreads();

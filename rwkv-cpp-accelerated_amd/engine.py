@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RWKV_LIB") or os.path.join(_HERE, "csrc", "librwkv_mi355x.so")   # RWKV_LIB: tuning variants
 
 MODE_PARRALEL, MODE_GPT = 0, 1   # reference enums/enum.h:2-5
+SAMPLE_BAN0, SAMPLE_RECIPE = 1, 2   # include/rwkv_mi355x.h
 N_KCLASS = 7
 KCLASS_NAMES = ["first", "att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head", "argmax"]
 
@@ -68,7 +69,7 @@ def lib():
     L.rwkv_profile_batched.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]; L.rwkv_profile_batched.restype = i32
     L.rwkv_debug_timeline.argtypes = [vp, u64, vp, u64]; L.rwkv_debug_timeline.restype = i32
     L.rwkv_sample_typical.argtypes = [vp, u64, C.c_float, C.c_float, C.c_double, i32, C.POINTER(u64)]; L.rwkv_sample_typical.restype = i32
-    L.rwkv_decode_typical.argtypes = [vp, u64, u64, C.c_float, C.c_float, u64, C.POINTER(u64)]; L.rwkv_decode_typical.restype = i32
+    L.rwkv_decode_typical.argtypes = [vp, u64, u64, C.c_float, C.c_float, u64, i32, C.POINTER(u64)]; L.rwkv_decode_typical.restype = i32
     _lib = L
     return L
 
@@ -230,20 +231,31 @@ class RWKV:
         if not self.ready:
             raise RuntimeError("RWKV not loaded")
         out = (C.c_uint64 * n_tokens)()
+        if not self.resident:
+            self.push_state(1)          # host state is authoritative: continue from it ...
         _chk(lib().rwkv_decode_greedy(self._h, int(first_token), n_tokens, out))
+        if not self.resident:
+            self.pull_state(1)          # ... and leave it where the generated tokens ended
         return np.frombuffer(out, dtype=np.uint64).copy()
 
-    def sample_typical(self, temp: float = 0.9, tau: float = 0.8, u: float = 0.5, row: int = 0, ban0: bool = False) -> int:
-        """typical sampling ON THE DEVICE from the logits of the last forward (reference typical.h:20-58);
-        u in [0, 1) is the caller's uniform -- the draw is the inverse CDF in token order."""
+    def sample_typical(self, temp: float = 0.9, tau: float = 0.8, u: float = 0.5, row: int = 0, ban0: bool = False, recipe: bool = False) -> int:
+        """the reference's typical() ON THE DEVICE from the logits of the last forward (reference typical.h:20-58); u in
+        [0, 1) is the caller's uniform -- the draw is the inverse CDF in token order.  Default: what the reference computes,
+        a draw from softmax^(1/temp) (its cut at tau is a no-op, typical.h:50); recipe=True applies the documented cut."""
         tok = C.c_uint64(0)
-        _chk(lib().rwkv_sample_typical(self._h, int(row), float(temp), float(tau), float(u), 1 if ban0 else 0, C.byref(tok)))
+        flags = (SAMPLE_BAN0 if ban0 else 0) | (SAMPLE_RECIPE if recipe else 0)
+        _chk(lib().rwkv_sample_typical(self._h, int(row), float(temp), float(tau), float(u), flags, C.byref(tok)))
         return int(tok.value)
 
-    def decode_typical(self, first_token: int, n_tokens: int, temp: float = 0.9, tau: float = 0.8, seed: int = 0) -> np.ndarray:
+    def decode_typical(self, first_token: int, n_tokens: int, temp: float = 0.9, tau: float = 0.8, seed: int = 0, recipe: bool = False) -> np.ndarray:
         """device-side sampled continuation (storygen's loop with the device sampler; logit 0 banned)"""
         out = (C.c_uint64 * n_tokens)()
-        _chk(lib().rwkv_decode_typical(self._h, int(first_token), n_tokens, float(temp), float(tau), int(seed), out))
+        if not self.resident:
+            self.push_state(1)
+        _chk(lib().rwkv_decode_typical(self._h, int(first_token), n_tokens, float(temp), float(tau), int(seed),
+                                       SAMPLE_RECIPE if recipe else 0, out))
+        if not self.resident:
+            self.pull_state(1)
         return np.frombuffer(out, dtype=np.uint64).copy()
 
     def logits(self, n_tokens: int = 1) -> np.ndarray:

@@ -1,0 +1,141 @@
+"""RUN the reference's own caller on the GPU box: reference examples/storygen/storygen.cpp, compiled from where it lies in
+the authoring container (oracle/Makefile: storygen = against this repo's include/rwkv.h, storygen_l2 = against the
+reference's own rwkv.h + integration/rwkv_backend_mi355x.cpp), on a 169M-shaped model.bin (BASELINE config 1: L=12, D=768).
+
+storygen is interactive and samples with typical(out, 0.8, 0.7): it is driven with one line on stdin and a model whose
+logits are so peaked that the typical set is the argmax alone, so its output is deterministic and can be compared id for
+id with the Python engine replaying the same call sequence (storygen.cpp:29-73).  The tokenizer is the reference's own
+GPT2Tokenizer (compiled in); its vocab files are not available on the GPU box, so the test writes a byte-level vocab
+(256 byte tokens + one unique 5-letter string per remaining id, no merges) -- enough for encode() and decode()."""
+import json
+import os
+import re
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from rwkv_cpp_accelerated_amd import modelfile as mf
+import parity
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INIT_PROMPT = "### Instruction: Write a story/book using the themes and details provided\n\n### Input:"   # storygen.cpp:5-7
+USER_LINE = "a knight"
+
+
+def bytes_to_unicode():
+    """the GPT-2 byte <-> printable-unicode table the reference tokenizer hard-codes (tokenizer.h:24-33)"""
+    bs = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    return {b: chr(c) for b, c in zip(bs, cs)}
+
+
+def word_of(i):
+    s = ""
+    for _ in range(4):
+        s = chr(97 + i % 26) + s; i //= 26
+    return "Z" + s
+
+
+def write_vocab(d):
+    os.makedirs(d, exist_ok=True)
+    b2u = bytes_to_unicode()
+    vocab = {b2u[b]: b for b in range(256)}
+    for i in range(256, mf.VOCAB):
+        vocab[word_of(i)] = i
+    assert len(vocab) == mf.VOCAB
+    with open(os.path.join(d, "vocab.json"), "w", encoding="utf-8") as f:
+        json.dump(vocab, f, ensure_ascii=False)
+    with open(os.path.join(d, "merges.txt"), "w") as f:
+        f.write("#version: 0.2\n")
+
+
+def encode(text):
+    return list(text.encode("utf-8"))       # no merges: one token per byte, id = byte value
+
+
+def decode_stream(raw):
+    ids, i = [], 0
+    while i < len(raw):
+        if raw[i:i + 1] == b"Z" and len(raw) >= i + 5 and raw[i + 1:i + 5].isalpha() and raw[i + 1:i + 5].islower():
+            v = 0
+            for ch in raw[i + 1:i + 5]:
+                v = v * 26 + (ch - 97)
+            ids.append(v); i += 5
+        else:
+            ids.append(raw[i]); i += 1
+    return ids
+
+
+@pytest.fixture(scope="module")
+def world(built, tmp_path_factory):
+    root = tmp_path_factory.mktemp("storygen")
+    cwd = root / "examples" / "storygen" / "build"
+    cwd.mkdir(parents=True)
+    write_vocab(str(root / "include" / "rwkv" / "tokenizer" / "vocab"))
+    (root / "converter").mkdir()
+    L, D = mf.SHAPES["169M"]
+    t = mf.synthetic_tensors(L, D, seed=169, head_scale=3.0e5)      # typical set == {argmax}: see module docstring
+    path = str(root / "converter" / "model.bin")
+    mf.write_bin(path, L, D, t)
+    return dict(cwd=str(cwd), model=path, L=L, D=D)
+
+
+def expected_ids(world, n):
+    from rwkv_cpp_accelerated_amd import engine
+    m = engine.RWKV(resident=False)          # host-authoritative state, as the reference's RWKV::forward (rwkv.h:353,372)
+    m.loadFile(world["model"], 1)
+    prompt = encode(INIT_PROMPT)
+    for tk in prompt:                         # loadContext(initPrompt), maxContext = 1
+        m.forward(tk)
+    for tk in encode(USER_LINE + "\n\n### Response:"):
+        m.forward(tk)
+    tk, out, pmax = prompt[-1], [], 1.0       # storygen feeds the prompt's last token again (storygen.cpp:33,57,65)
+    for _ in range(n):
+        lg = m.forward(tk)[: mf.VOCAB].astype(np.float64)
+        lg[0] = -99.0
+        e = np.exp(lg - lg.max())
+        pmax = min(pmax, float(e.max() / e.sum()))
+        tk = int(np.argmax(lg)); out.append(tk)
+    m.close()
+    return out, pmax
+
+
+@pytest.mark.parametrize("exe", ["storygen_mi355x", "storygen_l2"])
+def test_reference_storygen_runs_on_the_engine(world, exe):
+    binp = os.path.join(ROOT, "oracle", "_ref", exe)
+    if not os.path.exists(binp):
+        pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference at build time)")
+    env = dict(os.environ, RWKV_SAMPLER_SEED="1")
+    p = subprocess.Popen([binp], cwd=world["cwd"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    p.stdin.write((USER_LINE + "\n").encode()); p.stdin.flush()      # stdin stays open: the app blocks at its next prompt
+    buf, t0 = b"", time.time()
+    os.set_blocking(p.stdout.fileno(), False)
+    try:
+        while b"continue? (y/n):" not in buf and time.time() - t0 < 240 and p.poll() is None:
+            chunk = p.stdout.read()
+            if chunk:
+                buf += chunk
+            else:
+                time.sleep(0.05)
+    finally:
+        p.kill(); p.wait()
+    assert b"continue? (y/n):" in buf, (buf[-400:], p.stderr.read()[-400:])
+    head, gen = buf.split(b"written:>", 1)
+    assert b"Loaded model" in head and f"n_layers: {world['L']}".encode() in head
+    mt = re.match(rb"(\d+):token", gen)
+    assert mt, gen[:60]
+    gen = gen[mt.end(): gen.index(b"continue? (y/n):")]
+    got = decode_stream(gen)
+    assert len(got) >= 150
+    want, pmax = expected_ids(world, len(got))
+    assert pmax > 0.7, "test model not peaked enough: typical(0.8, 0.7) would keep more than the argmax"
+    assert got == want
+    assert len(set(got)) > 20

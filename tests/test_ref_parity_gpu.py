@@ -61,3 +61,26 @@ def test_reference_gpt_chunk(built, oracle, ref, tmp_path):
         parity.check_logits(lo[i], lr[i], f"oracle pos {i}")
         parity.check_logits(le[i], lr[i], f"engine pos {i}")
     om.close(); em.close()
+
+
+@pytest.mark.parametrize("name,steps", [("1B5", 96), ("14B", 64)])
+def test_full_depth_gate_vs_reference_kernel(built, ref, name, steps):
+    """BASELINE configs 2 and 4 at FULL depth (1B5: L=24, D=2048; 14B: L=40, D=5120): the engine, teacher-forced with the
+    reference kernel's greedy ids on the same device-resident tensors, matches its logits within 1e-3 and its greedy id at
+    every step (the 7B / 1024-step instance of this gate runs inside bench.py: parity_vs_reference_kernel)."""
+    import torch
+    from rwkv_cpp_accelerated_amd import engine
+    import refgate
+    L, D = mf.SHAPES[name]
+    t = mf.synthetic_tensors_torch(L, D, seed=5, device="cuda")
+    torch.cuda.synchronize()
+    em = engine.RWKV(resident=True); em.loadTensors(L, D, t, maxGPT=1)
+    rm = refgate.ref_model_from_torch(ref, mf, t, L, D, 1)
+    rng = np.random.default_rng(3)
+    prompt = [int(x) for x in rng.integers(2, mf.VOCAB, 8)]
+    g = refgate.run_gate(rm, em, mf, prompt, steps, strict=True, what=name)
+    assert g["steps"] == steps and g["steps_outside_tolerance"] == 0
+    assert len(set(g["ids"])) > 4, "degenerate greedy chain: the gate would not exercise the recurrence"
+    em.close()
+    del t
+    torch.cuda.empty_cache()
