@@ -149,9 +149,9 @@ template <typename T> int dalloc(rwkv_ctx *c, T **p, size_t count)
 }
 
 // one staged vector = 3 limb planes of S x 1 KiB
-size_t smem_att(int S, int gpb) { return RED_BYTES + 3 * (size_t)S * 3072 + (size_t)gpb * 3 * 4; }
+size_t smem_att(int S) { return RED_BYTES + 3 * (size_t)S * 3072; }
 size_t smem_attout(int S) { return RED_BYTES + (size_t)S * 3072; }
-size_t smem_frk(int S, int gpb) { return RED_BYTES + 2 * (size_t)S * 3072 + (size_t)gpb * 5 * 4; }
+size_t smem_frk(int S) { return RED_BYTES + 2 * (size_t)S * 3072; }
 size_t smem_fv(int S) { return RED_BYTES + 4 * (size_t)S * 3072; }
 size_t smem_head(int S) { return RED_BYTES + (size_t)S * 3072 + NW * 8; }
 
@@ -177,7 +177,6 @@ template <typename K> int allow_smem(K kernel, size_t bytes)
     return 0;
 }
 
-int gpb_of(const rwkv_ctx *c) { return (int)((c->D + c->grid - 1) / c->grid) + 1; }
 
 // ---- one launch helper per kernel class (0 embed, 1 att, 2 att_out, 3 ffn_rk, 4 ffn_v, 5 head, 6 argmax) ----
 void launch_class(rwkv_ctx *c, int cls, uint64_t l)
@@ -185,7 +184,6 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
     const int D = (int)c->D, S = c->S, grid = c->grid;
     const uint64_t L = c->L;
     const size_t LD = (size_t)L * D, lo = (size_t)l * D;
-    const int gpb = gpb_of(c);
     // debug timeline: the kernel of class tl_cls in the stage's middle layer stamps its phases
     auto tl_of = [&](int k) { return (c->tl_on && k == c->tl_cls && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr; };
     auto site_static = [&](int k, uint64_t ll) {
@@ -219,7 +217,7 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
         aa.slot_stride = LD; aa.ybuf = c->ybuf; aa.partS = c->partA; aa.partM = c->partMA;
         aa.ctl = c->ctl; aa.D = D; aa.tl = tl_of(1);
-        DISPATCH_S(S, k_att<S_><<<dim3(grid), dim3(NT), smem_att(S, gpb), c->stream>>>(aa));
+        DISPATCH_S(S, k_att<S_, nb_att(S_)><<<dim3(grid), dim3(NT), smem_att(S), c->stream>>>(aa));
     } break;
     case 2: {
         AttOutArgs ao;
@@ -227,7 +225,7 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         ao.x = c->x; ao.lnw = c->ln + (4 * l + 2) * D; ao.lnb = c->ln + (4 * l + 3) * D; ao.lnstat = c->lnstat + 0;
         ao.sxy = c->state[0] + lo; ao.st = site_static(1, l); ao.dy = site_dyn(1, grid); ao.sdd = c->state[4] + lo;
         ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.tl = tl_of(2);
-        DISPATCH_S(S, k_attout<S_, ATTOUT_R><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
+        DISPATCH_S(S, k_attout<S_, ATTOUT_R, nb_attout(S_)><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
     } break;
     case 3: {
         FfnRKArgs fa;
@@ -236,7 +234,7 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.partM = c->partMF; fa.ctl = c->ctl; fa.D = D;
         fa.tl = tl_of(3);
-        DISPATCH_S(S, k_ffn_rk<S_><<<dim3(grid), dim3(NT), smem_frk(S, gpb), c->stream>>>(fa));
+        DISPATCH_S(S, k_ffn_rk<S_, nb_frk(S_)><<<dim3(grid), dim3(NT), smem_frk(S), c->stream>>>(fa));
     } break;
     case 4: {
         FfnVArgs fv;
@@ -245,17 +243,17 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         fv.sdd = c->state[4] + lo; fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D; fv.tl = tl_of(4);
         if (l + 1 < c->l1) {   // next consumer: k_att of layer l+1
             fv.st = site_static(0, l + 1); fv.dy = site_dyn(0, grid); fv.sprev = c->state[0] + lo + D;
-            DISPATCH_S(S, k_ffnv<S_, 3><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
+            DISPATCH_S(S, k_ffnv<S_, 3, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
         } else {               // next consumer: k_head (on a non-final pipeline stage nobody reads it: the next stage's k_first re-opens its own site from x)
             fv.st = site_static(2, 0); fv.dy = site_dyn(2, grid); fv.sprev = nullptr;
-            DISPATCH_S(S, k_ffnv<S_, 1><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
+            DISPATCH_S(S, k_ffnv<S_, 1, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
         }
     } break;
     case 5: {
         HeadArgs ha;
         ha.x = c->x; ha.st = site_static(2, 0); ha.dy = site_dyn(2, grid); ha.w = c->w_head; ha.rs = c->rs_head; ha.logits = c->logits;
         ha.blk_val = c->blk_val; ha.blk_idx = c->blk_idx; ha.ctl = c->ctl; ha.D = D;
-        DISPATCH_S(S, k_head<S_><<<dim3(grid), dim3(NT), smem_head(S), c->stream>>>(ha));
+        DISPATCH_S(S, k_head<S_, nb_head(S_)><<<dim3(grid), dim3(NT), smem_head(S), c->stream>>>(ha));
     } break;
     default:
         k_argmax_finish<<<dim3(1), dim3(64), 0, c->stream>>>(c->blk_val, c->blk_idx, grid, c->ctl, c->gen, c->gen_cap);
@@ -329,14 +327,14 @@ template <typename T> int upload(rwkv_ctx *c, Source &src, int slot, T **dst)
 
 int set_smem_limits(rwkv_ctx *c)
 {
-    const int S = c->S, gpb = gpb_of(c);
+    const int S = c->S;
     int rc = 0;
-    DISPATCH_S(S, rc = allow_smem(k_att<S_>, smem_att(S, gpb))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R>, smem_attout(S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_>, smem_frk(S, gpb))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3>, smem_fv(S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1>, smem_fv(S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_head<S_>, smem_head(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_att<S_, nb_att(S_)>, smem_att(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R, nb_attout(S_)>, smem_attout(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_, nb_frk(S_)>, smem_frk(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, nb_fv(S_)>, smem_fv(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, nb_fv(S_)>, smem_fv(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_head<S_, nb_head(S_)>, smem_head(S))); if (rc) return rc;
     return 0;
 }
 
@@ -347,11 +345,6 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         return fail(RWKV_E_ARG, "unsupported model shape n_layers=%llu n_embed=%llu (n_embed must be a multiple of 16, <= 5120)",
                     (unsigned long long)L, (unsigned long long)D);
     if (max_ctx == 0) max_ctx = 1;
-    // k_att / k_ffn_rk finish the channels a workgroup owns with one thread per channel (k_att) after the last row:
-    // a grid so small that a workgroup owns more than NT channels would silently skip some
-    if ((D + (uint64_t)c->grid - 1) / (uint64_t)c->grid > (uint64_t)NT)
-        return fail(RWKV_E_ARG, "grid of %d workgroups is too small for n_embed=%llu (needs >= %llu; RWKV_GRID)", c->grid,
-                    (unsigned long long)D, (unsigned long long)((D + NT - 1) / NT));
     HIPCHK(hipSetDevice(c->device));
     c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
     if (c->l1 == UINT64_MAX) c->l1 = L;

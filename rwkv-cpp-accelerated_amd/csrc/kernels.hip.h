@@ -555,30 +555,92 @@ constexpr int RED_BC = 96;     // doubles: scalars published by the prologue wav
 // Row groups of a workgroup are handed out through an LDS counter (DYN): the waves that ran the
 // prologue start their first group late, the others take more of the remaining groups.  The counter
 // lives next to the published scalars and is set by thread 0 before the prologue's barriers.
-#ifndef RWKV_DYN
-#define RWKV_DYN 1
-#endif
 #ifndef RWKV_HEAD_R
 #define RWKV_HEAD_R 2      // rows per group in k_head (measured: 2 -> 35.8, 3 -> 36.2, 4 -> 36.8, 5 -> 38.0 us at 7B)
 #endif
+// Row-group buffers per wave.  2: a wave holds TWO groups of weight registers (A and B) and alternates between them, so
+// R*S*2 loads are requested ahead.  What that buys is not steady-state depth (the CU's memory pipe accepts only ~16 KB of
+// requests anyway) but PROLOGUE cover: the loader waves' registers are the only place weight bytes can land while the
+// prologue waves reduce and stage the vector (~3.6 us), and one group per loader (80 KB per CU at 7B) is 3 us of HBM
+// stream -- with two the stream never runs dry before the first dot.
+#ifndef RWKV_NBUF
+#define RWKV_NBUF 2
+#endif
+constexpr int NBUF = RWKV_NBUF;          // default; a kernel whose two buffers would not fit 256 registers (R*S*8 of them) takes 1
+constexpr int nb_att(int) { return NBUF; }                        // 3 rows:  254 registers at S = 5
+constexpr int nb_attout(int) { return NBUF; }
+constexpr int nb_frk(int S) { return S <= 4 ? NBUF : 1; }         // 5 rows:  245 at S = 4, spills at S = 5
+constexpr int nb_fv(int S) { return S <= 4 ? NBUF : 1; }          // 4 rows:  229 at S = 4, spills at S = 5
+constexpr int nb_head(int) { return NBUF; }
 __device__ __forceinline__ unsigned *group_counter(double *red) { return reinterpret_cast<unsigned *>(red + RED_BC) + 9; }
-__device__ __forceinline__ int next_group(unsigned *ctr, int after)
+__device__ __forceinline__ int next_group(unsigned *ctr)
 {
-#if RWKV_DYN
     unsigned v = 0;
     if ((threadIdx.x & 63) == 0) v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __builtin_amdgcn_readfirstlane((int)v);
-#else
-    return after + NW;
-#endif
+}
+
+// The streaming loop of every decode kernel.  A wave owns the groups it draws from the workgroup's LDS counter; group
+// indices drawn later are larger, so the OLDEST outstanding group is tested and a miss ends the loop.  Per group:
+// pre(g) requests the epilogue's inputs (before the dot issues the refills: a load placed after them would, by in-order
+// vmcnt, wait for the whole next group to land), group_dot consumes the group's registers and refills them step by step
+// with the group drawn now, epi(g, T, in) finishes the rows.  base(g) = weight address of a valid group.
+template <int R, int S, int PAT, int NB, class Base, class Pre, class Epi>
+__device__ __forceinline__ void stream_groups(u32x4 (&wA)[R][S], u32x4 (&wB)[R][S], int gA, int gB, int g0, int g1, unsigned *gctr,
+                                              const unsigned *xq, int lane, size_t stride, int chunks, Base base, Pre pre, Epi epi)
+{
+    for (;;) {
+        if (!(gA < g1)) break;
+        {
+            const int gn = next_group(gctr);
+            const bool nv = gn < g1;
+            const auto in = pre(gA);
+            unsigned long long T[R];
+            group_dot<R, S, PAT>(wA, xq, lane, T, base(nv ? gn : g0), stride, chunks, nv);
+            epi(gA, T, in);
+            gA = gn;
+        }
+        if (NB == 2) {
+            if (!(gB < g1)) break;
+            const int gn = next_group(gctr);
+            const bool nv = gn < g1;
+            const auto in = pre(gB);
+            unsigned long long T[R];
+            group_dot<R, S, PAT>(wB, xq, lane, T, base(nv ? gn : g0), stride, chunks, nv);
+            epi(gB, T, in);
+            gB = gn;
+        }
+    }
+}
+// first groups of a wave (A: g0 + wave, B: g0 + NW + wave) and the counter's start; set by thread 0 before the prologue's barriers
+template <int NB>
+__device__ __forceinline__ void first_groups(int g0, int wave, unsigned *gctr, int &gA, int &gB)
+{
+    gA = g0 + wave;
+    gB = NB == 2 ? g0 + NW + wave : 0x7fffffff;
+    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NB * NW);
+}
+// workgroup-wide sum of one double and max of one non-negative float in ONE barrier (the kernels' closing reduction)
+__device__ __forceinline__ void block_sum_max(double &sv, float &mv, double *red)
+{
+    float *redf = reinterpret_cast<float *>(red + NW);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    sv = wave_sum(sv);
+    mv = wave_max(mv);
+    if (lane == 0) { red[w] = sv; redf[w] = mv; }
+    __syncthreads();
+    double s = 0.0; float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; i++) { s += red[i]; m = fmaxf(m, redf[i]); }
+    sv = s; mv = m;
 }
 
 // LayerNorm-site consumer (k_att, k_ffn_rk, k_head): on return the NV vectors are staged in xq,
 // sr.S / sr.amax are valid in every wave and w holds (requests for) the wave's first row group.
-template <int NV, int R, int S, bool SPLIT>
+template <int NV, int R, int S, bool SPLIT, int NB>
 __device__ __forceinline__ void site_open(const SiteStatic &st, const SiteDyn &dy, const double *x, int D, double *red, unsigned *xq,
-                                          u32x4 (&w)[R][S], const uint8_t *wb, size_t stride, SiteRed<NV> &sr, bool publish_stats,
-                                          unsigned long long *tl)
+                                          u32x4 (&w)[R][S], u32x4 (&w2)[R][S], const uint8_t *wb, const uint8_t *wb2, size_t stride,
+                                          SiteRed<NV> &sr, bool publish_stats, unsigned long long *tl)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = D >> 4, nqd = D >> 2;
@@ -588,6 +650,7 @@ __device__ __forceinline__ void site_open(const SiteStatic &st, const SiteDyn &d
     if (SPLIT && wave >= NWP) {
         __syncthreads();   // order: the prologue waves' requests are in the memory pipe
         group_load<R, S, 0, S>(w, wb, stride, chunks, lane);
+        if (NB == 2) group_load<R, S, 0, S>(w2, wb2, stride, chunks, lane);
         tl_stamp(tl, 2);
         __syncthreads();   // staged
     } else {
@@ -631,6 +694,7 @@ __device__ __forceinline__ void site_open(const SiteStatic &st, const SiteDyn &d
         }
         __syncthreads();   // staged
         group_load<R, S, SPLIT ? 0 : pre_steps<S>(), S>(w, wb, stride, chunks, lane);
+        if (NB == 2) group_load<R, S, 0, S>(w2, wb2, stride, chunks, lane);
     }
     if (SPLIT) {
 #pragma unroll
@@ -641,10 +705,10 @@ __device__ __forceinline__ void site_open(const SiteStatic &st, const SiteDyn &d
 
 // Plain-vector consumer (k_attout: NVEC = 1; k_ffnv: the four quarter vectors of the hidden vector).
 // The producer left the pre-scaled vector and per-workgroup partials of the offset sum and of max|.|.
-template <int NVEC, int R, int S, bool SPLIT>
+template <int NVEC, int R, int S, bool SPLIT, int NB>
 __device__ __forceinline__ void vec_open(const float *vec, const double *partS, const float *partM, int n_part, int D, double *red,
-                                         unsigned *xq, u32x4 (&w)[R][S], const uint8_t *wb, size_t stride, float &Sf, float &amax,
-                                         unsigned long long *tl)
+                                         unsigned *xq, u32x4 (&w)[R][S], u32x4 (&w2)[R][S], const uint8_t *wb, const uint8_t *wb2, size_t stride,
+                                         float &Sf, float &amax, unsigned long long *tl)
 {
     constexpr int XVD = xvd<S>();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -655,6 +719,7 @@ __device__ __forceinline__ void vec_open(const float *vec, const double *partS, 
     if (SPLIT && wave >= NWP) {
         __syncthreads();   // order
         group_load<R, S, 0, S>(w, wb, stride, chunks, lane);
+        if (NB == 2) group_load<R, S, 0, S>(w2, wb2, stride, chunks, lane);
         tl_stamp(tl, 2);
         __syncthreads();   // staged
     } else {
@@ -706,6 +771,7 @@ __device__ __forceinline__ void vec_open(const float *vec, const double *partS, 
         if (SPLIT && threadIdx.x == 0) { bc[0] = Sf; bc[4] = amax; }
         __syncthreads();   // staged
         group_load<R, S, SPLIT ? 0 : pre_steps<S>(), S>(w, wb, stride, chunks, lane);
+        if (NB == 2) group_load<R, S, 0, S>(w2, wb2, stride, chunks, lane);
     }
     if (SPLIT) { Sf = bc[0]; amax = bc[4]; }
     tl_stamp(tl, 5);
@@ -775,77 +841,67 @@ struct AttArgs {
 };
 
 // ln1 site -> K,V,R dequant-GEMV -> WKV (rwkv.cu:535-545; kernels :351-392, :58-100, :221-259)
-template <int S>
+struct AttIn { unsigned rs[3]; double aa, bb, uw, ew; float ra, oa; };
+template <int S, int NB>
 __global__ __launch_bounds__(NT) void k_att(AttArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XVD = xvd<S>();
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    float *stash = reinterpret_cast<float *>(xq + 3 * XVD);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4, nqd = D >> 2;
+    const int chunks = D >> 4;
     const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
 
     tl_stamp(a.tl, 0);
-    // the epilogue's per-channel inputs (state, decay, att_out scale / offset) are requested now: asked for after
-    // the last row they would add a full cold-miss latency to the kernel's tail
-    const int ic = g0 + ((int)threadIdx.x < g1 - g0 ? (int)threadIdx.x : 0);
-    const double e_aa = a.saa[so + ic], e_bb = a.sbb[so + ic], e_uw = a.uw[ic], e_ew = a.ew[ic];
-    const float e_ra = a.r_att[ic], e_oa = a.o_att[ic];
-    u32x4 w[3][S];
-    int g = g0 + wave;
+    u32x4 wA[3][S], wB[3][S];
+    int gA, gB;
     unsigned *gctr = group_counter(red);
-    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NW);   // visible behind the prologue's barriers
-    // every wave requests a first group, even one without work (it re-reads a neighbour's rows): a
+    first_groups<NB>(g0, wave, gctr, gA, gB);   // the counter is visible behind the prologue's barriers
+    // every wave requests its first groups, even one without work (it re-reads a neighbour's rows): a
     // branch around the loads would make hipcc's waitcnt pass drain the weights early
-    const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 3 * D;
+    auto base = [&](int g) { return a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 3 * D; };
     SiteRed<3> sr;
-    site_open<3, 3, S, (RWKV_SPLIT & 1) != 0>(a.st, a.dy, a.x, D, red, xq, w, wb, (size_t)D, sr, true, a.tl);
+    site_open<3, 3, S, (RWKV_SPLIT & 1) != 0, NB>(a.st, a.dy, a.x, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, sr, true, a.tl);
     const double sc[3] = {scale_of(sr.amax[0]), scale_of(sr.amax[1]), scale_of(sr.amax[2])};
+    const float S0 = (float)sr.S[0], S1 = (float)sr.S[1], S2 = (float)sr.S[2];
 
-    int gn = next_group(gctr, g);   // the group whose rows refill the registers during the next dot
-    while (g < g1) {
-        unsigned long long T[3];
-        const bool nv = gn < g1;
-        const int gnn = nv ? next_group(gctr, gn) : g1;
-        // per-group epilogue inputs are requested BEFORE the dot issues the refill loads: a load
-        // placed after them would, by in-order vmcnt, wait for the whole next group to land
-        const unsigned rsum = a.rs[g * 3 + (lane < 3 ? lane : 0)];
-        group_dot<3, S, PAT_PER_ROW>(w, xq, lane, T, a.w + (size_t)(nv ? gn : 0) * 3 * D, (size_t)D, chunks, nv);
+    // channel g = one group of three rows (K, V, R); the wave that finished them runs the WKV recurrence and the
+    // receptance gate of that channel at once (rwkv.cu:242-255): no staging of k/v/r, no pass after the last row
+    double part = 0.0;
+    float pmax = 0.f;
+    stream_groups<3, S, PAT_PER_ROW, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base,
+        [&](int g) {
+            AttIn in;
 #pragma unroll
-        for (int m = 0; m < 3; m++)
-            if (lane == m) stash[(g - g0) * 3 + m] = row_value(T[m], rsum, sc[m]) + (float)sr.S[m];
-        g = gn; gn = gnn;
-    }
-    __syncthreads();
+            for (int m = 0; m < 3; m++) in.rs[m] = a.rs[g * 3 + m];
+            in.aa = a.saa[so + g]; in.bb = a.sbb[so + g]; in.uw = a.uw[g]; in.ew = a.ew[g];
+            in.ra = a.r_att[g]; in.oa = a.o_att[g];
+            return in;
+        },
+        [&](int g, const unsigned long long (&T)[3], const AttIn &in) {
+            if (lane == 0) {
+                const float k = row_value(T[0], in.rs[0], sc[0]) + S0, v = row_value(T[1], in.rs[1], sc[1]) + S1;
+                const float r = row_value(T[2], in.rs[2], sc[2]) + S2;
+                const double vv = (double)v;
+                const double e1 = exp(in.uw + (double)k);
+                double y = (in.aa + e1 * vv) / (in.bb + e1);
+                y = (1.0 / (1.0 + (double)expf(-r))) * y;       // rwkv.cu:250: exp of a float argument
+                const double ek = exp((double)k);
+                a.saa[so + g] = (in.aa + ek * vv) * in.ew;
+                a.sbb[so + g] = (in.bb + ek) * in.ew;
+                const float yf = (float)y;                       // att_out GEMV casts its input to f32 (rwkv.cu:290)
+                const float ys = yf * in.ra;
+                a.ybuf[g] = ys;
+                part += (double)(yf * in.oa);
+                pmax = fmaxf(pmax, fabsf(ys));
+            }
+        });
     tl_stamp(a.tl, 6);
-
-    // WKV recurrence + receptance gate, one lane per channel (rwkv.cu:242-255)
-    double part[1] = {0.0};
-    float pmax[1] = {0.f};
-    if ((int)threadIdx.x < g1 - g0) {
-        const int i = g0 + threadIdx.x;
-        const float k = stash[threadIdx.x * 3 + 0], v = stash[threadIdx.x * 3 + 1], r = stash[threadIdx.x * 3 + 2];
-        const double aa = e_aa, bb = e_bb;
-        const double vv = (double)v;
-        const double e1 = exp(e_uw + (double)k);
-        double y = (aa + e1 * vv) / (bb + e1);
-        y = (1.0 / (1.0 + (double)expf(-r))) * y;       // rwkv.cu:250: exp of a float argument
-        const double ek = exp((double)k), ew = e_ew;
-        a.saa[so + i] = (aa + ek * vv) * ew;
-        a.sbb[so + i] = (bb + ek) * ew;
-        const float yf = (float)y;                       // att_out GEMV casts its input to f32 (rwkv.cu:290)
-        const float ys = yf * e_ra;
-        a.ybuf[i] = ys;
-        part[0] = (double)(yf * e_oa);
-        pmax[0] = fabsf(ys);
-    }
-    block_sum<1>(part, red + RED_PART);
-    block_max<1>(pmax, red + RED_AUX);
-    if (threadIdx.x == 0) { a.partS[blockIdx.x] = part[0]; a.partM[blockIdx.x] = pmax[0]; }
+    __syncthreads();   // every wave is past its last read of the reduction scratch
+    block_sum_max(part, pmax, red + RED_PART);
+    if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
     tl_stamp(a.tl, 7);
 }
 
@@ -872,14 +928,15 @@ struct AttOutArgs {
 
 // att_out dequant-GEMV + residual through f32 (rwkv.cu:548-553), R rows per group; commits state xy;
 // opens the ln2 site for the rows it owns
-template <int S, int R>
+template <int R> struct AttOutIn { unsigned rsum; double xold, lw, lb, prev2; SitePre<2> pre; int mi, shift; };
+template <int S, int R, int NB>
 __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4, nqd = D >> 2;
+    const int chunks = D >> 4;
     tl_stamp(a.tl, 0);
     const int G = (D + R - 1) / R;
     const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
@@ -887,49 +944,45 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
 
     const double mean1 = a.lnstat[0], rstd1 = a.lnstat[1];
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
-    u32x4 w[R][S];
-    int g = g0 + wave;
+    u32x4 wA[R][S], wB[R][S];
+    int gA, gB;
     unsigned *gctr = group_counter(red);
-    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NW);   // visible behind the prologue's barriers
-    auto rowbase = [&](int gg) {
-        int row = gg * R;
-        if (row > D - R) row = D - R;
+    first_groups<NB>(g0, wave, gctr, gA, gB);
+    auto base = [&](int gg) {
+        int row = (gg < g1 ? gg : (g1 > g0 ? g1 - 1 : 0)) * R;
+        if (row > D - R) row = D - R;          // the last group may overlap the previous one
         return a.w + (size_t)row * D;
     };
-    const uint8_t *wb = rowbase(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0));
     float Sf, amax;
-    vec_open<1, R, S, (RWKV_SPLIT & 2) != 0>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, w, wb, (size_t)D, Sf, amax, a.tl);
+    vec_open<1, R, S, (RWKV_SPLIT & 2) != 0, NB>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, Sf, amax, a.tl);
     const double sc = scale_of(amax);
     SiteAcc<2> acc;
     acc.clear();
 
-    int gn = next_group(gctr, g);   // the group whose rows refill the registers during the next dot
-    while (g < g1) {
-        unsigned long long T[R];
-        const bool nv = gn < g1;
-        const int gnn = nv ? next_group(gctr, gn) : g1;
-        int row0 = g * R;
-        const int shift = (row0 > D - R) ? row0 - (D - R) : 0;   // last group may overlap the previous one
-        row0 -= shift;
-        // epilogue inputs first (before the refills): lane r owns row row0 + r
-        const int mi = row0 + (lane < R ? lane : 0);
-        const unsigned rsum = a.rs[mi];
-        const double xold = a.x[mi], lw = a.lnw[mi], lb = a.lnb[mi], prev2 = a.sdd[so + mi];
-        SitePre<2> pre;
-        site_prefetch<2>(a.st, mi, pre);
-        group_dot<R, S, PAT_SHARED>(w, xq, lane, T, rowbase(nv ? gn : 0), (size_t)D, chunks, nv);
+    stream_groups<R, S, PAT_SHARED, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base,
+        [&](int g) {
+            AttOutIn<R> in;
+            int row0 = g * R;
+            in.shift = (row0 > D - R) ? row0 - (D - R) : 0;
+            row0 -= in.shift;
+            in.mi = row0 + (lane < R ? lane : 0);               // lane r owns row row0 + r
+            in.rsum = a.rs[in.mi];
+            in.xold = a.x[in.mi]; in.lw = a.lnw[in.mi]; in.lb = a.lnb[in.mi]; in.prev2 = a.sdd[so + in.mi];
+            site_prefetch<2>(a.st, in.mi, in.pre);
+            return in;
+        },
+        [&](int, const unsigned long long (&T)[R], const AttOutIn<R> &in) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            if (lane == r && r >= shift) {
-                const float accf = (float)xold + (row_value(T[r], rsum, sc) + Sf);   // f32 accumulator pre-loaded with x (:548)
-                const double xnew = (double)accf;                                     // :553
-                a.x[mi] = xnew;
-                a.sxy[so + mi] = lw * ((xold - mean1) * rstd1) + lb;                  // mixatt's state write (:385): ln1 output
-                site_emit<2>(pre, a.dy, D, mi, xnew, prev2, acc);
+            for (int r = 0; r < R; r++) {
+                if (lane == r && r >= in.shift) {
+                    const float accf = (float)in.xold + (row_value(T[r], in.rsum, sc) + Sf);   // f32 accumulator pre-loaded with x (:548)
+                    const double xnew = (double)accf;                                           // :553
+                    a.x[in.mi] = xnew;
+                    a.sxy[so + in.mi] = in.lw * ((in.xold - mean1) * rstd1) + in.lb;           // mixatt's state write (:385): ln1 output
+                    site_emit<2>(in.pre, a.dy, D, in.mi, xnew, in.prev2, acc);
+                }
             }
-        }
-        g = gn; gn = gnn;
-    }
+        });
     __syncthreads();   // every wave is past its last read of the reduction scratch
     tl_stamp(a.tl, 6);
     site_publish<2, R>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
@@ -954,68 +1007,63 @@ struct FfnRKArgs {
 };
 
 // ln2 site -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573)
-template <int S>
+struct FfnRKIn { unsigned rsum; float rq, oq; };
+template <int S, int NB>
 __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XVD = xvd<S>();
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    float *stash = reinterpret_cast<float *>(xq + 2 * XVD);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4, nqd = D >> 2;
+    const int chunks = D >> 4;
     const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
     tl_stamp(a.tl, 0);
-    // epilogue item of this thread (thread t finishes stash[t]): its ffn_v scale / offset are requested now (see k_att)
-    const int eq = threadIdx.x % 5, ei = g0 + ((int)threadIdx.x < 5 * (g1 - g0) ? (int)threadIdx.x / 5 : 0);
-    const float e_r = a.r_fv[4 * ei + (eq < 4 ? eq : 0)], e_o = a.o_fv[4 * ei + (eq < 4 ? eq : 0)];
 
-    u32x4 w[5][S];
-    int g = g0 + wave;
+    u32x4 wA[5][S], wB[5][S];
+    int gA, gB;
     unsigned *gctr = group_counter(red);
-    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NW);   // visible behind the prologue's barriers
-    const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 5 * D;
+    first_groups<NB>(g0, wave, gctr, gA, gB);
+    auto base = [&](int g) { return a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 5 * D; };
     SiteRed<2> sr;
-    site_open<2, 5, S, (RWKV_SPLIT & 4) != 0>(a.st, a.dy, a.x, D, red, xq, w, wb, (size_t)D, sr, true, a.tl);
-    const double sc[2] = {scale_of(sr.amax[0]), scale_of(sr.amax[1])};
+    site_open<2, 5, S, (RWKV_SPLIT & 4) != 0, NB>(a.st, a.dy, a.x, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, sr, true, a.tl);
+    const double sck = scale_of(sr.amax[0]), scr = scale_of(sr.amax[1]);
+    const float Sk = (float)sr.S[0], Sr = (float)sr.S[1];
 
-    int gn = next_group(gctr, g);   // the group whose rows refill the registers during the next dot
-    while (g < g1) {
-        unsigned long long T[5];
-        const bool nv = gn < g1;
-        const int gnn = nv ? next_group(gctr, gn) : g1;
-        const unsigned rsum = a.rs[g * 5 + (lane < 5 ? lane : 0)];   // before the refills (see k_att)
-        group_dot<5, S, PAT_FFN_RK>(w, xq, lane, T, a.w + (size_t)(nv ? gn : 0) * 5 * D, (size_t)D, chunks, nv);
+    // channel g = the four ffn_k rows 4g..4g+3 and the ffn_r row g; lane q < 4 finishes hidden unit 4g + q (relu^2,
+    // pre-scaled for ffn_v), lane 4 the receptance gate -- as soon as the group's sums exist
+    double part = 0.0;
+    float pmax = 0.f;
+    stream_groups<5, S, PAT_FFN_RK, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base,
+        [&](int g) {
+            FfnRKIn in;
+            in.rsum = a.rs[g * 5 + (lane < 5 ? lane : 0)];
+            const int kk = 4 * g + (lane < 4 ? lane : 0);
+            in.rq = a.r_fv[kk]; in.oq = a.o_fv[kk];
+            return in;
+        },
+        [&](int g, const unsigned long long (&T)[5], const FfnRKIn &in) {
+            float val = 0.f;     // lane r finishes row r (the sums are wave-uniform, the row sums per lane)
 #pragma unroll
-        for (int r = 0; r < 5; r++)
-            if (lane == r) stash[(g - g0) * 5 + r] = row_value(T[r], rsum, sc[r < 4 ? 0 : 1]) + (float)sr.S[r < 4 ? 0 : 1];
-        g = gn; gn = gnn;
-    }
-    __syncthreads();
+            for (int r = 0; r < 5; r++) {
+                const float vr = row_value(T[r], in.rsum, r < 4 ? sck : scr) + (r < 4 ? Sk : Sr);
+                val = lane == r ? vr : val;
+            }
+            if (lane < 4) {
+                float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
+                h = h * h;
+                const float hs = h * in.rq;
+                a.hbuf[4 * g + lane] = hs;
+                part += (double)(h * in.oq);
+                pmax = fmaxf(pmax, fabsf(hs));
+            } else if (lane == 4) {
+                a.rgate[g] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
+            }
+        });
     tl_stamp(a.tl, 6);
-
-    double part[1] = {0.0};
-    float pmax[1] = {0.f};
-    for (int t = threadIdx.x; t < 5 * (g1 - g0); t += NT) {
-        const int q = t % 5, i = g0 + t / 5;
-        const float val = stash[t];
-        if (q < 4) {
-            float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
-            h = h * h;
-            const int kk = 4 * i + q;
-            const bool pre = t == (int)threadIdx.x;                      // the first (normally only) trip uses the prefetched pair
-            const float hs = h * (pre ? e_r : a.r_fv[kk]);
-            a.hbuf[kk] = hs;
-            part[0] += (double)(h * (pre ? e_o : a.o_fv[kk]));
-            pmax[0] = fmaxf(pmax[0], fabsf(hs));
-        } else {
-            a.rgate[i] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
-        }
-    }
-    block_sum<1>(part, red + RED_PART);
-    block_max<1>(pmax, red + RED_AUX);
-    if (threadIdx.x == 0) { a.partS[blockIdx.x] = part[0]; a.partM[blockIdx.x] = pmax[0]; }
+    __syncthreads();   // every wave is past its last read of the reduction scratch
+    block_sum_max(part, pmax, red + RED_PART);
+    if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
     tl_stamp(a.tl, 7);
 }
 
@@ -1042,53 +1090,51 @@ struct FfnVArgs {
 };
 
 // ffn_v dequant-GEMV, x += v * sigmoid(r) (rwkv.cu:574-577); commits state dd; opens the next site
-template <int S, int NVN>
+template <int NVN> struct FfnVIn { unsigned rsum; double xold, lw, lb, prevn; float rg; SitePre<NVN> pre; };
+template <int S, int NVN, int NB>
 __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XVD = xvd<S>();
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4, nqd = D >> 2;
+    const int chunks = D >> 4;
     tl_stamp(a.tl, 0);
     const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
 
     const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
-    u32x4 w[4][S];
-    int g = g0 + wave;
+    u32x4 wA[4][S], wB[4][S];
+    int gA, gB;
     unsigned *gctr = group_counter(red);
-    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NW);   // visible behind the prologue's barriers
-    const uint8_t *wb = a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 4 * D;
+    first_groups<NB>(g0, wave, gctr, gA, gB);
+    auto base = [&](int g) { return a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 4 * D; };
     float Sf, amax;   // one scale for the whole 4D hidden vector
-    vec_open<4, 4, S, (RWKV_SPLIT & 8) != 0>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, w, wb, (size_t)D, Sf, amax, a.tl);
+    vec_open<4, 4, S, (RWKV_SPLIT & 8) != 0, NB>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, Sf, amax, a.tl);
     const double sc = scale_of(amax);
     SiteAcc<NVN> acc;
     acc.clear();
 
-    int gn = next_group(gctr, g);   // the group whose rows refill the registers during the next dot
-    while (g < g1) {
-        unsigned long long T[4];
-        const bool nv = gn < g1;
-        const int gnn = nv ? next_group(gctr, gn) : g1;
-        const unsigned rsum = a.rs[g];   // epilogue inputs before the refills (see k_att)
-        const double xold = a.x[g], lw = a.lnw[g], lb = a.lnb[g];
-        const double prevn = NVN == 3 ? a.sprev[so + g] : 0.0;
-        const float rg = a.rgate[g];
-        SitePre<NVN> pre;
-        site_prefetch<NVN>(a.st, g, pre);
-        group_dot<4, S, PAT_PER_ROW>(w, xq, lane, T, a.w + (size_t)(nv ? gn : 0) * 4 * D, (size_t)D, chunks, nv);
-        if (lane == 0) {
-            const float v = row_value((T[0] + T[1]) + (T[2] + T[3]), rsum, sc) + Sf;
-            const double xnew = xold + (double)(v * rg);        // blockout, rwkv.cu:407 (f32 product)
-            a.x[g] = xnew;
-            a.sdd[so + g] = lw * ((xold - mean2) * rstd2) + lb;  // mixffn's state write (:344): ln2 output
-            site_emit<NVN>(pre, a.dy, D, g, xnew, prevn, acc);
-        }
-        g = gn; gn = gnn;
-    }
+    stream_groups<4, S, PAT_PER_ROW, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base,
+        [&](int g) {
+            FfnVIn<NVN> in;
+            in.rsum = a.rs[g];
+            in.xold = a.x[g]; in.lw = a.lnw[g]; in.lb = a.lnb[g];
+            in.prevn = NVN == 3 ? a.sprev[so + g] : 0.0;
+            in.rg = a.rgate[g];
+            site_prefetch<NVN>(a.st, g, in.pre);
+            return in;
+        },
+        [&](int g, const unsigned long long (&T)[4], const FfnVIn<NVN> &in) {
+            if (lane == 0) {
+                const float v = row_value((T[0] + T[1]) + (T[2] + T[3]), in.rsum, sc) + Sf;
+                const double xnew = in.xold + (double)(v * in.rg);               // blockout, rwkv.cu:407 (f32 product)
+                a.x[g] = xnew;
+                a.sdd[so + g] = in.lw * ((in.xold - mean2) * rstd2) + in.lb;     // mixffn's state write (:344): ln2 output
+                site_emit<NVN>(in.pre, a.dy, D, g, xnew, in.prevn, acc);
+            }
+        });
     __syncthreads();   // every wave is past its last read of the reduction scratch
     tl_stamp(a.tl, 6);
     site_publish<NVN, 1>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
@@ -1110,7 +1156,8 @@ struct HeadArgs {
 };
 
 // ln_out site -> head dequant-GEMV -> logits (rwkv.cu:585-589); also per-workgroup argmax partials
-template <int S>
+template <int R> struct HeadIn { unsigned rsr[R]; int row0, shift; };
+template <int S, int NB>
 __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1121,51 +1168,48 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
     float *bval = reinterpret_cast<float *>(xq + XVD);
     unsigned *bidx = reinterpret_cast<unsigned *>(bval + NW);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = D >> 4, nqd = D >> 2;
+    const int chunks = D >> 4;
     const int V = (int)VOCAB;
     const int G = (V + R - 1) / R;
     const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
     const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
     float *lg = a.logits + (size_t)a.ctl->out_row * V;   // read at entry: behind the prologue's barriers it is a cold scalar load
 
-    u32x4 w[R][S];
-    int g = g0 + wave;
+    u32x4 wA[R][S], wB[R][S];
+    int gA, gB;
     unsigned *gctr = group_counter(red);
-    if (threadIdx.x == 0) *gctr = (unsigned)(g0 + NW);   // visible behind the prologue's barriers
-    auto rowbase = [&](int gg) {
-        int row = gg * R;
+    first_groups<NB>(g0, wave, gctr, gA, gB);
+    auto base = [&](int gg) {
+        int row = (gg < g1 ? gg : (g1 > g0 ? g1 - 1 : 0)) * R;
         if (row > V - R) row = V - R;
         return a.w + (size_t)row * D;
     };
-    const uint8_t *wb = rowbase(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0));
     SiteRed<1> sr;
-    site_open<1, R, S, (RWKV_SPLIT & 16) != 0>(a.st, a.dy, a.x, D, red, xq, w, wb, (size_t)D, sr, false, nullptr);
+    site_open<1, R, S, (RWKV_SPLIT & 16) != 0, NB>(a.st, a.dy, a.x, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, sr, false, nullptr);
     const float Sf = (float)sr.S[0];
     const double sc = scale_of(sr.amax[0]);
 
     float best = -INFINITY;
     unsigned besti = 0xffffffffu;
-    int gn = next_group(gctr, g);   // the group whose rows refill the registers during the next dot
-    while (g < g1) {
-        unsigned long long T[R];
-        const bool nv = gn < g1;
-        const int gnn = nv ? next_group(gctr, gn) : g1;
-        int row0 = g * R;
-        const int shift = (row0 > V - R) ? row0 - (V - R) : 0;
-        row0 -= shift;
-        unsigned rsr[R];   // before the refills (see k_att)
+    stream_groups<R, S, PAT_SHARED, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base,
+        [&](int g) {
+            HeadIn<R> in;
+            in.row0 = g * R;
+            in.shift = (in.row0 > V - R) ? in.row0 - (V - R) : 0;
+            in.row0 -= in.shift;
 #pragma unroll
-        for (int r = 0; r < R; r++) rsr[r] = a.rs[row0 + r];
-        group_dot<R, S, PAT_SHARED>(w, xq, lane, T, rowbase(nv ? gn : 0), (size_t)D, chunks, nv);
+            for (int r = 0; r < R; r++) in.rsr[r] = a.rs[in.row0 + r];
+            return in;
+        },
+        [&](int, const unsigned long long (&T)[R], const HeadIn<R> &in) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int i = row0 + r;
-            const float val = row_value(T[r], rsr[r], sc) + Sf;
-            if (lane == r && r >= shift) lg[i] = val;
-            if (i != 0 && (val > best || (val == best && (unsigned)i < besti))) { best = val; besti = (unsigned)i; }
-        }
-        g = gn; gn = gnn;
-    }
+            for (int r = 0; r < R; r++) {
+                const int i = in.row0 + r;
+                const float val = row_value(T[r], in.rsr[r], sc) + Sf;
+                if (lane == r && r >= in.shift) lg[i] = val;
+                if (i != 0 && (val > best || (val == best && (unsigned)i < besti))) { best = val; besti = (unsigned)i; }
+            }
+        });
     if (lane == 0) { bval[wave] = best; bidx[wave] = besti; }
     __syncthreads();
     if (threadIdx.x == 0) {
