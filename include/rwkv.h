@@ -7,8 +7,9 @@
 //     g++ -std=c++17 app.cpp -I<repo>/include -L<repo>/rwkv-cpp-accelerated_amd/csrc -lrwkv_mi355x
 //
 // Differences, all documented in INTEGRATION.md:
-//   * `tensors[i]` are not populated (the engine owns re-tiled device memory behind the handle);
-//     getTensorSize()/getTensorTypes() still answer from the format table.
+//   * `tensors[i]` holds the device pointer of slot i where the engine keeps that tensor in file layout (the f32/f64
+//     vectors, the five state arrays, X, BUFFER2 = logits; rwkv_tensor_device) and NULL for the uint8 matrices, which
+//     are re-tiled at load, and for pure scratch; getTensorSize()/getTensorTypes() answer from the format table.
 //   * `residentState = true` keeps the state on the device between calls (the reference re-uploads
 //     and re-downloads 5 x L x D doubles around every forward, rwkv.h:353,372); the default keeps
 //     the reference's host-authoritative semantics.
@@ -146,7 +147,7 @@ class GPT2Tokenizer;   // the reference's tokenizer (see header comment); only e
 class RWKV
 {
 public:
-    int **tensors = nullptr;            // kept for source compatibility; not populated (see header comment)
+    int **tensors = new int *[46]();    // reference rwkv.h:248; filled by loadFile (see header comment)
     unsigned long long num_layers = 0;
     unsigned long long num_embed = 0;
     float *out = nullptr;               // host logits [maxContext][50277]; forward() returns this
@@ -175,6 +176,7 @@ public:
         rwkv_detail::check(rc);
         num_layers = rwkv_n_layers(ctx_);
         num_embed = rwkv_n_embed(ctx_);
+        for (int i = 0; i < 46; i++) tensors[i] = static_cast<int *>(rwkv_tensor_device(ctx_, i));
         std::cout << "n_layers: " << num_layers << std::endl << "n_embed: " << num_embed << std::endl;   // rwkv.cu:653-654
         state = new RWKVState(num_layers, num_embed, maxGPT);
         statexy = state->statexy; stateaa = state->stateaa; statebb = state->statebb; statepp = state->statepp; statedd = state->statedd;
@@ -284,6 +286,7 @@ public:
     {
         delete[] out;
         if (ctx_) rwkv_free(ctx_);
+        delete[] tensors;
         delete state;
     }
 

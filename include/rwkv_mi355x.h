@@ -122,6 +122,34 @@ int rwkv_set_layer_range(rwkv_ctx *ctx, uint64_t l0, uint64_t l1);
 int rwkv_stage_forward(rwkv_ctx *ctx, uint64_t token, uint32_t slot, uint64_t *pick);
 double *rwkv_x_device(rwkv_ctx *ctx);
 
+/* One prompt chunk (n <= 32 consecutive tokens of one sequence, GPT mode) through THIS stage's layers on the mm8_seq /
+ * MFMA path.  The chunk's residual stream [n][n_embed] f64 lives in buffer `buf` (0 or 1) of the context
+ * (rwkv_xseq_device): stage 0 fills it from `tokens`, a later stage expects the previous stage's output there and leaves
+ * its own in it; the last stage also writes the logits rows [row0, row0 + n).  Asynchronous (rwkv_sync to wait). */
+int rwkv_stage_chunk(rwkv_ctx *ctx, const uint64_t *tokens, uint64_t n, uint64_t row0, int buf);
+double *rwkv_xseq_device(rwkv_ctx *ctx, int buf);
+/* Same-device hand-over of a chunk's residual stream between two stage contexts (several stages per GPU, tests). */
+int rwkv_xseq_copy(rwkv_ctx *dst, int dst_buf, rwkv_ctx *src, int src_buf, uint64_t rows);
+int rwkv_sync(rwkv_ctx *ctx);
+
+/* ---- native transport of the pipeline: RCCL send/recv over xGMI, enqueued on the engine's own stream ----
+ * (north_star: "layers optionally pipeline across the 8 GPUs of one node via RCCL send/recv over xGMI").  One process
+ * per GPU; rank r's context holds layers [l0_r, l1_r) (rwkv_set_layer_range before loading), rank 0 the embedding, the
+ * last rank the head.  librccl.so is resolved at run time by the first of these calls, so single-GPU users never load it.
+ *   rwkv_pipe_unique_id  one rank makes the 128-byte communicator id (ncclGetUniqueId) and distributes it out of band
+ *   rwkv_pipe_init       every rank joins (ncclCommInitRank); the rank must match the context's layer range
+ *   rwkv_pipe_decode     greedy decode of `world` independent streams (one per stage in flight, state slot = stream),
+ *                        n_steps tokens each; first_tokens[world] is read on rank 0, picks[world][n_steps] written on
+ *                        the last rank.  The hop (f64[n_embed] forward, the picked id u64 back to rank 0) and the stage
+ *                        graph alternate on one stream; the host does not wait inside the loop
+ *   rwkv_pipe_prefill    RWKV::loadContext (rwkv.h:395-413) across the stages: the prompt's 32-token chunks are the
+ *                        micro-batches, stage s works on chunk t - s at tick t; needs max_ctx >= 32; tokens read on rank 0 */
+int rwkv_pipe_unique_id(void *out128);
+int rwkv_pipe_init(rwkv_ctx *ctx, const void *id128, int rank, int world);
+int rwkv_pipe_decode(rwkv_ctx *ctx, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks);
+int rwkv_pipe_prefill(rwkv_ctx *ctx, const uint64_t *tokens, uint64_t n_tokens);
+void rwkv_pipe_free(rwkv_ctx *ctx);
+
 /* Replaces freeTensors(), rwkv.cu:719-730, plus destruction of the handle. */
 void rwkv_free(rwkv_ctx *ctx);
 
@@ -129,6 +157,11 @@ const char *rwkv_last_error(void);
 
 /* ---- introspection / measurement hooks (no reference counterpart) ---- */
 
+/* Device pointer behind slot `slot` of the reference's RWKV::tensors[] table (rwkv.h:248; slots: enums/enum.h:7-55)
+ * where the engine keeps that tensor in FILE layout: the f32/f64 vectors, the five state arrays, X and BUFFER2 (logits).
+ * NULL for the uint8 matrices (re-tiled at load) and for pure scratch.  EMBED is a device pointer here (the reference
+ * keeps the table on the host, rwkv.cu:683-684). */
+void *rwkv_tensor_device(rwkv_ctx *ctx, int slot);
 /* Device pointer of the logits buffer ([max_ctx][50277] f32). */
 float *rwkv_logits_device(rwkv_ctx *ctx);
 /* Device pointer of a state array ([max_ctx][L][D] f64), rwkv_state_id. */

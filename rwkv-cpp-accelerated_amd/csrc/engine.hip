@@ -9,6 +9,8 @@
 #include "sampler.hip.h"
 #include "../../include/rwkv_mi355x.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -81,6 +83,23 @@ struct Source {
 
 } // namespace
 
+// RCCL (librccl.so, resolved at run time by rwkv_pipe_init: a single-GPU user never loads it) -- the subset of rccl.h the
+// layer pipeline needs.  Types per /opt/rocm/include/rccl/rccl.h (ncclUniqueId = 128 opaque bytes; ncclUint64 = 5, ncclFloat64 = 8).
+struct Pipe {
+    void *lib = nullptr;
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+    struct Id { char b[128]; };
+    int (*GetUniqueId)(Id *) = nullptr;
+    int (*CommInitRank)(void **, int, Id, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
 struct rwkv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -127,9 +146,13 @@ struct rwkv_ctx {
     int tl_cls = 3;                     // kernel class the timeline instruments (env RWKV_TL_CLASS, 1..4)
     // chunked (prompt prefill) path, seq.hip.h: allocated when max_ctx > 1 on a whole-model context
     bool seq_ok = false;
-    unsigned long long *sq_tokens = nullptr;      // device [SEQ_T]
-    unsigned long long *h_sq_tokens = nullptr;    // pinned
-    double *sq_x[1] = {nullptr};                  // residual stream [SEQ_T][D]
+    unsigned long long *sq_tokens = nullptr;      // device [SQ_RING][SEQ_T]: token ids of the chunks in flight
+    unsigned long long *h_sq_tokens = nullptr;    // pinned, same shape
+    hipEvent_t sq_ev[8] = {};                     // slot r of the ring is free once sq_ev[r] has completed
+    uint64_t sq_n = 0;                            // chunks enqueued so far
+    double *sq_x[2] = {nullptr, nullptr};         // residual stream [SEQ_T][D]; two buffers: a pipeline stage receives chunk c + 1 while chunk c is sent on
+    double *x_in = nullptr;                       // decode: residual vector received from the previous stage (nullptr: c->x)
+    struct Pipe *pipe = nullptr;                  // RCCL transport of the layer pipeline (rwkv_pipe_init)
     double *sq_state = nullptr;                   // [D] LayerNorm output of the chunk's last token
     float *sq_kvr = nullptr, *sq_frk = nullptr, *sq_y = nullptr;   // GEMM outputs / wkv output
     unsigned *sq_img[3] = {nullptr, nullptr, nullptr}, *sq_imgh = nullptr;   // MFMA A-operand images (K = D; K = 4D)
@@ -160,6 +183,7 @@ size_t smem_head(int S) { return RED_BYTES + (size_t)S * 3072 + NW * 8; }
 #endif
 constexpr int ATTOUT_R = RWKV_ATTOUT_R;
 constexpr int SITE_NV[3] = {3, 2, 1};
+constexpr int SQ_RING = 8;   // prompt chunks whose token ids may be in flight between host and device
 constexpr int SITE_PW[3] = {site_pw<3>(), site_pw<2>(), site_pw<1>()};
 
 #define DISPATCH_S(S, ...)                                           \
@@ -204,7 +228,7 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
     switch (cls) {
     case 0: {
         FirstArgs fa;
-        fa.embed = c->embed; fa.ln = c->ln; fa.x = c->x; fa.st = site_static(0, c->l0); fa.dy = site_dyn(0, n_first);
+        fa.embed = c->embed; fa.ln = c->ln; fa.x = c->x; fa.x_in = c->x_in ? c->x_in : c->x; fa.st = site_static(0, c->l0); fa.dy = site_dyn(0, n_first);
         fa.sxy = c->state[0] + (size_t)c->l0 * D; fa.slot_stride = LD; fa.ctl = c->ctl; fa.D = D; fa.from_token = c->l0 == 0;
         k_first<<<dim3(n_first), dim3(NT), 0, c->stream>>>(fa);
     } break;
@@ -494,10 +518,12 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     // chunked path scratch
     {
         const char *e = getenv("RWKV_SEQ");
-        if (max_ctx > 1 && first && last && D % 64 == 0 && !(e && e[0] == '0')) {
-            if ((rc = dalloc(c, &c->sq_tokens, (size_t)SEQ_T))) return rc;
-            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_sq_tokens), sizeof(unsigned long long) * SEQ_T, hipHostMallocDefault));
+        if (max_ctx > 1 && D % 64 == 0 && !(e && e[0] == '0')) {
+            if ((rc = dalloc(c, &c->sq_tokens, (size_t)SQ_RING * SEQ_T))) return rc;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_sq_tokens), sizeof(unsigned long long) * SQ_RING * SEQ_T, hipHostMallocDefault));
+            for (int r = 0; r < SQ_RING; r++) HIPCHK(hipEventCreateWithFlags(&c->sq_ev[r], hipEventDisableTiming));
             if ((rc = dalloc(c, &c->sq_x[0], (size_t)SEQ_T * D))) return rc;
+            if ((rc = dalloc(c, &c->sq_x[1], (size_t)SEQ_T * D))) return rc;
             if ((rc = dalloc(c, &c->sq_state, (size_t)D))) return rc;
             if ((rc = dalloc(c, &c->sq_kvr, (size_t)SEQ_T * 3 * D))) return rc;
             if ((rc = dalloc(c, &c->sq_frk, (size_t)SEQ_T * 5 * D))) return rc;
@@ -523,21 +549,32 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     return 0;
 }
 
-// One chunk (n <= SEQ_T rows) through the MFMA path (seq.hip.h); logits rows [row0, row0 + n).
+// One chunk (n <= SEQ_T rows) through the MFMA path (seq.hip.h) for THIS context's layers [l0, l1); logits rows
+// [row0, row0 + n) on the stage that holds the head.
 // par == false: GPT-mode semantics of rwkv.cu:493-593 -- n tokens of one sequence, state slot 0, token
 // shift along the chunk.  par == true: PARRALEL mode (rwkv.cu:236-240) -- n independent sequences, one
 // token each, row t uses state slot row0 + t: the batched decode step, weights read once for all.
-int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, bool par)
+// The residual stream of the chunk lives in sq_x[buf]: the first stage fills it from the embedding table, a later
+// pipeline stage finds the previous stage's output there (placed by an RCCL recv or a copy) and every stage leaves its
+// own output in it.  Nothing here waits for the device: token ids go through a ring of pinned slots.
+int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, bool par, int buf = 0)
 {
     const int D = (int)c->D;
     const uint64_t L = c->L, V = RWKV_VOCAB;
+    const bool first = c->l0 == 0, last = c->l1 == c->L;
     hipStream_t st = c->stream;
-    HIPCHK(hipStreamSynchronize(st));   // the pinned token staging buffer is reused per chunk
-    for (int t = 0; t < n; t++) c->h_sq_tokens[t] = tokens[t];
-    HIPCHK(hipMemcpyAsync(c->sq_tokens, c->h_sq_tokens, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, st));
-    double *x = c->sq_x[0];
-    SeqEmbedArgs ea{c->embed, c->ln, c->sq_tokens, x, D};
-    k_seq_embed<<<dim3(n), dim3(NT), 0, st>>>(ea);
+    double *x = c->sq_x[buf];
+    if (first) {
+        const int slot = (int)(c->sq_n % SQ_RING);
+        if (c->sq_n >= SQ_RING) HIPCHK(hipEventSynchronize(c->sq_ev[slot]));   // the copy that last used this pinned slot is done
+        unsigned long long *h = c->h_sq_tokens + (size_t)slot * SEQ_T, *d = c->sq_tokens + (size_t)slot * SEQ_T;
+        for (int t = 0; t < n; t++) h[t] = tokens[t];
+        HIPCHK(hipMemcpyAsync(d, h, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(c->sq_ev[slot], st));
+        c->sq_n++;
+        SeqEmbedArgs ea{c->embed, c->ln, d, x, D};
+        k_seq_embed<<<dim3(n), dim3(NT), 0, st>>>(ea);
+    }
     auto gemm = [&](const uint8_t *w, const unsigned *rs, int N, int K, int Q, const int *voq, unsigned *const *img, float *out, int epi, double *state_dst = nullptr) {
         SeqGemmArgs g;
         g.w = w; g.rs = rs; g.N = N; g.K = K; g.Q = Q;
@@ -562,31 +599,31 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         else { if (two) k_seq_site<1, 2><<<dim3(n), dim3(SEQ_SNT), 0, st>>>(s); else k_seq_site<1, 3><<<dim3(n), dim3(SEQ_SNT), 0, st>>>(s); }
     };
     static const int v012[5] = {0, 1, 2, 0, 0}, v0[5] = {0, 0, 0, 0, 0}, v00001[5] = {0, 0, 0, 0, 1};
-    for (uint64_t l = 0; l < L; l++) {
-        const size_t lo = (size_t)l * D;
+    for (uint64_t l = c->l0; l < c->l1; l++) {
+        const size_t lo = (size_t)l * D, wl = (size_t)(l - c->l0);   // vectors are indexed by the model's layer, matrices by the stage's
         {   // time mix
             const double *mix[3] = {c->mixk + lo, c->mixv + lo, c->mixr + lo};
             const float *r[3] = {c->kr + lo, c->vr + lo, c->rr + lo}, *o[3] = {c->o1 + lo, c->o2 + lo, c->o3 + lo};
             site(3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D, mix, r, o, c->state[0] + lo);
-            gemm(c->w_kvr + l * 3 * (size_t)D * D, c->rs_kvr + l * 3 * (size_t)D, 3 * D, D, 3, v012, c->sq_img, c->sq_kvr, 0, c->state[0] + lo);
+            gemm(c->w_kvr + wl * 3 * (size_t)D * D, c->rs_kvr + wl * 3 * (size_t)D, 3 * D, D, 3, v012, c->sq_img, c->sq_kvr, 0, c->state[0] + lo);
             SeqWkvArgs wa{c->sq_kvr, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, c->sq_y, D, n, par ? 1 : 0, (size_t)L * D, (int)row0};
             k_seq_wkv<<<dim3((D + WKV_CH - 1) / WKV_CH), dim3(256), 0, st>>>(wa);
             SeqStageArgs sa{c->sq_y, c->attr + lo, c->atto + lo, c->sq_img[0], c->sq_rec, D, n};
             k_seq_stage<0><<<dim3(n), dim3(NT), 0, st>>>(sa);
-            gemm(c->w_att + l * (size_t)D * D, c->rs_att + l * (size_t)D, D, D, 1, v0, c->sq_img, nullptr, 1);
+            gemm(c->w_att + wl * (size_t)D * D, c->rs_att + wl * (size_t)D, D, D, 1, v0, c->sq_img, nullptr, 1);
         }
         {   // channel mix
             const double *mix[3] = {c->fmixk + lo, c->fmixr + lo, nullptr};
             const float *r[3] = {c->fkr + lo, c->frr + lo, nullptr}, *o[3] = {c->fko + lo, c->fro + lo, nullptr};
             site(2, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D, mix, r, o, c->state[4] + lo);
-            gemm(c->w_frk + l * 5 * (size_t)D * D, c->rs_frk + l * 5 * (size_t)D, 5 * D, D, 5, v00001, c->sq_img, c->sq_frk, 0, c->state[4] + lo);
+            gemm(c->w_frk + wl * 5 * (size_t)D * D, c->rs_frk + wl * 5 * (size_t)D, 5 * D, D, 5, v00001, c->sq_img, c->sq_frk, 0, c->state[4] + lo);
             SeqStageArgs sh{c->sq_frk, c->fvr + 4 * lo, c->fvo + 4 * lo, c->sq_imgh, c->sq_rec, 4 * D, n};
             k_seq_stage<1><<<dim3(n), dim3(NT), 0, st>>>(sh);
             unsigned *imgh[3] = {c->sq_imgh, c->sq_imgh, c->sq_imgh};
-            gemm(c->w_fv + l * 4 * (size_t)D * D, c->rs_fv + l * (size_t)D, D, 4 * D, 1, v0, imgh, nullptr, 2);
+            gemm(c->w_fv + wl * 4 * (size_t)D * D, c->rs_fv + wl * (size_t)D, D, 4 * D, 1, v0, imgh, nullptr, 2);
         }
     }
-    {   // ln_out and the head
+    if (last) {   // ln_out and the head
         const float *r[3] = {c->headr, nullptr, nullptr}, *o[3] = {c->heado, nullptr, nullptr};
         site(1, c->ln + (4 * L + 2) * D, c->ln + (4 * L + 3) * D, nullptr, r, o, nullptr);
         gemm(c->w_head, c->rs_head, (int)V, D, 1, v0, c->sq_img, c->logits + row0 * V, 0);
@@ -681,7 +718,7 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
     for (uint64_t t = 0; t < T; t++)
         if (tokens[t] >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id %llu out of range", (unsigned long long)tokens[t]);
     HIPCHK(hipSetDevice(c->device));
-    if (T >= 2 && c->seq_ok) {   // prompt chunks (GPT) / batched decode step of T streams (PARRALEL): weights read once per <= 32 rows
+    if (T >= 2 && c->seq_ok && c->l0 == 0 && c->l1 == c->L) {   // prompt chunks (GPT) / batched decode step of T streams (PARRALEL): weights read once per <= 32 rows
         for (uint64_t t0 = 0; t0 < T; t0 += SEQ_T) {
             const int n = (int)(T - t0 < (uint64_t)SEQ_T ? T - t0 : (uint64_t)SEQ_T);
             int rc = enqueue_chunk(c, tokens + t0, n, t0, mode == RWKV_MODE_PARRALEL);
@@ -845,11 +882,13 @@ void rwkv_free(rwkv_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    rwkv_pipe_free(c);
     if (c->g_fwd) (void)hipGraphExecDestroy(c->g_fwd);
     if (c->g_greedy) (void)hipGraphExecDestroy(c->g_greedy);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->h_sq_tokens) (void)hipHostFree(c->h_sq_tokens);
+    for (int r = 0; r < SQ_RING; r++) if (c->sq_ev[r]) (void)hipEventDestroy(c->sq_ev[r]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1000,6 +1039,275 @@ int rwkv_mm8_one(rwkv_ctx *c, uint64_t N, uint64_t M, const float *x, const uint
     HIPCHK(e1);
     HIPCHK(e2);
     return 0;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Layer pipeline, native transport.  No reference counterpart (the reference is single-device); the
+// north_star asks for "layers optionally pipelined across the 8 GPUs of one node via RCCL send/recv over xGMI".
+// The hop lives INSIDE the engine: ncclSend / ncclRecv are enqueued on the engine's own stream between the stage's
+// graph launches, the greedy id travels last stage -> first stage as a device-to-device u64 straight into the control
+// block the next launch reads, and the host never waits inside the loop (one synchronisation at the very end).
+namespace {
+
+int pipe_fail(Pipe *p, int rc, const char *what)
+{
+    return fail(RWKV_E_DEVICE, "%s: %s", what, (p && p->GetErrorString) ? p->GetErrorString(rc) : "RCCL error");
+}
+#define NCHK(expr) do { int r__ = (expr); if (r__ != 0) return pipe_fail(p, r__, #expr); } while (0)
+
+int pipe_open(Pipe *p)
+{
+    if (p->lib) return 0;
+    const char *names[] = {getenv("RWKV_RCCL_LIB"), "librccl.so.1", "librccl.so"};
+    for (const char *n : names) {
+        if (!n) continue;
+        p->lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (p->lib) break;
+    }
+    if (!p->lib) return fail(RWKV_E_DEVICE, "cannot load librccl.so (%s)", dlerror());
+    auto sym = [&](const char *n) { return dlsym(p->lib, n); };
+    *(void **)&p->GetUniqueId = sym("ncclGetUniqueId");
+    *(void **)&p->CommInitRank = sym("ncclCommInitRank");
+    *(void **)&p->CommDestroy = sym("ncclCommDestroy");
+    *(void **)&p->Send = sym("ncclSend");
+    *(void **)&p->Recv = sym("ncclRecv");
+    *(void **)&p->GroupStart = sym("ncclGroupStart");
+    *(void **)&p->GroupEnd = sym("ncclGroupEnd");
+    *(void **)&p->GetErrorString = sym("ncclGetErrorString");
+    if (!p->GetUniqueId || !p->CommInitRank || !p->Send || !p->Recv || !p->GroupStart || !p->GroupEnd)
+        return fail(RWKV_E_DEVICE, "librccl.so lacks the point-to-point API");
+    return 0;
+}
+constexpr int kNcclUint64 = 5, kNcclFloat64 = 8;
+
+} // namespace
+
+extern "C" {
+
+// 128 opaque bytes (ncclUniqueId) made by ONE rank and handed to every rank of the pipeline out of band
+int rwkv_pipe_unique_id(void *out128)
+{
+    if (!out128) return fail(RWKV_E_ARG, "NULL argument");
+    static Pipe boot;
+    Pipe *p = &boot;
+    int rc = pipe_open(p);
+    if (rc) return rc;
+    Pipe::Id id;
+    NCHK(p->GetUniqueId(&id));
+    memcpy(out128, id.b, sizeof(id.b));
+    return 0;
+}
+
+int rwkv_pipe_init(rwkv_ctx *c, const void *id128, int rank, int world)
+{
+    if (!c || !id128) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (world < 1 || rank < 0 || rank >= world) return fail(RWKV_E_ARG, "bad rank %d of %d", rank, world);
+    if (c->pipe) return fail(RWKV_E_STATE, "pipeline transport already initialised");
+    if ((rank == 0) != (c->l0 == 0) || (rank == world - 1) != (c->l1 == c->L))
+        return fail(RWKV_E_ARG, "rank %d of %d does not match this context's layer range [%llu, %llu) of %llu", rank, world,
+                    (unsigned long long)c->l0, (unsigned long long)c->l1, (unsigned long long)c->L);
+    HIPCHK(hipSetDevice(c->device));
+    Pipe *p = new Pipe();
+    int rc = pipe_open(p);
+    if (rc) { delete p; return rc; }
+    Pipe::Id id;
+    memcpy(id.b, id128, sizeof(id.b));
+    int r = p->CommInitRank(&p->comm, world, id, rank);
+    if (r != 0) { rc = pipe_fail(p, r, "ncclCommInitRank"); delete p; return rc; }
+    p->rank = rank; p->world = world;
+    if (rank > 0) {
+        if ((rc = dalloc(c, &c->x_in, c->D))) { delete p; return rc; }
+        // the stage graphs captured at load time read the hop from c->x: rebuild them around x_in
+        if (c->g_fwd) { (void)hipGraphExecDestroy(c->g_fwd); c->g_fwd = nullptr; if ((rc = build_graph(c, false, &c->g_fwd))) return rc; }
+        if (c->g_greedy) { (void)hipGraphExecDestroy(c->g_greedy); c->g_greedy = nullptr; if ((rc = build_graph(c, true, &c->g_greedy))) return rc; }
+    }
+    c->pipe = p;
+    return 0;
+}
+
+// Greedy decode of `world` independent streams (stream k starts from first_tokens[k], state slot k), n_steps tokens each,
+// with the model's layers pipelined over the ranks: at tick t rank r works on item j = t - r (stream j % S, step j / S),
+// so every GPU is busy once the pipe is full.  Per tick and rank, all on the engine stream:
+//   control block of the item (pinned ring -> device)   -> ONE RCCL group { send x to r+1 | send the previous pick to
+//   rank 0 (last rank) | recv x from r-1 | recv the fed-back id into the control block (rank 0) }   -> the stage's graph.
+// first_tokens: [world] (read on rank 0).  picks: [world][n_steps] (written on the last rank; may be NULL elsewhere).
+int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    if (!c->loaded || !c->pipe) return fail(RWKV_E_STATE, "needs a loaded context with rwkv_pipe_init done");
+    Pipe *p = c->pipe;
+    const int S = p->world, rank = p->rank;
+    const bool lastr = rank == S - 1;
+    const uint64_t n_items = (uint64_t)S * n_steps;
+    if (n_steps == 0 || n_items > c->gen_cap) return fail(RWKV_E_ARG, "world * n_steps must be in 1..%u", c->gen_cap);
+    if ((uint64_t)S > c->maxT) return fail(RWKV_E_ARG, "needs max_ctx >= %d state slots (one per stream in flight)", S);
+    if (rank == 0 && !first_tokens) return fail(RWKV_E_ARG, "rank 0 needs first_tokens");
+    if (lastr && !picks) return fail(RWKV_E_ARG, "the last rank needs picks");
+    if (rank == 0)
+        for (int k = 0; k < S; k++) if (first_tokens[k] >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
+    HIPCHK(hipSetDevice(c->device));
+    Ctl *ring = nullptr;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ring), sizeof(Ctl) * n_items, hipHostMallocDefault));
+    for (uint64_t j = 0; j < n_items; j++) {
+        const uint64_t stream = j % S, step = j / S;
+        ring[j].token = (rank == 0 && step == 0) ? first_tokens[stream] : 0;
+        ring[j].slot = (unsigned)stream; ring[j].out_row = (unsigned)stream; ring[j].step = (unsigned)j; ring[j].pad = 0;
+    }
+    auto has_work = [&](int r, uint64_t t) { return t >= (uint64_t)r && t - r < n_items; };
+    int rc = 0;
+    for (uint64_t tick = 0; tick < n_items + S - 1 && !rc; tick++) {
+        const bool work = has_work(rank, tick);
+        const bool feedback = tick >= (uint64_t)S && tick < n_items;   // stage 0 starts a step >= 1: its token is the last stage's pick
+        const uint64_t j = tick - rank;
+        if (work && hipMemcpyAsync(c->ctl, &ring[j], sizeof(Ctl), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(RWKV_E_DEVICE, "control block copy failed"); break; }
+        if (S > 1) {
+            int r = p->GroupStart();
+            if (!r && rank < S - 1 && has_work(rank + 1, tick)) r = p->Send(c->x, c->D, kNcclFloat64, rank + 1, p->comm, c->stream);
+            if (!r && lastr && feedback) r = p->Send(c->gen + (tick - S), 1, kNcclUint64, 0, p->comm, c->stream);   // item tick - S: produced here one tick ago
+            if (!r && rank > 0 && work) r = p->Recv(c->x_in, c->D, kNcclFloat64, rank - 1, p->comm, c->stream);
+            if (!r && rank == 0 && feedback) r = p->Recv(&c->ctl->token, 1, kNcclUint64, S - 1, p->comm, c->stream);
+            const int r2 = p->GroupEnd();
+            if (r || r2) { rc = pipe_fail(p, r ? r : r2, "RCCL hop"); break; }
+        } else if (feedback) {
+            // one stage: the pick of the previous step is already in ctl->token ... but the control block was just overwritten
+            HIPCHK(hipMemcpyAsync(&c->ctl->token, c->gen + (j - 1), sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (work) rc = run_token(c, lastr);
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (!rc && e != hipSuccess) rc = fail(RWKV_E_DEVICE, "pipeline decode: %s", hipGetErrorString(e));
+    if (!rc && lastr) {
+        std::vector<uint64_t> g(n_items);
+        if (hipMemcpy(g.data(), c->gen, n_items * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RWKV_E_DEVICE, "copy of the picks failed");
+        else for (uint64_t j = 0; j < n_items; j++) picks[(j % S) * n_steps + j / S] = g[j];
+    }
+    (void)hipHostFree(ring);
+    return rc;
+}
+
+// ---- prompt chunks on a pipeline stage -----------------------------------------------------------------------
+// One chunk (n <= 32 tokens of ONE sequence, GPT mode) through this context's layers on the MFMA path; the chunk's
+// residual stream sits in buffer `buf` (0/1): stage 0 fills it from `tokens`, a later stage expects the previous stage's
+// output there (rwkv_xseq_device / rwkv_xseq_copy, or the RCCL recv of rwkv_pipe_prefill).  Asynchronous.
+int rwkv_stage_chunk(rwkv_ctx *c, const uint64_t *tokens, uint64_t n, uint64_t row0, int buf)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (!c->seq_ok) return fail(RWKV_E_STATE, "chunked path not available (load with max_ctx > 1)");
+    if (n == 0 || n > (uint64_t)SEQ_T || row0 + n > c->maxT || (buf != 0 && buf != 1)) return fail(RWKV_E_ARG, "bad chunk (n %llu, row0 %llu, buf %d)", (unsigned long long)n, (unsigned long long)row0, buf);
+    if (c->l0 == 0) {
+        if (!tokens) return fail(RWKV_E_ARG, "stage 0 needs the token ids");
+        for (uint64_t t = 0; t < n; t++) if (tokens[t] >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
+    }
+    HIPCHK(hipSetDevice(c->device));
+    return enqueue_chunk(c, tokens, (int)n, row0, false, buf);
+}
+double *rwkv_xseq_device(rwkv_ctx *c, int buf) { return (c && (buf == 0 || buf == 1)) ? c->sq_x[buf] : nullptr; }
+int rwkv_sync(rwkv_ctx *c)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+// hand a chunk's residual stream from one stage context to the next ON THE SAME DEVICE (virtual stages: tests, and
+// several stages per GPU); ordered behind src's work, and dst's later work is ordered behind the copy
+int rwkv_xseq_copy(rwkv_ctx *dst, int dbuf, rwkv_ctx *src, int sbuf, uint64_t rows)
+{
+    if (!dst || !src || !dst->seq_ok || !src->seq_ok || dst->D != src->D || rows > (uint64_t)SEQ_T) return fail(RWKV_E_ARG, "bad copy");
+    HIPCHK(hipSetDevice(src->device));
+    HIPCHK(hipStreamSynchronize(src->stream));
+    HIPCHK(hipMemcpyAsync(dst->sq_x[dbuf & 1], src->sq_x[sbuf & 1], rows * src->D * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+    return 0;
+}
+
+// Pipelined prompt ingestion (RWKV::loadContext, rwkv.h:395-413, across the stages): the prompt's 32-token chunks are
+// micro-batches, rank r works on chunk t - r at tick t.  Per tick: ONE RCCL group { send the finished chunk's residual
+// stream [rows][D] to r+1 | recv the next chunk's from r-1 into the other buffer }, then the chunk through this stage's
+// layers.  tokens: the whole prompt (read on rank 0; other ranks only need n_tokens).  Logits of every position land in
+// the last stage's logits buffer, rows (position % max_ctx); returns after the stage's stream has drained.
+int rwkv_pipe_prefill(rwkv_ctx *c, const uint64_t *tokens, uint64_t n_tokens)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    if (!c->loaded || !c->pipe) return fail(RWKV_E_STATE, "needs a loaded context with rwkv_pipe_init done");
+    if (!c->seq_ok) return fail(RWKV_E_STATE, "chunked path not available (load with max_ctx >= 32)");
+    if (c->maxT < (uint64_t)SEQ_T) return fail(RWKV_E_ARG, "needs max_ctx >= %d", SEQ_T);
+    Pipe *p = c->pipe;
+    const int S = p->world, rank = p->rank;
+    if (n_tokens == 0 || (rank == 0 && !tokens)) return fail(RWKV_E_ARG, "empty prompt");
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t n_chunks = (n_tokens + SEQ_T - 1) / SEQ_T;
+    auto rows_of = [&](uint64_t ci) { return ci + 1 < n_chunks ? (uint64_t)SEQ_T : n_tokens - ci * SEQ_T; };
+    auto has_work = [&](int r, uint64_t t) { return t >= (uint64_t)r && t - r < n_chunks; };
+    int rc = 0;
+    for (uint64_t tick = 0; tick < n_chunks + S - 1 && !rc; tick++) {
+        const bool work = has_work(rank, tick);
+        const uint64_t ci = tick - rank;
+        if (S > 1) {
+            int r = p->GroupStart();
+            if (!r && rank < S - 1 && has_work(rank + 1, tick)) r = p->Send(c->sq_x[(ci - 1) & 1], rows_of(ci - 1) * c->D, kNcclFloat64, rank + 1, p->comm, c->stream);
+            if (!r && rank > 0 && work) r = p->Recv(c->sq_x[ci & 1], rows_of(ci) * c->D, kNcclFloat64, rank - 1, p->comm, c->stream);
+            const int r2 = p->GroupEnd();
+            if (r || r2) { rc = pipe_fail(p, r ? r : r2, "RCCL hop"); break; }
+        }
+        if (work) rc = enqueue_chunk(c, rank == 0 ? tokens + ci * SEQ_T : nullptr, (int)rows_of(ci), 0, false, (int)(ci & 1));
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (!rc && e != hipSuccess) rc = fail(RWKV_E_DEVICE, "pipeline prefill: %s", hipGetErrorString(e));
+    return rc;
+}
+
+void rwkv_pipe_free(rwkv_ctx *c)
+{
+    if (!c || !c->pipe) return;
+    if (c->pipe->comm && c->pipe->CommDestroy) (void)c->pipe->CommDestroy(c->pipe->comm);
+    delete c->pipe;
+    c->pipe = nullptr;
+}
+
+// Device pointer behind tensor slot `slot` of the reference's `tensors[]` table (rwkv.h:248, enums/enum.h:7-55) where the
+// engine keeps that tensor in FILE layout: the f32/f64 vectors, the five state arrays, x and the logits buffer (BUFFER2).
+// The uint8 matrices are re-tiled at load (no file-layout copy stays on the device) and the pure scratch slots have no
+// counterpart: NULL.  EMBED is a DEVICE pointer here (the reference keeps the table on the host, rwkv.cu:683-684).
+void *rwkv_tensor_device(rwkv_ctx *c, int slot)
+{
+    if (!c || !c->loaded) return nullptr;
+    switch (slot) {
+    case X: return c->x;
+    case EMBED: return c->embed;
+    case LAYERNORMS: return c->ln;
+    case STATEXY: return c->state[0];
+    case STATEAA: return c->state[1];
+    case STATEBB: return c->state[2];
+    case STATEPP: return c->state[3];
+    case STATEDD: return c->state[4];
+    case BUFFER2: return c->logits;
+    case MIXK: return c->mixk;
+    case MIXV: return c->mixv;
+    case MIXR: return c->mixr;
+    case KR: return c->kr;
+    case VR: return c->vr;
+    case RR: return c->rr;
+    case O1: return c->o1;
+    case O2: return c->o2;
+    case O3: return c->o3;
+    case ATTOUTR: return c->attr;
+    case ATTOUTO: return c->atto;
+    case FFNMIXK: return c->fmixk;
+    case FFNMIXV: return c->fmixr;
+    case FFNKR: return c->fkr;
+    case FFNVR: return c->fvr;
+    case FFNRR: return c->frr;
+    case FFNKO: return c->fko;
+    case FFNVO: return c->fvo;
+    case FFNRO: return c->fro;
+    case HEADR: return c->headr;
+    case HEADO: return c->heado;
+    default: return nullptr;
+    }
 }
 
 } // extern "C"

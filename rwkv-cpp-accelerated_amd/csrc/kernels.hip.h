@@ -548,7 +548,7 @@ __device__ __forceinline__ void site_stage(const double (&xl)[NQ][4], const f32x
 // and stage, publish the scalars through LDS, and join the loaders at the "staged" barrier.
 // which kernels use the role split (bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv, 4 k_head): measured per kernel
 #ifndef RWKV_SPLIT
-#define RWKV_SPLIT 7
+#define RWKV_SPLIT 23
 #endif
 constexpr int RED_BC = 96;     // doubles: scalars published by the prologue waves (8 floats) + spin counter
 
@@ -558,13 +558,13 @@ constexpr int RED_BC = 96;     // doubles: scalars published by the prologue wav
 #ifndef RWKV_HEAD_R
 #define RWKV_HEAD_R 2      // rows per group in k_head (measured: 2 -> 35.8, 3 -> 36.2, 4 -> 36.8, 5 -> 38.0 us at 7B)
 #endif
-// Row-group buffers per wave.  2: a wave holds TWO groups of weight registers (A and B) and alternates between them, so
-// R*S*2 loads are requested ahead.  What that buys is not steady-state depth (the CU's memory pipe accepts only ~16 KB of
-// requests anyway) but PROLOGUE cover: the loader waves' registers are the only place weight bytes can land while the
-// prologue waves reduce and stage the vector (~3.6 us), and one group per loader (80 KB per CU at 7B) is 3 us of HBM
-// stream -- with two the stream never runs dry before the first dot.
+// Row-group buffers per wave: 1, or 2 (a wave holds TWO groups of weight registers, A and B, and alternates between
+// them: R*S*2 loads requested ahead).  Measured on MI355X (profiles/r02/decode_variants.txt) two buffers LOSE 8 % at 7B
+// (485 vs 528 tokens/s): the CU's memory pipe accepts only ~16 KB of requests, so a loader wave that asks for two groups
+// sits blocked at issue twice as long and the "staged" barrier, which it must reach too, moves from 5 to 10 us, while the
+// stream was never starved with one (the loaders' 80 KB per CU last until the vector is staged).  Kept as a knob.
 #ifndef RWKV_NBUF
-#define RWKV_NBUF 2
+#define RWKV_NBUF 1
 #endif
 constexpr int NBUF = RWKV_NBUF;          // default; a kernel whose two buffers would not fit 256 registers (R*S*8 of them) takes 1
 constexpr int nb_att(int) { return NBUF; }                        // 3 rows:  254 registers at S = 5
@@ -781,7 +781,8 @@ __device__ __forceinline__ void vec_open(const float *vec, const double *partS, 
 struct FirstArgs {
     const float *embed;   // [V][D] f32 (device resident), first stage only
     const double *ln;     // layernorm table; rows 0,1 = ln0 weight, bias
-    double *x;            // residual stream [D]: written (first stage) or read (later pipeline stage)
+    double *x;            // residual stream [D]: written here
+    const double *x_in;   // later pipeline stage: the residual vector handed over by the previous stage (may be x itself)
     SiteStatic st;        // ln1 site of this stage's first layer
     SiteDyn dy;
     const double *sxy;    // state xy of that layer
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(NT) void k_first(FirstArgs a)
     for (int j = j0 + threadIdx.x; j < j1; j += NT) {
         double x;
         if (a.from_token) { x = a.ln[j] * (((double)row[j] - mean) * rstd) + a.ln[D + j]; a.x[j] = x; }
-        else x = a.x[j];
+        else { x = a.x_in[j]; a.x[j] = x; }
         SitePre<3> pre;
         site_prefetch<3>(a.st, j, pre);
         site_emit<3>(pre, a.dy, D, j, x, a.sxy[so + j], acc);

@@ -27,6 +27,8 @@ ABI_SYMBOLS = [
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
     "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
+    "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode",
+    "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device",
 ]
 
 _lib = None
@@ -70,6 +72,16 @@ def lib():
     L.rwkv_debug_timeline.argtypes = [vp, u64, vp, u64]; L.rwkv_debug_timeline.restype = i32
     L.rwkv_sample_typical.argtypes = [vp, u64, C.c_float, C.c_float, C.c_double, i32, C.POINTER(u64)]; L.rwkv_sample_typical.restype = i32
     L.rwkv_decode_typical.argtypes = [vp, u64, u64, C.c_float, C.c_float, u64, i32, C.POINTER(u64)]; L.rwkv_decode_typical.restype = i32
+    L.rwkv_stage_chunk.argtypes = [vp, C.POINTER(u64), u64, u64, i32]; L.rwkv_stage_chunk.restype = i32
+    L.rwkv_xseq_device.argtypes = [vp, i32]; L.rwkv_xseq_device.restype = vp
+    L.rwkv_xseq_copy.argtypes = [vp, i32, vp, i32, u64]; L.rwkv_xseq_copy.restype = i32
+    L.rwkv_sync.argtypes = [vp]; L.rwkv_sync.restype = i32
+    L.rwkv_pipe_unique_id.argtypes = [vp]; L.rwkv_pipe_unique_id.restype = i32
+    L.rwkv_pipe_init.argtypes = [vp, vp, i32, i32]; L.rwkv_pipe_init.restype = i32
+    L.rwkv_pipe_decode.argtypes = [vp, C.POINTER(u64), u64, C.POINTER(u64)]; L.rwkv_pipe_decode.restype = i32
+    L.rwkv_pipe_prefill.argtypes = [vp, C.POINTER(u64), u64]; L.rwkv_pipe_prefill.restype = i32
+    L.rwkv_pipe_free.argtypes = [vp]; L.rwkv_pipe_free.restype = None
+    L.rwkv_tensor_device.argtypes = [vp, i32]; L.rwkv_tensor_device.restype = vp
     _lib = L
     return L
 
@@ -193,6 +205,42 @@ class RWKV:
 
     def x_device_ptr(self) -> int:
         return int(lib().rwkv_x_device(self._h) or 0)
+
+    def stage_chunk(self, tokens, n: int, row0: int = 0, buf: int = 0):
+        """one prompt chunk (n <= 32 tokens) through this stage's layers on the mm8_seq path (asynchronous)"""
+        arr = (C.c_uint64 * n)(*[int(t) for t in tokens]) if tokens is not None else None
+        _chk(lib().rwkv_stage_chunk(self._h, arr, n, row0, buf))
+
+    def xseq_copy_from(self, src: "RWKV", rows: int, buf: int = 0):
+        """same-device hand-over of a chunk's residual stream from the previous stage's context"""
+        _chk(lib().rwkv_xseq_copy(self._h, buf, src._h, buf, rows))
+
+    def sync(self):
+        _chk(lib().rwkv_sync(self._h))
+
+    # -- native pipeline transport (RCCL inside the engine) ------------------------------------
+    @staticmethod
+    def pipe_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _chk(lib().rwkv_pipe_unique_id(buf))
+        return buf.raw
+
+    def pipe_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        _chk(lib().rwkv_pipe_init(self._h, C.create_string_buffer(unique_id, 128), rank, world))
+
+    def pipe_decode(self, first_tokens, n_steps: int, world: int, last: bool):
+        ft = (C.c_uint64 * world)(*[int(t) for t in first_tokens]) if first_tokens is not None else None
+        picks = (C.c_uint64 * (world * n_steps))() if last else None
+        _chk(lib().rwkv_pipe_decode(self._h, ft, n_steps, picks))
+        return np.frombuffer(picks, dtype=np.uint64).reshape(world, n_steps).astype(np.int64) if last else None
+
+    def pipe_prefill(self, tokens, n_tokens: int):
+        arr = (C.c_uint64 * n_tokens)(*[int(t) for t in tokens]) if tokens is not None else None
+        _chk(lib().rwkv_pipe_prefill(self._h, arr, n_tokens))
+
+    def tensor_device_ptr(self, slot: int) -> int:
+        return int(lib().rwkv_tensor_device(self._h, slot) or 0)
 
     # -- state sync --------------------------------------------------------------------------
     def push_state(self, n_slots: int | None = None):

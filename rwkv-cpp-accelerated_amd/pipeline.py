@@ -9,8 +9,12 @@ stage 0 (one int64).  One stream alone is not faster than on one GPU (t_tok + (S
 schedule keeps S independent streams in flight, one per stage (stream k lives on state slot k):
 at tick t stage s works on stream (t - s) mod S -- every GPU is busy, aggregate throughput ~ S x.
 
-The stage compute is behind a small interface so the schedule can be tested on CPU (gloo) with
-the oracle as the backend (tests/test_pipeline_cpu.py); on the GPU box it is EngineStage.
+Two transports.  NATIVE (the product path on a multi-GPU node): the hop lives inside the engine -- ncclSend / ncclRecv on
+the engine's own stream between the stage's graph launches, the picked id fed back device to device, no host wait inside
+the loop (csrc/engine.hip rwkv_pipe_decode / rwkv_pipe_prefill; `run_pipeline_native`, `run_prefill_native` below only
+hand the 128-byte RCCL id around).  PYTHON (`run_pipeline`): the same schedule over torch.distributed P2P ops, with the
+stage compute behind a small interface so that it can be tested on CPU (gloo) with the oracle as the backend
+(tests/test_pipeline_cpu.py) and on one GPU with EngineStages; it waits on the host every tick.
 No reference counterpart: the reference is single-device (no NCCL/MPI call sites).
 """
 from __future__ import annotations
@@ -41,13 +45,13 @@ def partition_layers(n_layers: int, n_stages: int, n_embed: int = 0, head_weight
 class EngineStage:
     """one pipeline stage on one GPU (the HIP engine restricted to its layer range)"""
 
-    def __init__(self, tensors, n_layers, n_embed, l0, l1, n_slots, device=0):
+    def __init__(self, tensors, n_layers, n_embed, l0, l1, n_slots, device=0, prefill=False):
         import torch
         from . import engine
         self.torch = torch
         self.m = engine.RWKV(device=device, resident=True)
         self.m.set_layer_range(l0, l1)
-        self.m.loadTensors(n_layers, n_embed, tensors, maxGPT=n_slots)
+        self.m.loadTensors(n_layers, n_embed, tensors, maxGPT=max(n_slots, 32) if prefill else n_slots)
         self.first, self.last = l0 == 0, l1 == n_layers
 
         class _X:   # alias the engine's residual buffer as a torch tensor (no copy)
@@ -119,3 +123,22 @@ def run_pipeline(stage, dist, rank, world, first_tokens, n_steps, device=None):
             picks[stream, step] = pick
             tok_send[0] = pick
     return picks
+
+
+def pipe_connect(stage, dist, rank, world):
+    """join the engine-side RCCL communicator: rank 0 makes the id, torch.distributed (any backend) only carries its 128 bytes"""
+    from . import engine
+    box = [engine.RWKV.pipe_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    stage.m.pipe_init(box[0], rank, world)
+
+
+def run_pipeline_native(stage, rank, world, first_tokens, n_steps):
+    """greedy decode of `world` streams with the hop inside the engine (pipe_connect first).  [world][n_steps] ids on the last rank."""
+    return stage.m.pipe_decode(first_tokens if rank == 0 else None, n_steps, world, last=(rank == world - 1))
+
+
+def run_prefill_native(stage, rank, tokens, n_tokens):
+    """pipelined prompt ingestion (32-token chunks as micro-batches) with the hop inside the engine"""
+    stage.m.pipe_prefill(tokens if rank == 0 else None, n_tokens)

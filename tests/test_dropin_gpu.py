@@ -2,9 +2,13 @@
 the authoring container (oracle/Makefile: storygen = against this repo's include/rwkv.h, storygen_l2 = against the
 reference's own rwkv.h + integration/rwkv_backend_mi355x.cpp), on a 169M-shaped model.bin (BASELINE config 1: L=12, D=768).
 
-storygen is interactive and samples with typical(out, 0.8, 0.7): it is driven with one line on stdin and a model whose
-logits are so peaked that the typical set is the argmax alone, so its output is deterministic and can be compared id for
-id with the Python engine replaying the same call sequence (storygen.cpp:29-73).  The tokenizer is the reference's own
+storygen is interactive and SAMPLES with typical(out, 0.8, 0.7) (as compiled: a draw from softmax(logits), see
+include/rwkv_sampler.h) from its own random generator, so its ids cannot be predicted; the test drives it with one line
+on stdin, decodes the ids it printed, and REPLAYS them through the Python engine along the same call sequence
+(storygen.cpp:29-73), teacher-forced: every printed id must be a token the engine's logits at that point give real
+probability to, and -- the test model's logits are peaked -- most of them must be the argmax.  A state or plumbing error
+anywhere (tokenizer ids, loadContext chunks, sub-state snapshot, the doubled last prompt token, out[0] = -99) makes the
+replayed probabilities collapse.  The tokenizer is the reference's own
 GPT2Tokenizer (compiled in); its vocab files are not available on the GPU box, so the test writes a byte-level vocab
 (256 byte tokens + one unique 5-letter string per remaining id, no merges) -- enough for encode() and decode()."""
 import json
@@ -82,13 +86,15 @@ def world(built, tmp_path_factory):
     write_vocab(str(root / "include" / "rwkv" / "tokenizer" / "vocab"))
     (root / "converter").mkdir()
     L, D = mf.SHAPES["169M"]
-    t = mf.synthetic_tensors(L, D, seed=169, head_scale=3.0e5)      # typical set == {argmax}: see module docstring
+    t = mf.synthetic_tensors(L, D, seed=169, head_scale=120.0)      # peaked logits, yet exp(logit) finite: NumCpp's softmax subtracts no max
     path = str(root / "converter" / "model.bin")
     mf.write_bin(path, L, D, t)
     return dict(cwd=str(cwd), model=path, L=L, D=D)
 
 
-def expected_ids(world, n):
+def replay(world, ids):
+    """feed storygen's own ids back through the engine along storygen's call sequence; returns the probability the engine's
+    logits gave each id and whether it was the argmax"""
     from rwkv_cpp_accelerated_amd import engine
     m = engine.RWKV(resident=False)          # host-authoritative state, as the reference's RWKV::forward (rwkv.h:353,372)
     m.loadFile(world["model"], 1)
@@ -97,15 +103,15 @@ def expected_ids(world, n):
         m.forward(tk)
     for tk in encode(USER_LINE + "\n\n### Response:"):
         m.forward(tk)
-    tk, out, pmax = prompt[-1], [], 1.0       # storygen feeds the prompt's last token again (storygen.cpp:33,57,65)
-    for _ in range(n):
+    tk, probs, top = prompt[-1], [], []       # storygen feeds the prompt's last token again (storygen.cpp:33,57,65)
+    for want in ids:
         lg = m.forward(tk)[: mf.VOCAB].astype(np.float64)
         lg[0] = -99.0
         e = np.exp(lg - lg.max())
-        pmax = min(pmax, float(e.max() / e.sum()))
-        tk = int(np.argmax(lg)); out.append(tk)
+        probs.append(float(e[want] / e.sum())); top.append(int(np.argmax(lg)) == want)
+        tk = want
     m.close()
-    return out, pmax
+    return np.array(probs), np.array(top)
 
 
 @pytest.mark.parametrize("exe", ["storygen_mi355x", "storygen_l2"])
@@ -135,7 +141,8 @@ def test_reference_storygen_runs_on_the_engine(world, exe):
     gen = gen[mt.end(): gen.index(b"continue? (y/n):")]
     got = decode_stream(gen)
     assert len(got) >= 150
-    want, pmax = expected_ids(world, len(got))
-    assert pmax > 0.7, "test model not peaked enough: typical(0.8, 0.7) would keep more than the argmax"
-    assert got == want
+    assert all(0 < g < mf.VOCAB for g in got)
+    probs, top = replay(world, got)
+    assert probs.min() > 1e-9, f"id {got[int(probs.argmin())]} at step {int(probs.argmin())} has probability {probs.min():.2e} under the engine's logits"
+    assert top.mean() > 0.7, f"only {top.mean():.2f} of the sampled ids are the argmax of peaked logits"
     assert len(set(got)) > 20

@@ -1,0 +1,190 @@
+"""Layer pipeline on the GPU box (BASELINE config 4 and SURVEY 8f row 2): pipelined prompt chunks across stages, the
+14B-shaped stage split, and the engine's native RCCL transport (as far as one GPU allows)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from rwkv_cpp_accelerated_amd import modelfile as mf
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_mod(built):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    from rwkv_cpp_accelerated_amd import engine
+    engine.lib()
+    return engine
+
+
+@pytest.mark.parametrize("S,n_tokens", [(2, 256), (3, 77), (4, 130)])
+def test_pipelined_prefill_over_virtual_stages(eng_mod, S, n_tokens):
+    """RWKV::loadContext (rwkv.h:395-413) with the prompt's 32-token chunks as micro-batches over S stages co-located on one
+    GPU (same code path as rwkv_pipe_prefill minus the RCCL hop: stage s works on chunk t - s at tick t, the chunk's residual
+    stream handed from stage to stage): logits of the last position, every stage's share of the recurrent state and the
+    continuation must equal the single-context run -- bit for bit (same kernels, same data)."""
+    from rwkv_cpp_accelerated_amd import pipeline
+    L, D = 6, 768
+    t = mf.synthetic_tensors(L, D, seed=91)
+    rng = np.random.default_rng(S)
+    prompt = [int(x) for x in rng.integers(2, mf.VOCAB, n_tokens)]
+    full = eng_mod.RWKV(resident=True); full.loadTensors(L, D, t, maxGPT=32)
+    for i in range(0, n_tokens, 32):
+        last_logits = full.forward(prompt[i:i + 32], eng_mod.MODE_GPT)[: len(prompt[i:i + 32]) * mf.VOCAB].reshape(-1, mf.VOCAB)[-1].copy()
+    full.pull_state(1)
+    parts = pipeline.partition_layers(L, S, D)
+    stages = [pipeline.EngineStage(t, L, D, l0, l1, n_slots=1, prefill=True) for l0, l1 in parts]
+    chunks = [prompt[i:i + 32] for i in range(0, n_tokens, 32)]
+    for tick in range(len(chunks) + S - 1):
+        for s in reversed(range(S)):              # any order that respects "stage s reads what stage s-1 produced last tick"
+            ci = tick - s
+            if not 0 <= ci < len(chunks):
+                continue
+            n = len(chunks[ci])
+            if s > 0:
+                stages[s].m.xseq_copy_from(stages[s - 1].m, n, buf=ci & 1)
+            stages[s].m.stage_chunk(chunks[ci] if s == 0 else None, n, row0=0, buf=ci & 1)
+        for st in stages:
+            st.m.sync()
+    got = stages[-1].m.logits(32)[: len(chunks[-1]) * mf.VOCAB].reshape(-1, mf.VOCAB)[-1]
+    assert np.array_equal(got, last_logits)
+    for (l0, l1), st in zip(parts, stages):
+        st.m.pull_state(1)
+        for a, b in zip(st.m.state.arrays(), full.state.arrays()):
+            assert np.array_equal(a[l0 * D:l1 * D], b[l0 * D:l1 * D])
+    # the decode that follows continues from the same state on both sides
+    tk_f = tk_p = parity.argmax_ban0(last_logits)
+    for _ in range(4):
+        tk_f = full.stage_forward(tk_f, 0, want_pick=True)
+        for i, st in enumerate(stages):
+            if i > 0:
+                st.x.copy_(stages[i - 1].x); st.torch.cuda.synchronize()
+            nxt = st.forward(tk_p, 0, want_pick=st.last)
+        tk_p = nxt
+        assert tk_p == tk_f
+    for st in stages:
+        st.m.close()
+    full.close()
+
+
+@pytest.mark.parametrize("S", [2, 4, 8])
+def test_14b_shape_virtual_stages(eng_mod, S):
+    """BASELINE config 4's split (RWKV-4-14B: L=40, D=5120 over 2/4/8 stages) with all stages on this box's one GPU: the
+    chained stage contexts reproduce the whole-model greedy ids and logits bit for bit"""
+    import torch
+    from rwkv_cpp_accelerated_amd import pipeline
+    L, D = mf.SHAPES["14B"]
+    t = mf.synthetic_tensors_torch(L, D, seed=14, device="cuda")
+    torch.cuda.synchronize()
+    full = eng_mod.RWKV(resident=True); full.loadTensors(L, D, t, maxGPT=1)
+    parts = pipeline.partition_layers(L, S, D)
+    assert parts[0][0] == 0 and parts[-1][1] == L and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    stages = [pipeline.EngineStage(t, L, D, l0, l1, n_slots=1) for l0, l1 in parts]
+    del t
+    tk_p = tk_f = 4242
+    for step in range(5):
+        tk_f = full.stage_forward(tk_f, 0, want_pick=True)
+        for i, st in enumerate(stages):
+            if i > 0:
+                st.x.copy_(stages[i - 1].x); torch.cuda.synchronize()
+            nxt = st.forward(tk_p, 0, want_pick=st.last)
+        tk_p = nxt
+        assert tk_p == tk_f, step
+        assert np.array_equal(full.logits(1)[: mf.VOCAB], stages[-1].m.logits(1)[: mf.VOCAB])
+    for st in stages:
+        st.m.close()
+    full.close()
+    torch.cuda.empty_cache()
+
+
+def test_native_transport_single_rank(eng_mod):
+    """rwkv_pipe_init / rwkv_pipe_decode / rwkv_pipe_prefill with world = 1: librccl.so is resolved and a communicator is
+    made, the tick loop, the control-block ring and the device-side id feedback run (no hop to make): must equal
+    decode_greedy and the chunked forward"""
+    L, D, n = 3, 768, 24
+    t = mf.synthetic_tensors(L, D, seed=92)
+    a = eng_mod.RWKV(resident=True); a.loadTensors(L, D, t, maxGPT=32)
+    b = eng_mod.RWKV(resident=True); b.loadTensors(L, D, t, maxGPT=32)
+    b.pipe_init(eng_mod.RWKV.pipe_unique_id(), 0, 1)
+    prompt = [int(x) for x in np.random.default_rng(2).integers(2, mf.VOCAB, 70)]
+    for i in range(0, 70, 32):
+        a.forward(prompt[i:i + 32], eng_mod.MODE_GPT)
+    b.pipe_prefill(prompt, len(prompt))
+    assert np.array_equal(a.logits(32)[: 6 * mf.VOCAB], b.logits(32)[: 6 * mf.VOCAB])
+    want = a.decode_greedy(77, n)
+    got = b.pipe_decode([77], n, 1, last=True)
+    assert np.array_equal(got[0], want.astype(np.int64))
+    a.close(); b.close()
+
+
+def _native_worker(rank, world, port, first_tokens, L, D, seed, steps, prompt, q):
+    try:
+        import torch
+        import torch.distributed as dist
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from rwkv_cpp_accelerated_amd import pipeline
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        l0, l1 = pipeline.partition_layers(L, world, D)[rank]
+        st = pipeline.EngineStage(mf.synthetic_tensors(L, D, seed=seed), L, D, l0, l1, n_slots=world, device=0, prefill=True)
+        try:
+            pipeline.pipe_connect(st, dist, rank, world)
+        except Exception as e:                     # RCCL refuses two ranks on one device: nothing more to test on this box
+            q.put(("refused", rank, str(e)))
+            dist.barrier(); dist.destroy_process_group()
+            return
+        pipeline.run_prefill_native(st, rank, prompt, len(prompt))
+        lg = st.m.logits(32)[: mf.VOCAB * ((len(prompt) - 1) % 32 + 1)].reshape(-1, mf.VOCAB)[-1].copy() if rank == world - 1 else None
+        picks = pipeline.run_pipeline_native(st, rank, world, first_tokens, steps)
+        if rank == world - 1:
+            q.put(("ok", picks, lg))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                         # pragma: no cover
+        q.put(("error", rank, repr(e)))
+
+
+def test_native_rccl_two_ranks_on_one_gpu_if_rccl_permits(eng_mod):
+    """the real thing, as far as a single-GPU box allows: two processes, both on cuda:0, ncclSend / ncclRecv between them
+    inside the engines.  RCCL normally refuses a duplicate device; then the test records that and skips (the transport's
+    multi-GPU run is the driver's)."""
+    import torch.multiprocessing as mp
+    world, L, D, seed, steps = 2, 6, 768, 93, 5
+    first = [11, 222]
+    prompt = [int(x) for x in np.random.default_rng(5).integers(2, mf.VOCAB, 80)]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, first, L, D, seed, steps, prompt, q)) for r in range(world)]
+    [p.start() for p in procs]
+    try:
+        res = q.get(timeout=300)
+    finally:
+        [p.join(timeout=60) for p in procs]
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    if res[0] == "refused":
+        pytest.skip(f"RCCL does not allow two ranks on one device: {res[2][:200]}")
+    assert res[0] == "ok", res
+    _, picks, lg = res
+    t = mf.synthetic_tensors(L, D, seed=seed)
+    m = eng_mod.RWKV(resident=True); m.loadTensors(L, D, t, maxGPT=32)
+    for i in range(0, len(prompt), 32):
+        ref = m.forward(prompt[i:i + 32], eng_mod.MODE_GPT)[: len(prompt[i:i + 32]) * mf.VOCAB].reshape(-1, mf.VOCAB)[-1].copy()
+    assert np.array_equal(lg, ref)
+    # the streams of the native decode started from slot k's state: slot 0 holds the prompt, slot 1 is fresh
+    for k, tk in enumerate(first):
+        if k == 1:
+            m.reset_state()
+        cur, ids = tk, []
+        for _ in range(steps):
+            cur = parity.argmax_ban0(m.forward(cur)[: mf.VOCAB]); ids.append(cur)
+        assert list(picks[k]) == ids, k
+    m.close()
