@@ -236,25 +236,36 @@ def main():
 
 
 def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
-    """N > 1: the model's layers are pipelined across the N GPUs (stage s = rank s holds layers
-    [l0_s, l1_s), stage 0 the embedding, the last stage the head); the hop is an RCCL send/recv of the
-    residual vector (f64[D]) over xGMI.  N independent greedy streams are in flight, one per stage, so
-    every GPU is busy: a "step" = one token of every stream.  value = N*K tokens / max-over-ranks time."""
+    """N > 1: the model's layers are pipelined across the N GPUs (stage s = rank s holds layers [l0_s, l1_s), stage 0 the
+    embedding, the last stage the head).  The hop is INSIDE the engine: ncclSend / ncclRecv (RCCL over xGMI) of the residual
+    vector (f64[D]) on the engine's own stream, the picked id fed back device to device, no host wait per tick
+    (rwkv_pipe_decode).  N independent greedy streams are in flight, one per stage, so every GPU is busy: a "step" = one
+    token of every stream.  value = N*K tokens / max-over-ranks time.  torch.distributed only carries the 128-byte RCCL id,
+    the barriers and the timing reduction.  (RWKV_BENCH_BACKEND=gloo: the Python schedule over torch P2P ops instead.)"""
     import numpy as np
     import torch
     from rwkv_cpp_accelerated_amd import modelfile as mf, pipeline
     tensors = mf.synthetic_tensors_torch(L, D, seed=args.seed, device=dev)     # same seed on every rank: one model
     l0, l1 = pipeline.partition_layers(L, world, D)[rank]
-    stage = pipeline.EngineStage(tensors, L, D, l0, l1, n_slots=world, device=local_rank)
+    native = dist.get_backend() == "nccl" and os.environ.get("RWKV_BENCH_NATIVE", "1") == "1"
+    stage = pipeline.EngineStage(tensors, L, D, l0, l1, n_slots=world, device=local_rank, prefill=native and args.prefill_chunks > 0)
     del tensors
     torch.cuda.empty_cache()
+    if native:
+        pipeline.pipe_connect(stage, dist, rank, world)
     rng = np.random.default_rng(1)
     first = [int(x) for x in rng.integers(2, mf.VOCAB, world)]
+
+    def run(n):
+        if native:
+            return pipeline.run_pipeline_native(stage, rank, world, first, n)
+        return pipeline.run_pipeline(stage, dist, rank, world, first, n, device=dev)
+
     if args.warmup > 0:
-        pipeline.run_pipeline(stage, dist, rank, world, first, max(1, args.warmup // world), device=dev)
+        run(max(1, args.warmup // world))
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pipeline.run_pipeline(stage, dist, rank, world, first, args.steps, device=dev)
+    run(args.steps)
     dist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -262,7 +273,27 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     dt = float(tmax.item())
     B_tok = mf.bytes_per_token(L, D)
     tok_s = world * args.steps / dt
+    # per-stage roofline: every token of every stream crosses every stage, so stage s streams its share of the bytes
+    # world * K times in dt
+    mine = torch.tensor([stage.m.bytes_per_token() * world * args.steps / dt / 1e9], device=dev, dtype=torch.float64)
+    per_stage = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(per_stage, mine)
+    per_stage = [round(float(v.item()), 1) for v in per_stage]
+    prefill = None
+    if native and args.prefill_chunks > 0:
+        n_tok = 32 * max(args.prefill_chunks, 2 * world)
+        prompt = [int(x) for x in rng.integers(2, mf.VOCAB, n_tok)]
+        pipeline.run_prefill_native(stage, rank, prompt, n_tok)
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipeline.run_prefill_native(stage, rank, prompt, n_tok)
+        dist.barrier(); torch.cuda.synchronize()
+        tp = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        prefill = dict(prompt_tokens=n_tok, tokens_per_s=round(n_tok / float(tp.item()), 1),
+                       note="pipelined RWKV::loadContext: 32-token chunks as micro-batches, stage s on chunk t - s (rwkv_pipe_prefill)")
     if rank == 0:
+        worst = min(per_stage)
         print(json.dumps(dict(
             metric="tokens/sec single-stream RWKV-4 uint8 greedy decode", value=round(tok_s, 2), unit="tokens/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 5),
@@ -271,11 +302,16 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
             data="synthetic",
             config=dict(workload=f"RWKV-4-Raven-{args.model} uint8 greedy decode (L={L}, D={D}), layers pipelined over {world} GPUs, "
                                  f"{world} independent streams in flight (one per stage), {args.steps} tokens per stream",
-                        parallelism=f"pp{world}: layer pipeline, RCCL send/recv of the residual vector (f64[{D}]) between stages, "
-                                    "greedy id fed back last->first stage",
+                        parallelism=f"pp{world}: layer pipeline, " + ("RCCL ncclSend/ncclRecv of the residual vector inside the engine, on its stream"
+                                                                       if native else "torch.distributed P2P ops (Python schedule)") +
+                                    f" (f64[{D}] between stages, greedy id fed back last->first stage)",
                         layer_ranges=pipeline.partition_layers(L, world, D), bytes_per_token=B_tok),
+            roofline=dict(bound="hbm", kernel="stage (all decode kernels of a rank's layers)", achieved=worst, peak=HBM_PEAK_GBPS, unit="GB/s",
+                          frac=round(worst / HBM_PEAK_GBPS, 4), traffic=None, per_stage_GBps=per_stage,
+                          method="algorithmic bytes of the stage's layers per token x tokens through the stage / wall time of the timed region; "
+                                 "the slowest stage is quoted"),
             end_to_end=dict(achieved_GBps=round(B_tok * tok_s / 1e9, 1), frac_of_aggregate_peak=round(B_tok * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)),
-            per_stream_tokens_per_s=round(args.steps / dt, 2))), flush=True)
+            per_stream_tokens_per_s=round(args.steps / dt, 2), prefill=prefill)), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
