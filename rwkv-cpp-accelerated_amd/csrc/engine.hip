@@ -121,7 +121,6 @@ struct rwkv_ctx {
     float *siteP[3] = {nullptr, nullptr, nullptr};    // [L or 1][D][PW]
     double *siteTC[3] = {nullptr, nullptr, nullptr};  // [L or 1][NV]
     float *siteMC[3] = {nullptr, nullptr, nullptr};   // [L or 1][NV]
-    float *siteMX[3] = {nullptr, nullptr, nullptr};   // [L or 1][16] static bounds for the chunked path (k_site_static)
     float *siteB[3] = {nullptr, nullptr, nullptr};    // [NV][D]   per-token, emitted by the row owners
     double *sitePD[3] = {nullptr, nullptr, nullptr};  // [grid][8] per-workgroup partial tuples
     float *sitePF[3] = {nullptr, nullptr, nullptr};   // [grid][4]
@@ -155,15 +154,14 @@ struct rwkv_ctx {
     double *x_in = nullptr;                       // decode: residual vector received from the previous stage (nullptr: c->x)
     struct Pipe *pipe = nullptr;                  // RCCL transport of the layer pipeline (rwkv_pipe_init)
     double *sq_state = nullptr;                   // [D] LayerNorm output of the chunk's last token
-    float *sq_kvr = nullptr, *sq_frk = nullptr, *sq_y = nullptr;   // GEMM outputs / wkv output
+    float *sq_y = nullptr;                        // gated wkv output [SEQ_T][D]
     unsigned *sq_img[3] = {nullptr, nullptr, nullptr}, *sq_imgh = nullptr;   // MFMA A-operand images (K = D; K = 4D)
-    SeqPart *sq_qpart = nullptr, *sq_qparth = nullptr;   // quantisation records [3][SEQ_T][SEQ_O] (K = D vectors), [SEQ_T][SEQ_O] (K = 4D)
-    float *sq_amax = nullptr, *sq_amaxh = nullptr;       // [3][SEQ_T], [SEQ_T]
+    SeqPart *sq_qpart = nullptr, *sq_qparta = nullptr, *sq_qparth = nullptr;   // quantisation records: site vectors [3][SEQ_T][SEQ_O], att_out input [SEQ_T][SEQ_O], ffn_v input [SEQ_T][SEQ_O]
     SeqStat *sq_stat = nullptr;                          // [SEQ_T][SEQ_O] LayerNorm partial statistics
-    double *sq_part = nullptr;                           // [SEQ_O][SEQ_T][D] K-slice partial sums of att_out / ffn_v
-    float *sq_pmaxA = nullptr, *sq_pmaxF = nullptr;      // per-producer partial maxima: wkv workgroups, ffn k/r GEMM workgroups
-    // MFMA B-operand images of the matrices (second resident copy, chunked path only)
+    float *sq_pk3 = nullptr, *sq_pk5 = nullptr, *sq_pk1 = nullptr;   // per-slice partial values [SEQ_O][SEQ_T][3D / 5D / D] of the K/V/R, ffn k/r, att_out | ffn_v GEMMs
+    // second resident copy of the matrices (chunked path only): MFMA B-operand images, row sums per octant of K
     uint8_t *b_kvr = nullptr, *b_att = nullptr, *b_frk = nullptr, *b_fv = nullptr, *b_head = nullptr;
+    unsigned *r8_kvr = nullptr, *r8_att = nullptr, *r8_frk = nullptr, *r8_fv = nullptr, *r8_head = nullptr;
     std::vector<void *> allocs;
 };
 
@@ -356,6 +354,19 @@ template <typename T> int upload(rwkv_ctx *c, Source &src, int slot, T **dst)
     return 0;
 }
 
+int seq_smem_limits()
+{
+    int rc = 0;
+#define SEQ_ALLOW(TAG, NTW, NKB, MTS, NVS) if (!rc) rc = allow_smem(k_seq_gemm<TAG, NTW, NKB, MTS, NVS>, seq_gemm_smem(NTW, NKB, MTS, NVS))
+    SEQ_ALLOW(0, 3, 8, false, 3); SEQ_ALLOW(0, 3, 10, false, 2);
+    SEQ_ALLOW(1, 1, 8, false, 1); SEQ_ALLOW(1, 1, 10, false, 1);
+    SEQ_ALLOW(2, 5, 8, true, 2); SEQ_ALLOW(2, 4, 10, true, 2);
+    SEQ_ALLOW(3, 1, 8, false, 1); SEQ_ALLOW(3, 1, 10, false, 1);
+#undef SEQ_ALLOW
+    if (!rc) rc = allow_smem(k_seq_gemm_ks, SEQ_KS_SMEM);
+    return rc;
+}
+
 int set_smem_limits(rwkv_ctx *c)
 {
     const int S = c->S;
@@ -423,14 +434,13 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         if ((rc = dalloc(c, &c->siteP[k], n * D * SITE_PW[k]))) return rc;
         if ((rc = dalloc(c, &c->siteTC[k], n * SITE_NV[k]))) return rc;
         if ((rc = dalloc(c, &c->siteMC[k], n * SITE_NV[k]))) return rc;
-        if ((rc = dalloc(c, &c->siteMX[k], n * 16))) return rc;
         HIPCHK(hipMemsetAsync(c->siteP[k], 0, n * D * SITE_PW[k] * sizeof(float), c->stream));
     }
     {
         auto build = [&](int k, uint64_t ll, int m, const double *lnw, const double *lnb, const double *mix, const float *r, const float *o) {
             k_site_static<<<dim3(1), dim3(NT), 0, c->stream>>>(lnw, lnb, mix, r, o, c->siteC[k] + (size_t)ll * SITE_NV[k] * D,
                                                                c->siteP[k] + (size_t)ll * D * SITE_PW[k], c->siteTC[k] + (size_t)ll * SITE_NV[k],
-                                                               c->siteMC[k] + (size_t)ll * SITE_NV[k], c->siteMX[k] + (size_t)ll * 16, SITE_NV[k], m, SITE_PW[k], (int)D);
+                                                               c->siteMC[k] + (size_t)ll * SITE_NV[k], m, SITE_PW[k], (int)D);
         };
         for (uint64_t l = l0; l < l1; l++) {
             const size_t lo = (size_t)l * D;
@@ -533,8 +543,6 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
             if ((rc = dalloc(c, &c->sq_x[0], (size_t)SEQ_T * D))) return rc;
             if ((rc = dalloc(c, &c->sq_x[1], (size_t)SEQ_T * D))) return rc;
             if ((rc = dalloc(c, &c->sq_state, (size_t)D))) return rc;
-            if ((rc = dalloc(c, &c->sq_kvr, (size_t)SEQ_T * 3 * D))) return rc;
-            if ((rc = dalloc(c, &c->sq_frk, (size_t)SEQ_T * 5 * D))) return rc;
             if ((rc = dalloc(c, &c->sq_y, (size_t)SEQ_T * D))) return rc;
             for (int k = 0; k < 3; k++) {
                 if ((rc = dalloc(c, &c->sq_img[k], a_image_bytes(D) / 4))) return rc;
@@ -543,37 +551,34 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
             if ((rc = dalloc(c, &c->sq_imgh, a_image_bytes(4 * D) / 4))) return rc;
             HIPCHK(hipMemsetAsync(c->sq_imgh, 0, a_image_bytes(4 * D), c->stream));
             if ((rc = dalloc(c, &c->sq_qpart, (size_t)3 * SEQ_T * SEQ_O))) return rc;
+            if ((rc = dalloc(c, &c->sq_qparta, (size_t)SEQ_T * SEQ_O))) return rc;
             if ((rc = dalloc(c, &c->sq_qparth, (size_t)SEQ_T * SEQ_O))) return rc;
-            if ((rc = dalloc(c, &c->sq_amax, (size_t)3 * SEQ_T))) return rc;
-            if ((rc = dalloc(c, &c->sq_amaxh, (size_t)SEQ_T))) return rc;
-            if ((rc = dalloc(c, &c->sq_stat, (size_t)SEQ_T * SEQ_O))) return rc;
-            if ((rc = dalloc(c, &c->sq_part, (size_t)SEQ_O * SEQ_T * D))) return rc;
-            if ((rc = dalloc(c, &c->sq_pmaxA, (size_t)((D + WKV_CH - 1) / WKV_CH) * SEQ_T))) return rc;
-            if ((rc = dalloc(c, &c->sq_pmaxF, (size_t)c->grid * SEQ_T))) return rc;
-            // every row of the element-wise buffers is defined even when a chunk is short
             HIPCHK(hipMemsetAsync(c->sq_qpart, 0, sizeof(SeqPart) * 3 * SEQ_T * SEQ_O, c->stream));
+            HIPCHK(hipMemsetAsync(c->sq_qparta, 0, sizeof(SeqPart) * SEQ_T * SEQ_O, c->stream));
             HIPCHK(hipMemsetAsync(c->sq_qparth, 0, sizeof(SeqPart) * SEQ_T * SEQ_O, c->stream));
-            HIPCHK(hipMemsetAsync(c->sq_amax, 0, sizeof(float) * 3 * SEQ_T, c->stream));
-            HIPCHK(hipMemsetAsync(c->sq_amaxh, 0, sizeof(float) * SEQ_T, c->stream));
-            // second resident copy of the matrices: MFMA B-operand images (seq.hip.h k_bimage)
+            if ((rc = dalloc(c, &c->sq_stat, (size_t)SEQ_T * SEQ_O))) return rc;
+            if ((rc = dalloc(c, &c->sq_pk3, (size_t)SEQ_O * SEQ_T * 3 * D))) return rc;
+            if ((rc = dalloc(c, &c->sq_pk5, (size_t)SEQ_O * SEQ_T * 5 * D))) return rc;
+            if ((rc = dalloc(c, &c->sq_pk1, (size_t)SEQ_O * SEQ_T * D))) return rc;
+            // second resident copy of the matrices: MFMA B-operand images (seq.hip.h k_bimage) + row sums per octant of K
             {
-                const uint64_t CB = (D + 15) / 16, KBd = D / 64;
-                auto bimage = [&](const uint8_t *w_t, uint8_t **dst, uint64_t layers, uint64_t N, uint64_t K, int Q) -> int {
+                auto second = [&](const uint8_t *w_t, uint8_t **bdst, unsigned **rdst, uint64_t layers, uint64_t N, uint64_t K, int Q) -> int {
                     const uint64_t nch = (N + Q - 1) / Q, cb = (nch + 15) / 16, per = (uint64_t)Q * cb * 16 * K;
-                    int r2 = dalloc(c, dst, layers * per);
+                    int r2 = dalloc(c, bdst, layers * per);
+                    if (!r2) r2 = dalloc(c, rdst, layers * SEQ_O * N);
                     if (r2) return r2;
                     for (uint64_t l = 0; l < layers; l++) {
                         const uint64_t units = per / 16;
-                        k_bimage<<<dim3((unsigned)((units + 255) / 256)), dim3(256), 0, c->stream>>>(w_t + l * N * K, *dst + l * per, (int)N, (int)K, Q, (int)cb);
+                        k_bimage<<<dim3((unsigned)((units + 255) / 256)), dim3(256), 0, c->stream>>>(w_t + l * N * K, *bdst + l * per, (int)N, (int)K, Q, (int)cb);
+                        k_rowsum8<<<dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream>>>(w_t + l * N * K, *rdst + l * SEQ_O * N, (int)N, (int)K);
                     }
                     return 0;
                 };
-                (void)CB; (void)KBd;
-                if ((rc = bimage(c->w_kvr, &c->b_kvr, nl, 3 * D, D, 3))) return rc;
-                if ((rc = bimage(c->w_att, &c->b_att, nl, D, D, 1))) return rc;
-                if ((rc = bimage(c->w_frk, &c->b_frk, nl, 5 * D, D, 5))) return rc;
-                if ((rc = bimage(c->w_fv, &c->b_fv, nl, D, 4 * D, 1))) return rc;
-                if (last && (rc = bimage(c->w_head, &c->b_head, 1, V, D, 1))) return rc;
+                if ((rc = second(c->w_kvr, &c->b_kvr, &c->r8_kvr, nl, 3 * D, D, 3))) return rc;
+                if ((rc = second(c->w_att, &c->b_att, &c->r8_att, nl, D, D, 1))) return rc;
+                if ((rc = second(c->w_frk, &c->b_frk, &c->r8_frk, nl, 5 * D, D, 5))) return rc;
+                if ((rc = second(c->w_fv, &c->b_fv, &c->r8_fv, nl, D, 4 * D, 1))) return rc;
+                if (last && (rc = second(c->w_head, &c->b_head, &c->r8_head, 1, V, D, 1))) return rc;
                 HIPCHK(hipGetLastError());
             }
             c->seq_ok = true;
@@ -581,7 +586,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     if ((rc = set_smem_limits(c))) return rc;
-    if (c->seq_ok && (rc = allow_smem(k_seq_gemm_tw<0>, SEQ_TW_SMEM)) || (rc = allow_smem(k_seq_gemm_tw<1>, SEQ_TW_SMEM))) return rc;
+    if (c->seq_ok && (rc = seq_smem_limits())) return rc;
     const char *nograph = getenv("RWKV_NO_GRAPH");
     if (!(nograph && nograph[0] == '1')) {
         if ((rc = build_graph(c, false, &c->g_fwd))) return rc;
@@ -619,91 +624,87 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
     }
     const size_t LD = (size_t)L * D;
     const int egrid = n * SEQ_O;
-    // K over the waves (K/V/R, ffn k/r, head)
-    auto gemm_ks = [&](const uint8_t *bimg, const unsigned *rs, int N, int K, int Q, const int *voq, unsigned *const *img, const SeqPart *qpart,
-                       const float *amaxv, float *out, int epi, const float *r_next, double *state_dst, int tag) {
-        SeqGemmArgs g;
-        g.bimg = reinterpret_cast<const u32x4 *>(bimg); g.rs = rs; g.N = N; g.K = K; g.Q = Q;
-        for (int q = 0; q < 5; q++) g.vec_of_q[q] = q < Q ? voq[q] : 0;
+    const bool big = (D >> 6) > 8 * SEQ_O;       // octants of K = D longer than 8 k-blocks (D > 4096): the NKB = 10 instances
+    static const int v012[5] = {0, 1, 2, 0, 0}, v0[5] = {0, 0, 0, 0, 0}, v00001[5] = {0, 0, 0, 0, 1};
+    // kind 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v: tile-per-wave GEMM over the 8 K-slices, partial values into pk
+    auto gemm = [&](int kind, const uint8_t *bimg, const unsigned *rs8, int N, int K, int Q, const int *voq, unsigned *const *img, const SeqPart *qpart,
+                    float *pk, double *state_dst) {
+        SeqGemmArgs g{};
+        g.bimg = reinterpret_cast<const u32x4 *>(bimg); g.rs8 = rs8; g.N = N; g.K = K; g.Q = Q;
+        for (int q = 0; q < 5; q++) g.vec_of_q[q] = q < Q ? voq[q] : voq[Q - 1];
         for (int k = 0; k < 3; k++) g.img[k] = reinterpret_cast<const u32x4 *>(img[k]);
-        g.part = qpart; g.amaxv = amaxv; g.out = out; g.epi = epi; g.r_next = r_next; g.pmax = c->sq_pmaxF; g.T = n;
+        g.part = qpart; g.pk = pk; g.out = nullptr; g.T = n;
         g.cp_src = c->sq_state; g.cp_dst = state_dst; g.cp_n = (state_dst && !par) ? D : 0;   // GPT: commit the site's state behind it
-        if (tag == 0) k_seq_gemm_ks<0><<<dim3(c->grid), dim3(SEQ_NT), 0, st>>>(g);
-        else if (tag == 1) k_seq_gemm_ks<1><<<dim3(c->grid), dim3(SEQ_NT), 0, st>>>(g);
-        else k_seq_gemm_ks<2><<<dim3(c->grid), dim3(SEQ_NT), 0, st>>>(g);
+        const int nch = (N + Q - 1) / Q, ntiles = Q * ((nch + 15) / 16);
+        const int ntw_max = kind == 0 ? 3 : kind == 2 ? (big ? 4 : 5) : 1;
+        const int RB = (ntiles + SEQ_NW * ntw_max - 1) / (SEQ_NW * ntw_max);
+        g.ntw = (ntiles + SEQ_NW * RB - 1) / (SEQ_NW * RB);
+        const dim3 grid(SEQ_O * RB), blk(SEQ_NT);
+#define SEQ_LAUNCH(TAG, NTW, NKB, MTS, NVS) k_seq_gemm<TAG, NTW, NKB, MTS, NVS><<<grid, blk, seq_gemm_smem(NTW, NKB, MTS, NVS), st>>>(g)
+        if (kind == 0) { if (big) SEQ_LAUNCH(0, 3, 10, false, 2); else SEQ_LAUNCH(0, 3, 8, false, 3); }
+        else if (kind == 1) { if (big) SEQ_LAUNCH(1, 1, 10, false, 1); else SEQ_LAUNCH(1, 1, 8, false, 1); }
+        else if (kind == 2) { if (big) SEQ_LAUNCH(2, 4, 10, true, 2); else SEQ_LAUNCH(2, 5, 8, true, 2); }
+        else { if (big) SEQ_LAUNCH(3, 1, 10, false, 1); else SEQ_LAUNCH(3, 1, 8, false, 1); }
+#undef SEQ_LAUNCH
     };
-    // one tile per wave, K over the XCDs (att_out, ffn_v): partial sums into sq_part
-    auto gemm_tw = [&](const uint8_t *bimg, int N, int K, const unsigned *img, int tag) {
-        SeqGemmTwArgs g;
-        g.bimg = reinterpret_cast<const u32x4 *>(bimg); g.img = reinterpret_cast<const u32x4 *>(img); g.part = c->sq_part; g.N = N; g.K = K; g.T = n;
-        g.cp_src = nullptr; g.cp_dst = nullptr; g.cp_n = 0;
-        const int nblk = ((N + 15) / 16 + SEQ_NW - 1) / SEQ_NW;
-        if (tag == 0) k_seq_gemm_tw<0><<<dim3(SEQ_O * nblk), dim3(SEQ_NT), SEQ_TW_SMEM, st>>>(g);
-        else k_seq_gemm_tw<1><<<dim3(SEQ_O * nblk), dim3(SEQ_NT), SEQ_TW_SMEM, st>>>(g);
-    };
-    auto resid = [&](int mode, const unsigned *rs, const SeqPart *qpart, const float *amaxv, const double *state_next) {
+    auto resid = [&](int mode, const SeqPart *qpart) {
         SeqResidArgs r{};
-        r.x = x; r.part = c->sq_part; r.rs = rs; r.qpart = qpart; r.amaxv = amaxv; r.gate = c->sq_frk;
-        r.state = state_next; r.slot_stride = LD; r.slot0 = (int)row0; r.par = par ? 1 : 0; r.stat = c->sq_stat; r.D = D; r.T = n;
+        r.x = x; r.pk = c->sq_pk1; r.qpart = qpart; r.pk_gate = c->sq_pk5; r.qpart_gate = c->sq_qpart + (size_t)1 * SEQ_T * SEQ_O;   // ffn r = vector 1 of the ln2 site
+        r.stat = c->sq_stat; r.D = D; r.T = n;
         if (mode == 0) k_seq_resid<0><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(r);
         else if (mode == 1) k_seq_resid<1><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(r);
         else k_seq_resid<2><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(r);
     };
-    auto site = [&](int nv, int k, uint64_t ll, const double *lnw, const double *lnb, const double *const *mix, const float *const *r, const float *const *o,
-                    double *state) {
+    auto site = [&](int nv, const double *lnw, const double *lnb, const double *const *mix, const float *const *r, const float *const *o, double *state) {
         SeqSiteArgs s{};
         s.x = x; s.stat = c->sq_stat; s.lnw = lnw; s.lnb = lnb;
         for (int q = 0; q < nv; q++) { s.mix[q] = mix ? mix[q] : nullptr; s.r[q] = r[q]; s.o[q] = o[q]; }
-        s.mxs = c->siteMX[k] + (size_t)ll * 16;
         s.state = state; s.state_new = (state && !par) ? c->sq_state : nullptr;
         s.par = par && state; s.state_par = state; s.slot_stride = LD; s.slot0 = (int)row0;
         for (int q = 0; q < 3; q++) s.img[q] = c->sq_img[q];
-        s.part = c->sq_qpart; s.amaxv = c->sq_amax; s.D = D; s.T = n;
+        s.part = c->sq_qpart; s.D = D; s.T = n;
         if (nv == 3) k_seq_site<3><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(s);
         else if (nv == 2) k_seq_site<2><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(s);
         else k_seq_site<1><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(s);
     };
-    static const int v012[5] = {0, 1, 2, 0, 0}, v0[5] = {0, 0, 0, 0, 0}, v00001[5] = {0, 0, 0, 0, 1};
     unsigned *imgh3[3] = {c->sq_imgh, c->sq_imgh, c->sq_imgh};
     const int n_wkv = (D + WKV_CH - 1) / WKV_CH;
     const uint64_t CBd = ((uint64_t)D + 15) / 16;
-    // LayerNorm statistics of the incoming residual stream (embedding rows, or the previous stage's output) and the bound
-    // of the first site's shift source
-    resid(0, nullptr, nullptr, nullptr, c->state[0] + (size_t)c->l0 * D);
+    resid(0, nullptr);     // LayerNorm statistics of the incoming residual stream (embedding rows, or the previous stage's output)
     for (uint64_t l = c->l0; l < c->l1; l++) {
         const size_t lo = (size_t)l * D, wl = (size_t)(l - c->l0);   // vectors are indexed by the model's layer, matrices by the stage's
         {   // time mix
             const double *mix[3] = {c->mixk + lo, c->mixv + lo, c->mixr + lo};
             const float *r[3] = {c->kr + lo, c->vr + lo, c->rr + lo}, *o[3] = {c->o1 + lo, c->o2 + lo, c->o3 + lo};
-            site(3, 0, l, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D, mix, r, o, c->state[0] + lo);
-            gemm_ks(c->b_kvr + wl * 3 * CBd * 16 * D, c->rs_kvr + wl * 3 * (size_t)D, 3 * D, D, 3, v012, c->sq_img, c->sq_qpart, c->sq_amax,
-                    c->sq_kvr, 0, nullptr, c->state[0] + lo, 0);
-            SeqWkvArgs wa{c->sq_kvr, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, c->attr + lo, c->sq_y, c->sq_pmaxA, D, n, par ? 1 : 0, LD, (int)row0};
+            site(3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D, mix, r, o, c->state[0] + lo);
+            gemm(0, c->b_kvr + wl * 3 * CBd * 16 * D, c->r8_kvr + wl * SEQ_O * 3 * (size_t)D, 3 * D, D, 3, v012, c->sq_img, c->sq_qpart, c->sq_pk3, c->state[0] + lo);
+            SeqWkvArgs wa{c->sq_pk3, c->sq_qpart, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, c->sq_y, D, n, par ? 1 : 0, LD, (int)row0};
             k_seq_wkv<<<dim3(n_wkv), dim3(SEQ_T * WKV_CH), 0, st>>>(wa);
-            SeqStageArgs sa{c->sq_y, c->attr + lo, c->atto + lo, c->sq_pmaxA, n_wkv, c->sq_img[0], c->sq_qpart, c->sq_amax, D, n};
+            SeqStageArgs sa{c->sq_y, nullptr, nullptr, c->attr + lo, c->atto + lo, c->sq_img[0], c->sq_qparta, D, n};
             k_seq_stage<0><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(sa);
-            gemm_tw(c->b_att + wl * CBd * 16 * D, D, D, c->sq_img[0], 0);
-            resid(1, c->rs_att + wl * (size_t)D, c->sq_qpart, c->sq_amax, c->state[4] + lo);     // x = f32(x) + att_out; statistics for ln2
+            gemm(1, c->b_att + wl * CBd * 16 * D, c->r8_att + wl * SEQ_O * (size_t)D, D, D, 1, v0, c->sq_img, c->sq_qparta, c->sq_pk1, nullptr);
+            resid(1, c->sq_qparta);     // x = f32(x) + att_out; statistics for ln2
         }
         {   // channel mix
             const double *mix[3] = {c->fmixk + lo, c->fmixr + lo, nullptr};
             const float *r[3] = {c->fkr + lo, c->frr + lo, nullptr}, *o[3] = {c->fko + lo, c->fro + lo, nullptr};
-            site(2, 1, l, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D, mix, r, o, c->state[4] + lo);
-            gemm_ks(c->b_frk + wl * 5 * CBd * 16 * D, c->rs_frk + wl * 5 * (size_t)D, 5 * D, D, 5, v00001, c->sq_img, c->sq_qpart, c->sq_amax,
-                    c->sq_frk, 3, c->fvr + 4 * lo, c->state[4] + lo, 1);
-            SeqStageArgs sh{c->sq_frk, c->fvr + 4 * lo, c->fvo + 4 * lo, c->sq_pmaxF, c->grid, c->sq_imgh, c->sq_qparth, c->sq_amaxh, 4 * D, n};
+            site(2, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D, mix, r, o, c->state[4] + lo);
+            gemm(2, c->b_frk + wl * 5 * CBd * 16 * D, c->r8_frk + wl * SEQ_O * 5 * (size_t)D, 5 * D, D, 5, v00001, c->sq_img, c->sq_qpart, c->sq_pk5, c->state[4] + lo);
+            SeqStageArgs sh{nullptr, c->sq_pk5, c->sq_qpart, c->fvr + 4 * lo, c->fvo + 4 * lo, c->sq_imgh, c->sq_qparth, 4 * D, n};
             k_seq_stage<1><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(sh);
-            gemm_tw(c->b_fv + wl * CBd * 16 * 4 * D, D, 4 * D, c->sq_imgh, 1);
-            // x += ffn_v * sigmoid(r); statistics for the next site: ln1 of layer l + 1 (shift source: its state xy) or ln_out
-            resid(2, c->rs_fv + wl * (size_t)D, c->sq_qparth, c->sq_amaxh, l + 1 < c->l1 ? c->state[0] + lo + D : nullptr);
+            gemm(3, c->b_fv + wl * CBd * 16 * 4 * D, c->r8_fv + wl * SEQ_O * (size_t)D, D, 4 * D, 1, v0, imgh3, c->sq_qparth, c->sq_pk1, nullptr);
+            resid(2, c->sq_qparth);     // x += ffn_v * sigmoid(r); statistics for the next site
         }
     }
     if (last) {   // ln_out and the head
         const float *r[3] = {c->headr, nullptr, nullptr}, *o[3] = {c->heado, nullptr, nullptr};
-        site(1, 2, 0, c->ln + (4 * L + 2) * D, c->ln + (4 * L + 3) * D, nullptr, r, o, nullptr);
-        gemm_ks(c->b_head, c->rs_head, (int)V, D, 1, v0, c->sq_img, c->sq_qpart, c->sq_amax, c->logits + row0 * V, 0, nullptr, nullptr, 2);
+        site(1, c->ln + (4 * L + 2) * D, c->ln + (4 * L + 3) * D, nullptr, r, o, nullptr);
+        SeqGemmArgs g{};
+        g.bimg = reinterpret_cast<const u32x4 *>(c->b_head); g.rs8 = c->r8_head; g.N = (int)V; g.K = D; g.Q = 1;
+        for (int k = 0; k < 3; k++) g.img[k] = reinterpret_cast<const u32x4 *>(c->sq_img[k]);
+        g.part = c->sq_qpart; g.out = c->logits + row0 * V; g.T = n;
+        k_seq_gemm_ks<<<dim3(c->grid), dim3(SEQ_NT), SEQ_KS_SMEM, st>>>(g);
     }
-    (void)imgh3;
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -1380,14 +1380,13 @@ __global__ void k_prep_wkv(const double *decay, const double *bonus, double *uw,
 // C[m][j] = r mix lnw; producer side P[j][PW] holds BL = r mix lnb, BP = r (1 - mix) and the same
 // with the offset o in place of the scale r (Co, BoL, BoP) at [m*5 + 0..4].  mix == nullptr means
 // no token shift (ln_out -> head).  Products are formed in f64 and stored as f32.  TC[m] = sum of the
-// stored Co, maxC[m] = max |C|.  MX (chunked path, seq.hip.h k_seq_site): [4 m + 0..2] = max|C|, max|BL|, max|BP| of this
-// vector, [4 NV + 0..1] = max|lnw|, max|lnb|.  One workgroup per call.
+// stored Co, maxC[m] = max |C|.  One workgroup per call.
 __global__ __launch_bounds__(NT) void k_site_static(const double *lnw, const double *lnb, const double *mix, const float *r, const float *o,
-                                                    float *C, float *P, double *TC, float *maxC, float *MX, int NV, int m, int PW, int D)
+                                                    float *C, float *P, double *TC, float *maxC, int m, int PW, int D)
 {
     __shared__ double red[RED_BYTES / 8];
     double s[1] = {0.0};
-    float mx[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float mx[1] = {0.f};
     for (int j = threadIdx.x; j < D; j += NT) {
         const double mk = mix ? mix[j] : 1.0, rr = (double)r[j], oo = (double)o[j];
         const float c = (float)(rr * mk * lnw[j]), co = (float)(oo * mk * lnw[j]);
@@ -1400,19 +1399,10 @@ __global__ __launch_bounds__(NT) void k_site_static(const double *lnw, const dou
         pp[4] = (float)(oo * (1.0 - mk));
         s[0] += (double)co;
         mx[0] = fmaxf(mx[0], fabsf(c));
-        mx[1] = fmaxf(mx[1], fabsf(pp[0]) * 1.0000002f);
-        mx[2] = fmaxf(mx[2], fabsf(pp[1]) * 1.0000002f);
-        mx[3] = fmaxf(mx[3], (float)fabs(lnw[j]) * 1.0000002f);
-        mx[4] = fmaxf(mx[4], (float)fabs(lnb[j]) * 1.0000002f);
     }
     block_sum<1>(s, red + RED_STATS);
-    __syncthreads();
-    block_max<5>(mx, red + RED_STATS);
-    if (threadIdx.x == 0) {
-        TC[m] = s[0]; maxC[m] = mx[0];
-        MX[4 * m] = mx[0] * 1.0000002f; MX[4 * m + 1] = mx[1]; MX[4 * m + 2] = mx[2]; MX[4 * m + 3] = 0.f;
-        if (m == 0) { MX[4 * NV] = mx[3]; MX[4 * NV + 1] = mx[4]; }
-    }
+    block_max<1>(mx, red + RED_MAX);
+    if (threadIdx.x == 0) { TC[m] = s[0]; maxC[m] = mx[0]; }
 }
 
 } // namespace rwkvk

@@ -14,16 +14,18 @@
 // and let every GEMM workgroup re-read the whole activation image):
 //   * weights have a second resident copy in the MFMA B-OPERAND IMAGE [16-row tile][k-block of 64][lane][16 B], signed,
 //     so a wave's weight load is one contiguous 1 KiB and needs no cross-lane transposition (7 GB more at 7B of 288 GB);
-//   * k_seq_gemm_ks (K/V/R, ffn k/r, head: many rows per workgroup): 8 waves take the k-blocks round-robin over the
-//     workgroup's <= 5 row tiles, operands two k-blocks ahead, exact f64 meeting in LDS, epilogue in the kernel;
-//   * k_seq_gemm_tw (att_out, ffn_v: 4096 rows only, where every workgroup re-reading the whole activation image moved
-//     6x the weight bytes through L2): 8 K-SLICES, slice j on XCD j (blockIdx % 8), a workgroup = 128 rows x one slice,
-//     one row tile per wave, the slice's activation image staged once in LDS for all 8 waves; exact f64 partial sums
-//     [8][T][N] that the following element-wise kernel adds up;
+//   * every row of an activation vector is quantised per OCTANT (an eighth of K, whole k-blocks) with the octant's own
+//     exact max|.|: no workgroup needs a row-wide maximum, and the scales are finer than one per row;
+//   * k_seq_gemm (K/V/R, att_out, ffn k/r, ffn_v): K-SLICE j = octant j runs on XCD j (blockIdx % 8, so the 32 workgroups
+//     of an XCD read the SAME slice of the activation image through their L2 and every workgroup reads an eighth of it);
+//     a workgroup = a block of row tiles x one slice, each wave owns NTW row tiles for the whole slice, ALL its weight
+//     loads (NTW x k-blocks KiB) are requested up front, the slice's activation image goes through LDS once for all 8 waves;
+//     output: per-slice partial values scale_j (M_j + corrections_j) as f32 [8][T][N], added up by the consumer;
+//   * k_seq_gemm_ks (head: 50277 rows, partials would be 50 MB): wave w takes octant w of K over the workgroup's <= 5
+//     row tiles, per-octant values meet in LDS, epilogue in the kernel;
 //   * element-wise work runs on (row, octant) workgroups -- 256 of them for a full chunk: k_seq_resid (partial sums ->
-//     residual update + LayerNorm partial statistics), k_seq_site (LayerNorm + token shift + quantisation with the
-//     decode path's upper bound for the fixed-point scale, so ONE statistics round suffices), k_seq_stage (relu^2 / gated
-//     wkv -> quantisation), k_seq_wkv (the recurrence).
+//     residual update + LayerNorm partial statistics), k_seq_site (LayerNorm + token shift + quantisation), k_seq_stage
+//     (relu^2 / gated wkv -> quantisation), k_seq_wkv (the recurrence).
 //
 //   k_seq_embed   rwkv.cu:513-524   embedding rows + ln0 for the chunk
 //   k_seq_resid   :548-553,:574-577,:407   residual updates behind att_out / ffn_v; LayerNorm statistics (:40-57)
@@ -49,21 +51,26 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ size_t a_unit(int kb, int mt, int limb, int lane) { return (((size_t)kb * 2 + mt) * 3 + limb) * 64 + lane; }
 __host__ __device__ inline size_t a_image_bytes(size_t K) { return (K / 64) * 2 * 3 * 64 * 16; }
 
-// quantisation record of one (vector, row): scale from the row's amax, the limb / offset sums as per-octant partials
-struct SeqPart { double cA; float So; float pad; };       // cA: 128 * sum_b 256^b * sum_k (limb_b[k] - 128) over the octant; So: sum_k f[k] * o[k]
-struct SeqStat { double sx, sxx; float amax, pmax; };     // per (row, octant): sum x, sum x^2, max|x|, max|shift source| (state rows only)
-struct SeqRec { double scale, cA; float So; };
-__device__ __forceinline__ SeqRec seq_rec(const SeqPart *part, const float *amaxv, int m, int t)
+// quantisation record of one (vector, row, octant): amax -> the octant's fixed-point scale;
+// cA = 128 * sum_b 256^b * sum_k (limb_b[k] - 128) over the octant; So = sum_k f[k] * o[k] over the octant
+struct SeqPart { double cA; float So; float amax; };
+struct SeqStat { double sx, sxx; };                       // per (row, octant): sum x, sum x^2
+// offset term of (vector m, row t): the octants' So added up (f32, fixed order)
+__device__ __forceinline__ float seq_so(const SeqPart *part, int m, int t)
 {
-    SeqRec r;
-    r.scale = scale_of(amaxv[m * SEQ_T + t]);
-    double ca = 0.0;
-    float so = 0.f;
     const SeqPart *p = part + ((size_t)m * SEQ_T + t) * SEQ_O;
+    float so = 0.f;
 #pragma unroll
-    for (int o = 0; o < SEQ_O; o++) { ca += p[o].cA; so += p[o].So; }
-    r.cA = ca; r.So = so;
-    return r;
+    for (int o = 0; o < SEQ_O; o++) so += p[o].So;
+    return so;
+}
+// value of a GEMM output from its per-slice partials pk[SEQ_O][SEQ_T][N] (each already scaled and corrected) and the offset term
+__device__ __forceinline__ float seq_val(const float *pk, int N, int t, size_t n, float so)
+{
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < SEQ_O; q++) v += (double)pk[((size_t)q * SEQ_T + t) * N + n];
+    return (float)v + so;
 }
 // octant o of K elements, in units of 64 (a k-block never straddles two octants): [k0, k1)
 __device__ __forceinline__ void octant_range(int K, int o, int &k0, int &k1)
@@ -138,7 +145,7 @@ __device__ __forceinline__ void eblock_max(float (&v)[K], double *redd)
     }
 }
 // limb sums + offset sum of one (vector, row, octant) -> its SeqPart; nk = elements of the octant
-__device__ __forceinline__ void seq_finish(unsigned (&ls)[3], double So, int nk, SeqPart *dst, double *red)
+__device__ __forceinline__ void seq_finish(unsigned (&ls)[3], double So, int nk, float amax, SeqPart *dst, double *red)
 {
     double s[4] = {(double)ls[0], (double)ls[1], (double)ls[2], So};   // the limb sums of a thread are < 2^32: exact in f64
     eblock_sum<4>(s, red);
@@ -147,7 +154,7 @@ __device__ __forceinline__ void seq_finish(unsigned (&ls)[3], double So, int nk,
 #pragma unroll
         for (int b = 0; b < 3; b++) { ca += f * (s[b] - 128.0 * (double)nk); f *= 256.0; }
         SeqPart p;
-        p.cA = ca; p.So = (float)s[3]; p.pad = 0.f;
+        p.cA = ca; p.So = (float)s[3]; p.amax = amax;
         *dst = p;
     }
 }
@@ -173,19 +180,15 @@ __global__ __launch_bounds__(NT) void k_seq_embed(SeqEmbedArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// (row, octant) workgroups: fold the K-slice partial sums of att_out / ffn_v into the residual stream and emit the
+// (row, octant) workgroups: fold the K-slice partial values of att_out / ffn_v into the residual stream and emit the
 // LayerNorm partial statistics of the new x.  MODE 0: statistics only (first layer of a chunk); 1: att_out
 // (x = f32(x) + v, rwkv.cu:548-553); 2: ffn_v (x += v * sigmoid(r), :574-577,:407,:212).
 struct SeqResidArgs {
     double *x;                   // [T][D]
-    const double *part;          // [SEQ_O][T][D] exact integer partial sums of the GEMM (K-slice major)
-    const unsigned *rs;          // [D] weight row sums
-    const SeqPart *qpart;        // records of the GEMM's input vector (vector 0): [T][SEQ_O]
-    const float *amaxv;          // [T]
-    const float *gate;           // MODE 2: ffn k/r GEMM output [T][5D], r of channel j at [t][5 j + 4]
-    const double *state;         // shift source of the NEXT site for rows that take it from the recurrent state:
-    size_t slot_stride;          //   GPT: row 0 <- state (slot 0); PARRALEL: row t <- state + (slot0 + t) * slot_stride; nullptr: none
-    int slot0, par;
+    const float *pk;             // [SEQ_O][SEQ_T][D] per-slice partial values of the GEMM
+    const SeqPart *qpart;        // records of the GEMM's input vector: [T][SEQ_O]
+    const float *pk_gate;        // MODE 2: partials of the ffn k/r GEMM [SEQ_O][SEQ_T][5D], r of channel j at column 5 j + 4
+    const SeqPart *qpart_gate;   //         records of the ffn r input vector
     SeqStat *stat;               // [T][SEQ_O]
     int D, T;
 };
@@ -196,36 +199,28 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_resid(SeqResidArgs a)
     const int D = a.D, t = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;
     int c0, c1;
     octant_range(D, o, c0, c1);
-    SeqRec rc{};
-    if (MODE != 0) rc = seq_rec(a.qpart, a.amaxv, 0, t);
-    const double *st = nullptr;
-    if (a.state) st = a.par ? a.state + (size_t)(a.slot0 + t) * a.slot_stride : (t == 0 ? a.state : nullptr);
+    const float so = MODE != 0 ? seq_so(a.qpart, 0, t) : 0.f;
+    const float sog = MODE == 2 ? seq_so(a.qpart_gate, 0, t) : 0.f;
     double s[2] = {0.0, 0.0};
-    float mx[2] = {0.f, 0.f};
     for (int j = c0 + threadIdx.x; j < c1; j += SEQ_ENT) {
         const size_t e = (size_t)t * D + j;
         double x = a.x[e];
         if (MODE != 0) {
-            double M = 0.0;
-#pragma unroll
-            for (int q = 0; q < SEQ_O; q++) M += a.part[((size_t)q * SEQ_T + t) * D + j];
-            const float v = (float)(rc.scale * (M + rc.cA + SEQ_CU * (double)a.rs[j])) + rc.So;
+            const float v = seq_val(a.pk, D, t, j, so);
             if (MODE == 1) x = (double)((float)x + v);
             else {
-                const float gt = (float)(1.0 / (1.0 + exp(-(double)a.gate[(size_t)t * 5 * D + 5 * (size_t)j + 4])));
+                const float r = seq_val(a.pk_gate, 5 * D, t, 5 * (size_t)j + 4, sog);
+                const float gt = (float)(1.0 / (1.0 + exp(-(double)r)));
                 x = x + (double)(v * gt);
             }
             a.x[e] = x;
         }
         s[0] += x; s[1] += x * x;
-        mx[0] = fmaxf(mx[0], (float)fabs(x) * 1.0000002f);
-        if (st) mx[1] = fmaxf(mx[1], (float)fabs(st[j]) * 1.0000002f);
     }
     eblock_sum<2>(s, red);
-    eblock_max<2>(mx, red);
     if (threadIdx.x == 0) {
         SeqStat r;
-        r.sx = s[0]; r.sxx = s[1]; r.amax = mx[0]; r.pmax = mx[1];
+        r.sx = s[0]; r.sxx = s[1];
         a.stat[t * SEQ_O + o] = r;
     }
 }
@@ -237,7 +232,6 @@ struct SeqSiteArgs {
     const double *lnw, *lnb;     // this site's LayerNorm rows
     const double *mix[3];        // token-shift mix per vector (nullptr: no shift, ln_out -> head)
     const float *r[3], *o[3];    // scale / offset of the matrices the vectors feed
-    const float *mxs;            // static bounds of the site: per vector {max|r mix lnw|, max|r mix lnb|, max|r (1 - mix)|, 0}, then {max|lnw|, max|lnb|}
     const double *state;         // previous LayerNorm output (state xy / dd of this layer, slot 0): row 0's shift input
     double *state_new;           // GPT: [D] LayerNorm output of the last row (copied over the state afterwards)
     int par;                     // PARRALEL mode (rwkv.cu:236-240): row t is an independent sequence with state slot slot0 + t --
@@ -246,25 +240,22 @@ struct SeqSiteArgs {
     int slot0;
     unsigned *img[3];            // A-operand images
     SeqPart *part;               // [NV][T][SEQ_O]
-    float *amaxv;                // [NV][T]
     int D, T;
 };
-// mean, rstd, max|x| of row t from its octant partials (every thread computes them: 8 tiny loads)
-__device__ __forceinline__ void seq_row_stats(const SeqStat *stat, int t, int D, double &mean, double &rstd, float &xmax, float &pmax)
+// mean, rstd of row t from its octant partials (every thread computes them: 8 tiny loads)
+__device__ __forceinline__ void seq_row_stats(const SeqStat *stat, int t, int D, double &mean, double &rstd)
 {
     double sx = 0.0, sxx = 0.0;
-    xmax = 0.f; pmax = 0.f;
 #pragma unroll
     for (int o = 0; o < SEQ_O; o++) {
         const SeqStat r = stat[t * SEQ_O + o];
-        sx += r.sx; sxx += r.sxx; xmax = fmaxf(xmax, r.amax); pmax = fmaxf(pmax, r.pmax);
+        sx += r.sx; sxx += r.sxx;
     }
     mean = sx / (double)D;
     rstd = 1.0 / sqrt((sxx - sx * mean) / (double)(D - 1));    // reference: (D-1), no epsilon (rwkv.cu:43-44,53)
 }
-// (row, octant) workgroups.  The fixed-point scale of vector m comes from an UPPER BOUND of max|v_m| that needs only the
-// row statistics (as the decode kernels' site_reduce): |v| <= max|r mix lnw| (max|x| + |mean|) rstd + max|r mix lnb|
-// + max|r (1 - mix)| max|shift source|, so the site needs one statistics round, not two.
+// (row, octant) workgroups, one quad (4 channels) per thread: LayerNorm + shift mix of the octant, its exact max|.| per
+// vector (one workgroup reduction), quantisation into the A image.  D / 32 <= SEQ_ENT quads per octant.
 template <int NV>
 __global__ __launch_bounds__(SEQ_ENT) void k_seq_site(SeqSiteArgs a)
 {
@@ -276,24 +267,16 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_site(SeqSiteArgs a)
     const bool lnprev = shift && t > 0 && !a.par;   // the shift input is a LayerNorm output: of the previous row (GPT) or already stored (state)
     const double *xprow = !shift ? a.x : a.par ? a.state_par + (size_t)(a.slot0 + t) * a.slot_stride : (t > 0 ? a.x + (size_t)(t - 1) * D : a.state);
     double mean, rstd, meanp = 0.0, rstdp = 1.0;
-    float xmax, pmax, xmaxp = 0.f, dummy;
-    seq_row_stats(a.stat, t, D, mean, rstd, xmax, pmax);
-    if (lnprev) seq_row_stats(a.stat, t - 1, D, meanp, rstdp, xmaxp, dummy);
-    const float mlw = a.mxs[4 * NV], mlb = a.mxs[4 * NV + 1];
-    const float xhmax = (float)(((double)xmax + fabs(mean)) * rstd) * 1.0001f;
-    const float prevmax = !shift ? 0.f : lnprev ? (mlw * (float)(((double)xmaxp + fabs(meanp)) * rstdp) * 1.0001f + mlb) : pmax;
-    float amax[NV], inv_s[NV];
-#pragma unroll
-    for (int m = 0; m < NV; m++) {
-        amax[m] = (a.mxs[4 * m] * xhmax + a.mxs[4 * m + 1] + a.mxs[4 * m + 2] * prevmax) * 1.0001f;
-        inv_s[m] = inv_scale(amax[m]);
-    }
-    unsigned ls[NV][3];
+    seq_row_stats(a.stat, t, D, mean, rstd);
+    if (lnprev) seq_row_stats(a.stat, t - 1, D, meanp, rstdp);
+    const int qd = (c0 >> 2) + threadIdx.x;
+    const bool live = qd < (c1 >> 2);
+    float v[NV][4];
     double So[NV];
+    float amax[NV];
 #pragma unroll
-    for (int m = 0; m < NV; m++) { ls[m][0] = ls[m][1] = ls[m][2] = 0u; So[m] = 0.0; }
-    const int q0 = c0 >> 2, q1 = c1 >> 2;
-    for (int qd = q0 + threadIdx.x; qd < q1; qd += SEQ_ENT) {
+    for (int m = 0; m < NV; m++) { So[m] = 0.0; amax[m] = 0.f; v[m][0] = v[m][1] = v[m][2] = v[m][3] = 0.f; }
+    if (live) {
         double xt[4], xp[4], lw[4], lb[4];
         load_quad_f64(a.x + (size_t)t * D, qd, xt);
         load_quad_f64(xprow, qd, xp);
@@ -313,37 +296,38 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_site(SeqSiteArgs a)
             const f32x4 rr = reinterpret_cast<const f32x4 *>(a.r[m])[qd], oo = reinterpret_cast<const f32x4 *>(a.o[m])[qd];
             double mk[4] = {1.0, 1.0, 1.0, 1.0};
             if (shift) load_quad_f64(a.mix[m], qd, mk);
-            float v[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 float f = (float)xx[e];
                 if (shift) f = (float)(xx[e] * mk[e] + xprev[e] * (1.0 - mk[e]));   // :339-343,:377-384
-                v[e] = f * rr[e];
+                v[m][e] = f * rr[e];
                 So[m] += (double)(f * oo[e]);
+                amax[m] = fmaxf(amax[m], fabsf(v[m][e]));
             }
-            seq_store_quad(a.img[m], qd, t, v, inv_s[m], ls[m]);
         }
     }
+    eblock_max<NV>(amax, red);
 #pragma unroll
     for (int m = 0; m < NV; m++) {
-        seq_finish(ls[m], So[m], c1 - c0, a.part + ((size_t)m * SEQ_T + t) * SEQ_O + o, red);
-        if (o == 0 && threadIdx.x == 0) a.amaxv[m * SEQ_T + t] = amax[m];
+        unsigned ls[3] = {0u, 0u, 0u};
+        if (live) seq_store_quad(a.img[m], qd, t, v[m], inv_scale(amax[m]), ls);
+        seq_finish(ls, So[m], c1 - c0, amax[m], a.part + ((size_t)m * SEQ_T + t) * SEQ_O + o, red);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 struct SeqStageArgs {
-    const float *src;            // kind 0: gated wkv y [T][D]; kind 1: ffn k/r GEMM output [T][5D], element [t][5 i + q]
+    const float *src;            // KIND 0: gated wkv y [T][D]
+    const float *pk;             // KIND 1: partials of the ffn k/r GEMM [SEQ_O][SEQ_T][5D], k of hidden unit 4 i + q at column 5 i + q
+    const SeqPart *qpart_k;      //         records of the ffn k input vector (its offset term)
     const float *r, *o;          // scale / offset over K
-    const float *pmax;           // [n_pmax][SEQ_T] per-producer-workgroup partial max of |f * r| per row
-    int n_pmax;
     unsigned *img;
     SeqPart *part;               // [T][SEQ_O]
-    float *amaxv;                // [T]
     int K, T;
 };
+constexpr int SEQ_SQ = 3;        // quads per thread of a stage workgroup: K / 32 <= 3 * SEQ_ENT
 // (row, octant) workgroups.  KIND 0: f = src (att_out input).  KIND 1: f = relu(k)^2 with k = ffn_k GEMM output
-// (rwkv.cu:189-190), K = 4D.  The exact max|f * r| of the row comes from the producers' partials.
+// (rwkv.cu:189-190), K = 4D.  Exact max|f * r| of the octant by one workgroup reduction, then quantisation.
 template <int KIND>
 __global__ __launch_bounds__(SEQ_ENT) void k_seq_stage(SeqStageArgs a)
 {
@@ -351,40 +335,55 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_stage(SeqStageArgs a)
     const int K = a.K, t = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;
     int c0, c1;
     octant_range(K, o, c0, c1);
+    const float sok = KIND == 1 ? seq_so(a.qpart_k, 0, t) : 0.f;
+    const int q0 = c0 >> 2, q1 = c1 >> 2;
+    float v[SEQ_SQ][4];
+    double So = 0.0;
     float am[1] = {0.f};
-    for (int w = threadIdx.x; w < a.n_pmax; w += SEQ_ENT) am[0] = fmaxf(am[0], a.pmax[(size_t)w * SEQ_T + t]);
+#pragma unroll
+    for (int i = 0; i < SEQ_SQ; i++) {
+        const int qd = q0 + threadIdx.x + i * SEQ_ENT;
+        v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        if (qd < q1) {
+            float f[4];
+            if (KIND == 0) {
+                const f32x4 sv = reinterpret_cast<const f32x4 *>(a.src + (size_t)t * K)[qd];
+                f[0] = sv[0]; f[1] = sv[1]; f[2] = sv[2]; f[3] = sv[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float k = seq_val(a.pk, K / 4 * 5, t, (size_t)qd * 5 + e, sok);      // hidden units 4 qd .. 4 qd + 3 = k0..k3 of channel qd
+                    k = k * (float)(k > 0.f);
+                    f[e] = k * k;                                                          // relu(k)^2, rwkv.cu:189-190
+                }
+            }
+            const f32x4 rv = reinterpret_cast<const f32x4 *>(a.r)[qd], ov = reinterpret_cast<const f32x4 *>(a.o)[qd];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                v[i][e] = f[e] * rv[e];
+                So += (double)(f[e] * ov[e]);
+                am[0] = fmaxf(am[0], fabsf(v[i][e]));
+            }
+        }
+    }
     eblock_max<1>(am, red);
     const float inv_s = inv_scale(am[0]);
     unsigned ls[3] = {0u, 0u, 0u};
-    double So = 0.0;
-    const int q0 = c0 >> 2, q1 = c1 >> 2;
-    for (int qd = q0 + threadIdx.x; qd < q1; qd += SEQ_ENT) {
-        f32x4 sv;
-        if (KIND == 0) sv = reinterpret_cast<const f32x4 *>(a.src + (size_t)t * K)[qd];
-        else __builtin_memcpy(&sv, a.src + (size_t)t * (K / 4 * 5) + (size_t)qd * 5, 16);   // k0..k3 of channel qd: 4-byte aligned only
-        const f32x4 rv = reinterpret_cast<const f32x4 *>(a.r)[qd], ov = reinterpret_cast<const f32x4 *>(a.o)[qd];
-        float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            float f = sv[e];
-            if (KIND == 1) { f = f * (float)(f > 0.f); f = f * f; }     // relu(k)^2, rwkv.cu:189-190
-            v[e] = f * rv[e];
-            So += (double)(f * ov[e]);
-        }
-        seq_store_quad(a.img, qd, t, v, inv_s, ls);
+    for (int i = 0; i < SEQ_SQ; i++) {
+        const int qd = q0 + threadIdx.x + i * SEQ_ENT;
+        if (qd < q1) seq_store_quad(a.img, qd, t, v[i], inv_s, ls);
     }
-    seq_finish(ls, So, c1 - c0, a.part + (size_t)t * SEQ_O + o, red);
-    if (o == 0 && threadIdx.x == 0) a.amaxv[t] = am[0];
+    seq_finish(ls, So, c1 - c0, am[0], a.part + (size_t)t * SEQ_O + o, red);
 }
 
 // ------------------------------------------------------------------------------------------
 struct SeqWkvArgs {
-    const float *kvr;            // K/V/R GEMM output [T][3D], element [t][3 i + m]
+    const float *pk;             // partials of the K/V/R GEMM [SEQ_O][SEQ_T][3D], column 3 i + m
+    const SeqPart *qpart;        // records of the three input vectors [3][T][SEQ_O]
     const double *uw, *ew;       // bonus + decay, exp(decay) of this layer
     double *saa, *sbb;           // state of this layer, slot 0
-    const float *r_att;          // att_out scale [D]: the partial maxima are those of y * r_att (att_out's staged vector)
     float *y;                    // [T][D] gated wkv, cast to f32 as the att_out GEMV does (rwkv.cu:290)
-    float *pmax;                 // [gridDim.x][SEQ_T]
     int D, T;
     int par;                     // PARRALEL mode: row t uses state slot slot0 + t (no recurrence along the rows)
     size_t slot_stride;
@@ -397,14 +396,13 @@ constexpr int WKV_CH = 16;       // channels per workgroup (512 threads = 16 cha
 __global__ __launch_bounds__(SEQ_T * WKV_CH) void k_seq_wkv(SeqWkvArgs a)
 {
     __shared__ double e1s[SEQ_T][WKV_CH], eks[SEQ_T][WKV_CH], vs[SEQ_T][WKV_CH], sgs[SEQ_T][WKV_CH];
-    __shared__ float ya[SEQ_T][WKV_CH];
     const int ch = threadIdx.x & (WKV_CH - 1), t = threadIdx.x / WKV_CH;
     const int i = blockIdx.x * WKV_CH + ch;
     const bool live = i < a.D && t < a.T;
-    ya[t][ch] = 0.f;
     if (live) {
-        const float *p = a.kvr + (size_t)t * 3 * a.D + 3 * i;
-        const float k = p[0], v = p[1], r = p[2];
+        const float k = seq_val(a.pk, 3 * a.D, t, 3 * (size_t)i + 0, seq_so(a.qpart, 0, t));
+        const float v = seq_val(a.pk, 3 * a.D, t, 3 * (size_t)i + 1, seq_so(a.qpart, 1, t));
+        const float r = seq_val(a.pk, 3 * a.D, t, 3 * (size_t)i + 2, seq_so(a.qpart, 2, t));
         e1s[t][ch] = exp(a.uw[i] + (double)k);
         eks[t][ch] = exp((double)k);
         vs[t][ch] = (double)v;
@@ -416,40 +414,30 @@ __global__ __launch_bounds__(SEQ_T * WKV_CH) void k_seq_wkv(SeqWkvArgs a)
             const size_t so = (size_t)(a.slot0 + t) * a.slot_stride + i;
             const double aa = a.saa[so], bb = a.sbb[so], ew = a.ew[i];
             const double e1 = e1s[t][ch], ek = eks[t][ch], vv = vs[t][ch];
-            const float yf = (float)(sgs[t][ch] * ((aa + e1 * vv) / (bb + e1)));
-            a.y[(size_t)t * a.D + i] = yf;
-            ya[t][ch] = fabsf(yf * a.r_att[i]);
+            a.y[(size_t)t * a.D + i] = (float)(sgs[t][ch] * ((aa + e1 * vv) / (bb + e1)));
             a.saa[so] = (aa + ek * vv) * ew;
             a.sbb[so] = (bb + ek) * ew;
         }
-    } else if (threadIdx.x < WKV_CH && i < a.D) {
+        return;
+    }
+    if (threadIdx.x < WKV_CH && i < a.D) {
         double aa = a.saa[i], bb = a.sbb[i];
         const double ew = a.ew[i];
-        const float ra = a.r_att[i];
         for (int tt = 0; tt < a.T; tt++) {
             const double e1 = e1s[tt][ch], ek = eks[tt][ch], vv = vs[tt][ch];
             const double y = sgs[tt][ch] * ((aa + e1 * vv) / (bb + e1));
             aa = (aa + ek * vv) * ew;
             bb = (bb + ek) * ew;
-            const float yf = (float)y;
-            a.y[(size_t)tt * a.D + i] = yf;
-            ya[tt][ch] = fabsf(yf * ra);
+            a.y[(size_t)tt * a.D + i] = (float)y;
         }
         a.saa[i] = aa; a.sbb[i] = bb;
-    }
-    __syncthreads();
-    if (threadIdx.x < SEQ_T) {
-        float m = 0.f;
-#pragma unroll
-        for (int c = 0; c < WKV_CH; c++) m = fmaxf(m, ya[threadIdx.x][c]);
-        a.pmax[(size_t)blockIdx.x * SEQ_T + threadIdx.x] = m;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // Load-time: MFMA B-operand image of a re-tiled matrix w_t[N][K] (row-per-output).  Tiles are enumerated class-major:
 // tile id -> class q = id / CB, 16-channel block cb = id % CB, tile row c -> matrix row Q * (16 cb + c) + q (Q row classes
-// interleaved in w_t: K/V/R 3, ffn k,k,k,k,r 5, else 1), so that a pass of consecutive tiles shares one activation vector.
+// interleaved in w_t: K/V/R 3, ffn k,k,k,k,r 5, else 1), so that consecutive tiles share an activation vector.
 // bimg[((id * KB + kb) * 64 + lane) * 16 + b] = w_t[row(id, lane & 15)][64 kb + 16 (lane >> 4) + b] - 128 (rows past N: 0).
 __global__ void k_bimage(const uint8_t *__restrict__ w_t, uint8_t *__restrict__ bimg, int N, int K, int Q, int CB)
 {
@@ -461,39 +449,239 @@ __global__ void k_bimage(const uint8_t *__restrict__ w_t, uint8_t *__restrict__ 
     const size_t tk = unit >> 6;
     const int kb = (int)(tk % KB), id = (int)(tk / KB);
     const int q = id / CB, cb = id % CB;
-    const int row = Q * (16 * cb + (lane & 15)) + q;
+    const int ch = 16 * cb + (lane & 15), row = Q * ch + q;
+    const int nch = (N + Q - 1) / Q;
     u32x4 v = u32x4{0u, 0u, 0u, 0u};
-    if (row < N) {
+    if (ch < nch && row < N) {
         v = *reinterpret_cast<const u32x4 *>(w_t + (size_t)row * K + (size_t)kb * 64 + 16 * (lane >> 4));
 #pragma unroll
         for (int d = 0; d < 4; d++) v[d] ^= 0x80808080u;
     }
     reinterpret_cast<u32x4 *>(bimg)[unit] = v;
 }
+// Load-time: row sums of the unsigned weights per OCTANT of K: rs8[o][row] = sum over k in octant o of w_t[row][k].  One wave per row.
+__global__ void k_rowsum8(const uint8_t *__restrict__ w_t, unsigned *__restrict__ rs8, int N, int K)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63, KB = K >> 6;
+    unsigned acc[SEQ_O];
+#pragma unroll
+    for (int o = 0; o < SEQ_O; o++) acc[o] = 0u;
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(w_t + (size_t)row * K);
+    for (int c = lane; c < (K >> 4); c += 64) {
+        const u32x4 v = p[c];
+        unsigned sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) sum = __builtin_amdgcn_udot4(v[q], 0x01010101u, sum, false);
+        const int kb = c >> 2;
+#pragma unroll
+        for (int o = 0; o < SEQ_O; o++) {
+            const int k0 = (int)(((long long)o * KB) / SEQ_O), k1 = (int)(((long long)(o + 1) * KB) / SEQ_O);
+            acc[o] += (kb >= k0 && kb < k1) ? sum : 0u;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < SEQ_O; o++) {
+        const unsigned tot = wave_sum_dpp(acc[o]);
+        if (lane == 0) rs8[(size_t)o * N + row] = tot;
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 struct SeqGemmArgs {
     const u32x4 *bimg;           // B-operand image of the weights (k_bimage)
-    const unsigned *rs;          // [N] row sums of the unsigned weights
+    const unsigned *rs8;         // [SEQ_O][N] row sums of the unsigned weights per octant
     int N, K;
     int Q;                       // row classes interleaved in the matrix
-    int vec_of_q[5];             // activation vector each class multiplies
+    int vec_of_q[5];             // activation vector each class multiplies (non-decreasing in q)
     const u32x4 *img[3];         // A-operand images of the vectors
     const SeqPart *part;         // quantisation records [NV][T][SEQ_O]
-    const float *amaxv;          // [NV][T]
-    float *out;                  // epi 0 / 3: [T][N] f32
-    int epi;                     // 0 store; 3 store + per-workgroup partial max of relu(k)^2 * r_fv per row (ffn k/r GEMM, classes 0..3)
-    const float *r_next;         // epi 3: ffn_v scale [4 nch], hidden unit 4 i + q
-    float *pmax;                 // epi 3: [gridDim.x][SEQ_T]
+    float *pk;                   // k_seq_gemm: [SEQ_O][SEQ_T][N] per-slice partial values
+    float *out;                  // k_seq_gemm_ks: [T][N]
     int T;
+    int ntw;                     // k_seq_gemm: row tiles per wave in use (<= the template's NTW)
     const double *cp_src;        // piggy-back copy (stream-ordered behind the site kernel that produced it): the chunk's
     double *cp_dst;              // last LayerNorm output -> recurrent state; cp_n == 0: none
     int cp_n;
 };
-constexpr int SEQ_TB = 5;        // weight tiles (16 rows each) per workgroup pass
 constexpr int SEQ_NT = 512;      // GEMM workgroup: 8 waves, two per SIMD
 constexpr int SEQ_NW = SEQ_NT / 64;
 
+// value of one slice: scale_o (M + cA_o + CU * rowsum_o)
+__device__ __forceinline__ double seq_slice_value(const SeqPart &rc, double M, unsigned rs)
+{
+    return scale_of(rc.amax) * (M + rc.cA + SEQ_CU * (double)rs);
+}
+
+// "tile per wave, K over the XCDs": workgroup (rb, j): j = blockIdx % 8 = K-slice = octant (and the XCD the workgroup is
+// dispatched to), rb = block of 8 * ntw row tiles; wave w owns tiles (rb * 8 + w) * ntw + i for the whole slice.
+// NTW: tiles per wave (registers), NKB: k-blocks of a slice per chunk (registers, LDS); MTS: the two row tiles of the chunk one
+// after the other (halves the accumulators; single-chunk slices only), else both at once; NVS: activation vectors the
+// tiles of one workgroup may span (LDS).
+// Slices longer than NKB k-blocks (ffn_v: K = 4D) run in chunks: the activation image of chunk c + 1 is requested while
+// chunk c multiplies and the weights of chunk c + 1 go into a second register set.
+template <int TAG, int NTW, int NKB, bool MTS, int NVS>
+__global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool DB = !MTS && NTW * NKB <= 16;        // second weight register set + second LDS buffer
+    constexpr int CHU = NVS * NKB * 384;                // units of one LDS buffer: [vector][k][row tile][limb][lane]
+    u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
+    const int nch = (N + Q - 1) / Q, CB = (nch + 15) >> 4, ntiles = Q * CB;
+    const int j = blockIdx.x % SEQ_O, rb = blockIdx.x / SEQ_O;
+    const int kb0 = (int)(((long long)j * KB) / SEQ_O), kb1 = (int)(((long long)(j + 1) * KB) / SEQ_O);
+    const int nkb = kb1 - kb0, nchunk = (nkb + NKB - 1) / NKB;
+    if (blockIdx.x == gridDim.x - 1)
+        for (int q = threadIdx.x; q < a.cp_n; q += SEQ_NT) a.cp_dst[q] = a.cp_src[q];
+    const int ntw = a.ntw;
+    const int id0 = (rb * SEQ_NW + wave) * ntw;          // this wave's tiles: id0 .. id0 + ntw - 1
+    const int wg0 = rb * SEQ_NW * ntw, wg1 = min(wg0 + SEQ_NW * ntw, ntiles) - 1;
+    const int vlo = a.vec_of_q[min(wg0, ntiles - 1) / CB], vhi = a.vec_of_q[max(wg1, 0) / CB];
+
+    const u32x4 *wt[NTW];
+    int vi[NTW];
+    bool tv[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; i++) {
+        const int id = id0 + i;
+        tv[i] = i < ntw && id < ntiles;
+        const int idc = tv[i] ? id : 0;
+        wt[i] = a.bimg + ((size_t)idc * KB) * 64 + lane;
+        vi[i] = a.vec_of_q[idc / CB] - vlo;
+        vi[i] = vi[i] < 0 ? 0 : (vi[i] >= NVS ? NVS - 1 : vi[i]);
+        vi[i] = __builtin_amdgcn_readfirstlane(vi[i]);   // wave-uniform by construction
+    }
+    auto kclamp = [&](int c, int k) { const int n = min(NKB, nkb - c * NKB); return kb0 + c * NKB + (k < n ? k : (n > 0 ? n - 1 : 0)); };
+    u32x4 bw[DB ? 2 : 1][NTW][NKB];
+    auto load_b = [&](int set, int c) {
+#pragma unroll
+        for (int k = 0; k < NKB; k++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++) bw[set][i][k] = __builtin_nontemporal_load(wt[i] + (size_t)min(kclamp(c, k), KB - 1) * 64);
+    };
+    // activation image of chunk c, vectors vlo .. vhi: units [(kb0 + c NKB) * 384, + n * 384) of each image are contiguous
+    auto stage_a = [&](int c, int buf) {
+        const int kbs = kb0 + c * NKB, n = min(NKB, nkb - c * NKB);
+        u32x4 *dst = abuf + (size_t)buf * CHU;
+        for (int v = vlo; v <= vhi && v - vlo < NVS; v++) {
+            const u32x4 *src = a.img[v] + (size_t)kbs * 384;
+            u32x4 *d = dst + (size_t)(v - vlo) * NKB * 384;
+            for (int u = threadIdx.x; u < n * 384; u += SEQ_NT) d[u] = src[u];
+        }
+    };
+    if (nchunk > 0) { load_b(0, 0); stage_a(0, 0); }
+    __syncthreads();
+
+    i32x4 acc[NTW][MTS ? 1 : 2][3];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < NTW; i++)
+#pragma unroll
+            for (int mt = 0; mt < (MTS ? 1 : 2); mt++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) acc[i][mt][b] = i32x4{0, 0, 0, 0};
+    };
+    // per-slice value of tile i, row tile mt (accumulator set ms) -> pk
+    auto emit = [&](int mt, int ms) {
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            if (!tv[i]) continue;
+            const int id = id0 + i, q = id / CB, ch = 16 * (id % CB) + (lane & 15), row = Q * ch + q;
+            const int v = a.vec_of_q[q];
+            const bool rok = ch < nch && row < N;
+            const unsigned rs = rok ? a.rs8[(size_t)j * N + row] : 0u;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int t = mt * 16 + 4 * (lane >> 4) + r;
+                if (t < a.T && rok) {
+                    const SeqPart rc = a.part[((size_t)v * SEQ_T + t) * SEQ_O + j];
+                    const double M = (double)acc[i][ms][0][r] + 256.0 * (double)acc[i][ms][1][r] + 65536.0 * (double)acc[i][ms][2][r];
+                    a.pk[((size_t)j * SEQ_T + t) * N + row] = (float)seq_slice_value(rc, M, rs);
+                }
+            }
+        }
+    };
+    // the MFMAs of chunk c (weights in register set `set`, activation image in LDS buffer `buf`) for row tile(s) mt0 ..
+    // The A fragments of a k-block are read from LDS once and kept while consecutive tiles use the same activation vector
+    // (a wave's tiles are class-ordered; the re-read at a class change is a wave-uniform branch).
+    auto mult = [&](int set, int buf, int c, int mt0) {
+        const int n = min(NKB, nkb - c * NKB);
+        const u32x4 *ab = abuf + (size_t)buf * CHU + lane;
+#pragma unroll
+        for (int k = 0; k < NKB; k++) {
+            const bool kv = k < n;
+            u32x4 av[MTS ? 1 : 2][3];
+            auto read_a = [&](int vv) {
+#pragma unroll
+                for (int ms = 0; ms < (MTS ? 1 : 2); ms++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) av[ms][b] = ab[(((size_t)vv * NKB + k) * 2 + (MTS ? mt0 : ms)) * 3 * 64 + b * 64];
+            };
+            read_a(vi[0]);
+#pragma unroll
+            for (int i = 0; i < NTW; i++) {
+                if (NVS > 1 && i > 0 && vi[i] != vi[i - 1]) read_a(vi[i]);
+                const u32x4 w = bw[set][i][k];
+                const i32x4 bf = i32x4{kv ? (int)w[0] : 0, kv ? (int)w[1] : 0, kv ? (int)w[2] : 0, kv ? (int)w[3] : 0};   // past the slice: zero weights
+#pragma unroll
+                for (int ms = 0; ms < (MTS ? 1 : 2); ms++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        const i32x4 af = i32x4{(int)av[ms][b][0], (int)av[ms][b][1], (int)av[ms][b][2], (int)av[ms][b][3]};
+                        acc[i][ms][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[i][ms][b], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of the next k-block behind these MFMAs (register pressure)
+        }
+    };
+    if (MTS) {                        // single chunk: weights stay in registers for both row tiles
+        for (int mt = 0; mt < 2; mt++) {
+            zero_acc();
+            if (nchunk > 0) mult(0, 0, 0, mt);
+            emit(mt, 0);
+        }
+    } else {
+        zero_acc();
+        for (int c = 0; c < nchunk; c++) {
+            const int cn = c + 1 < nchunk ? c + 1 : c;
+            if (DB) {
+                // next chunk: weights into the other register set, activation image (one vector: att_out / ffn_v) requested
+                // now and written into the other LDS buffer after this chunk's MFMAs (its readers passed the previous barrier)
+                constexpr int UPT = (NKB * 384 + SEQ_NT - 1) / SEQ_NT;
+                u32x4 sa[UPT];
+                {
+                    const int kbs = kb0 + cn * NKB, nu = min(NKB, nkb - cn * NKB) * 384;
+                    const u32x4 *src = a.img[vlo] + (size_t)kbs * 384;
+#pragma unroll
+                    for (int q = 0; q < UPT; q++) { const int u = threadIdx.x + q * SEQ_NT; sa[q] = src[u < nu ? u : nu - 1]; }
+                }
+                if (c & 1) { load_b(0, cn); mult(1, 1, c, 0); } else { load_b(1, cn); mult(0, 0, c, 0); }
+                {
+                    u32x4 *dst = abuf + (size_t)((c + 1) & 1) * CHU;
+#pragma unroll
+                    for (int q = 0; q < UPT; q++) { const int u = threadIdx.x + q * SEQ_NT; if (u < NKB * 384) dst[u] = sa[q]; }
+                }
+                __syncthreads();
+            } else {
+                mult(0, 0, c, 0);
+                if (c + 1 < nchunk) {                     // one register set, one buffer: load, then multiply
+                    __syncthreads();
+                    load_b(0, c + 1); stage_a(c + 1, 0);
+                    __syncthreads();
+                }
+            }
+        }
+        emit(0, 0);
+        emit(1, 1);
+    }
+}
+constexpr size_t seq_gemm_smem(int ntw, int nkb, bool mts, int nvs) { return (size_t)((!mts && ntw * nkb <= 16) ? 2 : 1) * nvs * nkb * 384 * 16; }
+
+// ------------------------------------------------------------------------------------------
+constexpr int SEQ_TB = 5;        // weight tiles (16 rows each) per workgroup pass of k_seq_gemm_ks
 // operands of one k-block: B fragments of NTL tiles and the A fragments of the pass's vector
 template <int NTL> struct SeqFrag { u32x4 bw[NTL]; u32x4 af[2][3]; };
 template <int NTL>
@@ -521,50 +709,47 @@ __device__ __forceinline__ void seq_frag_mfma(const SeqFrag<NTL> &f, i32x4 (&acc
             }
     }
 }
-// K loop of one pass over NTL tiles: the waves take k-blocks round-robin (wave w: kb = w, w + 8, ...), so at any moment the
-// workgroup reads 8 adjacent 1 KiB pieces of each tile's image; operands of the next k-block(s) are requested before
-// the MFMAs of the current one issue.
+// K loop of one pass over NTL tiles: wave w multiplies the k-blocks [kb0, kb1) of ITS octant; operands of the next
+// k-block(s) are requested before the MFMAs of the current one issue.
 template <int NTL, int DEPTH>
-__device__ __forceinline__ void seq_pass(i32x4 (&acc)[SEQ_TB][2][3], const u32x4 *const (&wt)[SEQ_TB], const u32x4 *img, int KB, int wave, int lane)
+__device__ __forceinline__ void seq_pass(i32x4 (&acc)[SEQ_TB][2][3], const u32x4 *const (&wt)[SEQ_TB], const u32x4 *img, int kb0, int kb1, int lane)
 {
-    const int n = (KB - wave + SEQ_NW - 1) / SEQ_NW;      // k-blocks of this wave
+    const int n = kb1 - kb0;
     if (n <= 0) return;
-    auto kbi = [&](int it) { return wave + SEQ_NW * (it < n - 1 ? it : n - 1); };   // past the end: re-read the last (branch-free loop)
+    auto kbi = [&](int it) { return kb0 + (it < n - 1 ? it : n - 1); };   // past the end: re-read the last (branch-free loop)
     SeqFrag<NTL> f[DEPTH];
 #pragma unroll
-    for (int j = 0; j < DEPTH - 1; j++) seq_frag_load<NTL>(f[j], wt, img, kbi(j), lane);
+    for (int jj = 0; jj < DEPTH - 1; jj++) seq_frag_load<NTL>(f[jj], wt, img, kbi(jj), lane);
     int it = 0;
     for (; it + DEPTH <= n; it += DEPTH) {
 #pragma unroll
-        for (int j = 0; j < DEPTH; j++) {
-            seq_frag_load<NTL>(f[(j + DEPTH - 1) % DEPTH], wt, img, kbi(it + j + DEPTH - 1), lane);
-            seq_frag_mfma<NTL>(f[j], acc);
+        for (int jj = 0; jj < DEPTH; jj++) {
+            seq_frag_load<NTL>(f[(jj + DEPTH - 1) % DEPTH], wt, img, kbi(it + jj + DEPTH - 1), lane);
+            seq_frag_mfma<NTL>(f[jj], acc);
         }
     }
 #pragma unroll
-    for (int j = 0; j < DEPTH - 1; j++)
-        if (it + j < n) seq_frag_mfma<NTL>(f[j], acc);
+    for (int jj = 0; jj < DEPTH - 1; jj++)
+        if (it + jj < n) seq_frag_mfma<NTL>(f[jj], acc);
 }
 
-// "K over the waves": one workgroup owns a contiguous range of (class-major) 16-row tiles and works through it in passes
-// of up to SEQ_TB tiles that share an activation vector; its 8 waves split K; the integer partial sums meet in LDS
-// (exact: order does not matter), then the workgroup applies scale, offsets and corrections.
-// TAG only names the launch for the profiler: 0 K/V/R, 1 ffn k/r, 2 head
-template <int TAG>
+// "K over the waves" (head): one workgroup owns a contiguous range of 16-row tiles and works through it in passes of up to
+// SEQ_TB tiles; wave w takes octant w of K; the per-octant values (exact integers scaled in f64) meet in LDS, then the
+// workgroup adds the offset term and stores.
 __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_ks(SeqGemmArgs a)
 {
-    __shared__ double accl[SEQ_TB][2][4][64];   // [tile][row tile][reg][lane], 20 KiB
-    __shared__ SeqRec recl[SEQ_T];
-    __shared__ float pml[SEQ_T];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float (*accl)[SEQ_TB][2][4][64] = reinterpret_cast<float (*)[SEQ_TB][2][4][64]>(smem);   // [octant][tile][row tile][reg][lane], 80 KiB
+    float *sol = reinterpret_cast<float *>(smem + sizeof(float) * SEQ_O * SEQ_TB * 2 * 4 * 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
     const int nch = (N + Q - 1) / Q;                    // channels per class
     const int CB = (nch + 15) >> 4;                     // 16-channel blocks per class
     const int ntiles = Q * CB;
     const int tb0 = (int)(((long long)blockIdx.x * ntiles) / gridDim.x), tb1 = (int)(((long long)(blockIdx.x + 1) * ntiles) / gridDim.x);
+    const int kb0 = (int)(((long long)wave * KB) / SEQ_O), kb1 = (int)(((long long)(wave + 1) * KB) / SEQ_O);
     if (blockIdx.x == gridDim.x - 1)
         for (int j = threadIdx.x; j < a.cp_n; j += SEQ_NT) a.cp_dst[j] = a.cp_src[j];
-    if (threadIdx.x < SEQ_T) pml[threadIdx.x] = 0.f;
 
     int tg = tb0;
     int vcur = -1;
@@ -573,8 +758,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_ks(SeqGemmArgs a)
         const int v0 = a.vec_of_q[tg / CB];
         int nt = 1;
         while (nt < SEQ_TB && tg + nt < tb1 && a.vec_of_q[(tg + nt) / CB] == v0) nt++;
-        for (int e = threadIdx.x; e < SEQ_TB * 2 * 4 * 64; e += SEQ_NT) (&accl[0][0][0][0])[e] = 0.0;
-        if (v0 != vcur && threadIdx.x < a.T) recl[threadIdx.x] = seq_rec(a.part, a.amaxv, v0, threadIdx.x);
+        if (v0 != vcur && threadIdx.x < a.T) sol[threadIdx.x] = seq_so(a.part, v0, threadIdx.x);
         vcur = v0;
         __syncthreads();
 
@@ -590,23 +774,34 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_ks(SeqGemmArgs a)
 #pragma unroll
                 for (int b = 0; b < 3; b++) acc[i][mt][b] = i32x4{0, 0, 0, 0};
         switch (nt) {
-        case 1: seq_pass<1, 4>(acc, wt, img, KB, wave, lane); break;
-        case 2: seq_pass<2, 3>(acc, wt, img, KB, wave, lane); break;
-        case 3: seq_pass<3, 3>(acc, wt, img, KB, wave, lane); break;
-        case 4: seq_pass<4, 2>(acc, wt, img, KB, wave, lane); break;
-        default: seq_pass<5, 2>(acc, wt, img, KB, wave, lane); break;
+        case 1: seq_pass<1, 4>(acc, wt, img, kb0, kb1, lane); break;
+        case 2: seq_pass<2, 3>(acc, wt, img, kb0, kb1, lane); break;
+        case 3: seq_pass<3, 3>(acc, wt, img, kb0, kb1, lane); break;
+        case 4: seq_pass<4, 2>(acc, wt, img, kb0, kb1, lane); break;
+        default: seq_pass<5, 2>(acc, wt, img, kb0, kb1, lane); break;
         }
-        // fold limbs (exact in f64) and meet the other waves' K slices in LDS
+        // this wave's octant: fold the limbs (exact in f64), scale with the octant's records; the octants meet in LDS as f32
+        // values and are added in a fixed order below (deterministic; the same arithmetic as k_seq_gemm's per-slice partials)
 #pragma unroll
         for (int i = 0; i < SEQ_TB; i++)
-            if (i < nt)
+            if (i < nt) {
+                const int id = tg + i, q = id / CB, ch = 16 * (id % CB) + (lane & 15), row = Q * ch + q;
+                const bool rok = ch < nch && row < N;
+                const unsigned rs = rok ? a.rs8[(size_t)wave * N + row] : 0u;
 #pragma unroll
                 for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const double v = (double)acc[i][mt][0][r] + 256.0 * (double)acc[i][mt][1][r] + 65536.0 * (double)acc[i][mt][2][r];
-                        __hip_atomic_fetch_add(&accl[i][mt][r][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const int t = mt * 16 + 4 * (lane >> 4) + r;
+                        float val = 0.f;
+                        if (t < a.T && rok) {
+                            const SeqPart rc = a.part[((size_t)v0 * SEQ_T + t) * SEQ_O + wave];
+                            const double M = (double)acc[i][mt][0][r] + 256.0 * (double)acc[i][mt][1][r] + 65536.0 * (double)acc[i][mt][2][r];
+                            val = (float)seq_slice_value(rc, M, rs);
+                        }
+                        accl[wave][i][mt][r][lane] = val;
                     }
+            }
         __syncthreads();
         // epilogue: D[m][n] with n = lane & 15 (weight row of the tile), m = 4 * (lane >> 4) + reg (row of the chunk)
         for (int e = threadIdx.x; e < nt * 2 * 4 * 64; e += SEQ_NT) {
@@ -615,125 +810,17 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_ks(SeqGemmArgs a)
             const int id = tg + i, q = id / CB, ch = 16 * (id % CB) + (ln & 15);
             const int row = Q * ch + q;
             if (t < a.T && ch < nch && row < N) {
-                const SeqRec rc = recl[t];
-                const double M = accl[i][mt][r][ln];
-                const float v = (float)(rc.scale * (M + rc.cA + SEQ_CU * (double)a.rs[row])) + rc.So;
-                a.out[(size_t)t * N + row] = v;
-                if (a.epi == 3 && q < 4) {           // what k_seq_stage<1> will stage: relu(k)^2 * r_fv (rwkv.cu:189-190)
-                    float h = v * (float)(v > 0.f);
-                    h = h * h * a.r_next[4 * ch + q];
-                    atomicMax(reinterpret_cast<unsigned *>(&pml[t]), __float_as_uint(fabsf(h)));   // non-negative floats order like their bit patterns
-                }
+                double v = 0.0;
+#pragma unroll
+                for (int o = 0; o < SEQ_O; o++) v += (double)accl[o][i][mt][r][ln];
+                a.out[(size_t)t * N + row] = (float)v + sol[t];
             }
         }
         __syncthreads();
         tg += nt;
     }
-    if (a.epi == 3 && threadIdx.x < SEQ_T) a.pmax[(size_t)blockIdx.x * SEQ_T + threadIdx.x] = pml[threadIdx.x];
 }
 
-// ------------------------------------------------------------------------------------------
-struct SeqGemmTwArgs {
-    const u32x4 *bimg;           // B-operand image, Q = 1: tile id = 16-row block
-    const u32x4 *img;            // A-operand image of the input vector
-    double *part;                // [SEQ_O][SEQ_T][N] exact partial sums
-    int N, K, T;
-    const double *cp_src;        // piggy-back state commit (see SeqGemmArgs)
-    double *cp_dst;
-    int cp_n;
-};
-constexpr int SEQ_TW_CH = 8;     // k-blocks of the activation image staged in LDS at a time (48 KiB)
-// "one tile per wave, K over the XCDs": workgroup (i, j), i = 128-row block, j = K-slice = blockIdx % 8 (the XCD the
-// workgroup is dispatched to, so that the 32 workgroups of an XCD all read the SAME slice of the activation image through
-// their L2); wave w owns row tile 8 i + w for the whole slice; the slice's activation image goes through LDS once for
-// all 8 waves, in pieces of SEQ_TW_CH k-blocks (two buffers); the weights stream from the B image, 1 KiB per k-block per
-// wave, requested 8 k-blocks ahead.
-// TAG only names the launch for the profiler: 0 att_out, 1 ffn_v
-template <int TAG>
-__global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_tw(SeqGemmTwArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);      // [2][SEQ_TW_CH][2][3][64] units
-    constexpr int CHU = SEQ_TW_CH * 2 * 3 * 64;         // units per buffer
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int K = a.K, KB = K >> 6, N = a.N;
-    const int j = blockIdx.x % SEQ_O, ib = blockIdx.x / SEQ_O;
-    const int kb0 = (int)(((long long)j * KB) / SEQ_O), kb1 = (int)(((long long)(j + 1) * KB) / SEQ_O);
-    const int ntile = (N + 15) >> 4;
-    const int tile = ib * SEQ_NW + wave;
-    const bool live = tile < ntile;
-    if (blockIdx.x == gridDim.x - 1)
-        for (int q = threadIdx.x; q < a.cp_n; q += SEQ_NT) a.cp_dst[q] = a.cp_src[q];
-
-    const u32x4 *wt = a.bimg + ((size_t)(live ? tile : 0) * KB) * 64 + lane;
-    constexpr int DW = 8;                                // weight k-blocks in flight per wave
-    u32x4 bw[DW];
-    const int nkb = kb1 - kb0;
-    auto kbc = [&](int it) { return kb0 + (it < nkb ? it : nkb - 1); };
-#pragma unroll
-    for (int d = 0; d < DW; d++) bw[d] = __builtin_nontemporal_load(wt + (size_t)kbc(d) * 64);
-    i32x4 acc[2][3];
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) acc[mt][b] = i32x4{0, 0, 0, 0};
-
-    // chunk c of the slice's activation image: units [(kb0 + c CH) * 384, + ncb * 384) are contiguous in the image;
-    // 6 units per thread, requested BEFORE the MFMAs of the current chunk and written to the other LDS buffer after them
-    constexpr int UPT = SEQ_TW_CH * 384 / SEQ_NT;        // 6
-    static_assert(UPT * SEQ_NT == SEQ_TW_CH * 384, "chunk units must divide over the workgroup");
-    u32x4 sa[UPT];
-    auto stage_load = [&](int c) {
-        const int kbs = kb0 + c * SEQ_TW_CH, nu = min(SEQ_TW_CH, kb1 - kbs) * 384;
-        const u32x4 *src = a.img + (size_t)kbs * 384;
-#pragma unroll
-        for (int q = 0; q < UPT; q++) { const int u = threadIdx.x + q * SEQ_NT; sa[q] = src[u < nu ? u : nu - 1]; }
-    };
-    auto stage_write = [&](int buf) {
-        u32x4 *dst = abuf + (size_t)buf * CHU;
-#pragma unroll
-        for (int q = 0; q < UPT; q++) dst[threadIdx.x + q * SEQ_NT] = sa[q];
-    };
-    const int nch = (nkb + SEQ_TW_CH - 1) / SEQ_TW_CH;
-    if (nch > 0) { stage_load(0); stage_write(0); }
-    __syncthreads();
-    int it = 0;
-    for (int c = 0; c < nch; c++) {
-        if (c + 1 < nch) stage_load(c + 1);
-        const u32x4 *ab = abuf + (size_t)(c & 1) * CHU + lane;
-        const int ncb = min(SEQ_TW_CH, nkb - c * SEQ_TW_CH);
-#pragma unroll
-        for (int k = 0; k < SEQ_TW_CH; k++) {
-            if (k < ncb) {
-                const u32x4 w = bw[k % DW];
-                bw[k % DW] = __builtin_nontemporal_load(wt + (size_t)kbc(it + DW) * 64);
-                const i32x4 bf = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                    for (int b = 0; b < 3; b++) {
-                        const u32x4 av = ab[((k * 2 + mt) * 3 + b) * 64];
-                        const i32x4 af = i32x4{(int)av[0], (int)av[1], (int)av[2], (int)av[3]};
-                        acc[mt][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[mt][b], 0, 0, 0);
-                    }
-                it++;
-            }
-        }
-        if (c + 1 < nch) stage_write((c + 1) & 1);       // the other buffer: its last readers passed the previous barrier
-        __syncthreads();
-    }
-    if (live) {
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int t = mt * 16 + 4 * (lane >> 4) + r, row = tile * 16 + (lane & 15);
-                if (t < a.T && row < N)
-                    a.part[((size_t)j * SEQ_T + t) * N + row] =
-                        (double)acc[mt][0][r] + 256.0 * (double)acc[mt][1][r] + 65536.0 * (double)acc[mt][2][r];
-            }
-    }
-}
-constexpr size_t SEQ_TW_SMEM = (size_t)2 * SEQ_TW_CH * 2 * 3 * 64 * 16;   // 96 KiB
+constexpr size_t SEQ_KS_SMEM = sizeof(float) * SEQ_O * SEQ_TB * 2 * 4 * 64 + sizeof(float) * SEQ_T;
 
 } // namespace rwkvk
