@@ -557,9 +557,12 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
             HIPCHK(hipMemsetAsync(c->sq_qparta, 0, sizeof(SeqPart) * SEQ_T * SEQ_O, c->stream));
             HIPCHK(hipMemsetAsync(c->sq_qparth, 0, sizeof(SeqPart) * SEQ_T * SEQ_O, c->stream));
             if ((rc = dalloc(c, &c->sq_stat, (size_t)SEQ_T * SEQ_O))) return rc;
-            if ((rc = dalloc(c, &c->sq_pk3, (size_t)SEQ_O * SEQ_T * 3 * D))) return rc;
-            if ((rc = dalloc(c, &c->sq_pk5, (size_t)SEQ_O * SEQ_T * 5 * D))) return rc;
-            if ((rc = dalloc(c, &c->sq_pk1, (size_t)SEQ_O * SEQ_T * D))) return rc;
+            {   // accumulator images: [slice][tile][2][4][64] floats, tiles = classes x 16-channel blocks
+                const size_t cbd = ((size_t)D + 15) / 16;
+                if ((rc = dalloc(c, &c->sq_pk3, (size_t)SEQ_O * 3 * cbd * 512))) return rc;
+                if ((rc = dalloc(c, &c->sq_pk5, (size_t)SEQ_O * 5 * cbd * 512))) return rc;
+                if ((rc = dalloc(c, &c->sq_pk1, (size_t)SEQ_O * cbd * 512))) return rc;
+            }
             // second resident copy of the matrices: MFMA B-operand images (seq.hip.h k_bimage) + row sums per octant of K
             {
                 auto second = [&](const uint8_t *w_t, uint8_t **bdst, unsigned **rdst, uint64_t layers, uint64_t N, uint64_t K, int Q) -> int {

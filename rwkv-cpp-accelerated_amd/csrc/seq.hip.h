@@ -64,12 +64,19 @@ __device__ __forceinline__ float seq_so(const SeqPart *part, int m, int t)
     for (int o = 0; o < SEQ_O; o++) so += p[o].So;
     return so;
 }
-// value of a GEMM output from its per-slice partials pk[SEQ_O][SEQ_T][N] (each already scaled and corrected) and the offset term
-__device__ __forceinline__ float seq_val(const float *pk, int N, int t, size_t n, float so)
+// Per-slice partial values of a GEMM live in the ACCUMULATOR IMAGE of the MFMA tiles, pk[slice][tile id][row tile][reg][lane]
+// (so a wave stores a register with one coalesced 256-byte store): element (chunk row t, channel ch of class q) sits in
+// tile id = q * CB + ch / 16 at lane 16 * ((t % 16) / 4) + ch % 16, register t % 4, row tile t / 16.
+__device__ __forceinline__ size_t pk_index(int ntiles, int slice, int id, int t, int c16)
+{
+    return ((((size_t)slice * ntiles + id) * 2 + (t >> 4)) * 4 + (t & 3)) * 64 + 16 * ((t & 15) >> 2) + c16;
+}
+// value of a GEMM output from its per-slice partials (each already scaled and corrected) and the offset term
+__device__ __forceinline__ float seq_val(const float *pk, int ntiles, int id, int t, int c16, float so)
 {
     double v = 0.0;
 #pragma unroll
-    for (int q = 0; q < SEQ_O; q++) v += (double)pk[((size_t)q * SEQ_T + t) * N + n];
+    for (int q = 0; q < SEQ_O; q++) v += (double)pk[pk_index(ntiles, q, id, t, c16)];
     return (float)v + so;
 }
 // octant o of K elements, in units of 64 (a k-block never straddles two octants): [k0, k1)
@@ -185,9 +192,9 @@ __global__ __launch_bounds__(NT) void k_seq_embed(SeqEmbedArgs a)
 // (x = f32(x) + v, rwkv.cu:548-553); 2: ffn_v (x += v * sigmoid(r), :574-577,:407,:212).
 struct SeqResidArgs {
     double *x;                   // [T][D]
-    const float *pk;             // [SEQ_O][SEQ_T][D] per-slice partial values of the GEMM
+    const float *pk;             // per-slice partial values of the GEMM (Q = 1: tile id = channel / 16)
     const SeqPart *qpart;        // records of the GEMM's input vector: [T][SEQ_O]
-    const float *pk_gate;        // MODE 2: partials of the ffn k/r GEMM [SEQ_O][SEQ_T][5D], r of channel j at column 5 j + 4
+    const float *pk_gate;        // MODE 2: partials of the ffn k/r GEMM (5 classes), r = class 4
     const SeqPart *qpart_gate;   //         records of the ffn r input vector
     SeqStat *stat;               // [T][SEQ_O]
     int D, T;
@@ -206,10 +213,11 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_resid(SeqResidArgs a)
         const size_t e = (size_t)t * D + j;
         double x = a.x[e];
         if (MODE != 0) {
-            const float v = seq_val(a.pk, D, t, j, so);
+            const int CB = (D + 15) >> 4;
+            const float v = seq_val(a.pk, CB, j >> 4, t, j & 15, so);
             if (MODE == 1) x = (double)((float)x + v);
             else {
-                const float r = seq_val(a.pk_gate, 5 * D, t, 5 * (size_t)j + 4, sog);
+                const float r = seq_val(a.pk_gate, 5 * CB, 4 * CB + (j >> 4), t, j & 15, sog);
                 const float gt = (float)(1.0 / (1.0 + exp(-(double)r)));
                 x = x + (double)(v * gt);
             }
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_site(SeqSiteArgs a)
 // ------------------------------------------------------------------------------------------
 struct SeqStageArgs {
     const float *src;            // KIND 0: gated wkv y [T][D]
-    const float *pk;             // KIND 1: partials of the ffn k/r GEMM [SEQ_O][SEQ_T][5D], k of hidden unit 4 i + q at column 5 i + q
+    const float *pk;             // KIND 1: partials of the ffn k/r GEMM (5 classes): k of hidden unit 4 i + q = class q, channel i
     const SeqPart *qpart_k;      //         records of the ffn k input vector (its offset term)
     const float *r, *o;          // scale / offset over K
     unsigned *img;
@@ -352,7 +360,8 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_stage(SeqStageArgs a)
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    float k = seq_val(a.pk, K / 4 * 5, t, (size_t)qd * 5 + e, sok);      // hidden units 4 qd .. 4 qd + 3 = k0..k3 of channel qd
+                    const int CB = ((K >> 2) + 15) >> 4;
+                    float k = seq_val(a.pk, 5 * CB, e * CB + (qd >> 4), t, qd & 15, sok);   // hidden units 4 qd .. 4 qd + 3 = classes 0..3 of channel qd
                     k = k * (float)(k > 0.f);
                     f[e] = k * k;                                                          // relu(k)^2, rwkv.cu:189-190
                 }
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_stage(SeqStageArgs a)
 
 // ------------------------------------------------------------------------------------------
 struct SeqWkvArgs {
-    const float *pk;             // partials of the K/V/R GEMM [SEQ_O][SEQ_T][3D], column 3 i + m
+    const float *pk;             // partials of the K/V/R GEMM (3 classes)
     const SeqPart *qpart;        // records of the three input vectors [3][T][SEQ_O]
     const double *uw, *ew;       // bonus + decay, exp(decay) of this layer
     double *saa, *sbb;           // state of this layer, slot 0
@@ -400,9 +409,10 @@ __global__ __launch_bounds__(SEQ_T * WKV_CH) void k_seq_wkv(SeqWkvArgs a)
     const int i = blockIdx.x * WKV_CH + ch;
     const bool live = i < a.D && t < a.T;
     if (live) {
-        const float k = seq_val(a.pk, 3 * a.D, t, 3 * (size_t)i + 0, seq_so(a.qpart, 0, t));
-        const float v = seq_val(a.pk, 3 * a.D, t, 3 * (size_t)i + 1, seq_so(a.qpart, 1, t));
-        const float r = seq_val(a.pk, 3 * a.D, t, 3 * (size_t)i + 2, seq_so(a.qpart, 2, t));
+        const int CB = (a.D + 15) >> 4;
+        const float k = seq_val(a.pk, 3 * CB, 0 * CB + (i >> 4), t, i & 15, seq_so(a.qpart, 0, t));
+        const float v = seq_val(a.pk, 3 * CB, 1 * CB + (i >> 4), t, i & 15, seq_so(a.qpart, 1, t));
+        const float r = seq_val(a.pk, 3 * CB, 2 * CB + (i >> 4), t, i & 15, seq_so(a.qpart, 2, t));
         e1s[t][ch] = exp(a.uw[i] + (double)k);
         eks[t][ch] = exp((double)k);
         vs[t][ch] = (double)v;
@@ -497,7 +507,7 @@ struct SeqGemmArgs {
     int vec_of_q[5];             // activation vector each class multiplies (non-decreasing in q)
     const u32x4 *img[3];         // A-operand images of the vectors
     const SeqPart *part;         // quantisation records [NV][T][SEQ_O]
-    float *pk;                   // k_seq_gemm: [SEQ_O][SEQ_T][N] per-slice partial values
+    float *pk;                   // k_seq_gemm: per-slice partial values, accumulator image (pk_index)
     float *out;                  // k_seq_gemm_ks: [T][N]
     int T;
     int ntw;                     // k_seq_gemm: row tiles per wave in use (<= the template's NTW)
@@ -528,6 +538,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     constexpr bool DB = !MTS && NTW * NKB <= 16;        // second weight register set + second LDS buffer
     constexpr int CHU = NVS * NKB * 384;                // units of one LDS buffer: [vector][k][row tile][limb][lane]
     u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
+    double *recl = reinterpret_cast<double *>(smem + (size_t)(DB ? 2 : 1) * CHU * 16);   // [NVS][SEQ_T]{scale, cA} of this slice
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
     const int nch = (N + Q - 1) / Q, CB = (nch + 15) >> 4, ntiles = Q * CB;
@@ -541,14 +552,25 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     const int wg0 = rb * SEQ_NW * ntw, wg1 = min(wg0 + SEQ_NW * ntw, ntiles) - 1;
     const int vlo = a.vec_of_q[min(wg0, ntiles - 1) / CB], vhi = a.vec_of_q[max(wg1, 0) / CB];
 
+    // the slice's quantisation records of the vectors this workgroup multiplies: requested now, used by the epilogue
+    if (threadIdx.x < NVS * SEQ_T) {
+        const int v = min(vlo + (int)threadIdx.x / SEQ_T, vhi), t = threadIdx.x % SEQ_T;
+        const SeqPart rc = a.part[((size_t)v * SEQ_T + t) * SEQ_O + j];
+        recl[2 * threadIdx.x] = scale_of(rc.amax); recl[2 * threadIdx.x + 1] = rc.cA;
+    }
     const u32x4 *wt[NTW];
     int vi[NTW];
     bool tv[NTW];
+    unsigned rsv[NTW];          // row sum (this octant) of the row this lane finishes in tile i
 #pragma unroll
     for (int i = 0; i < NTW; i++) {
         const int id = id0 + i;
         tv[i] = i < ntw && id < ntiles;
         const int idc = tv[i] ? id : 0;
+        {
+            const int q = idc / CB, ch = 16 * (idc % CB) + (lane & 15), row = Q * ch + q;
+            rsv[i] = (tv[i] && ch < nch && row < N) ? a.rs8[(size_t)j * N + row] : 0u;
+        }
         wt[i] = a.bimg + ((size_t)idc * KB) * 64 + lane;
         vi[i] = a.vec_of_q[idc / CB] - vlo;
         vi[i] = vi[i] < 0 ? 0 : (vi[i] >= NVS ? NVS - 1 : vi[i]);
@@ -566,10 +588,13 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     auto stage_a = [&](int c, int buf) {
         const int kbs = kb0 + c * NKB, n = min(NKB, nkb - c * NKB);
         u32x4 *dst = abuf + (size_t)buf * CHU;
+        // every workgroup of an XCD copies the same image slice: each starts at its own offset so that they do not all
+        // hit the same L2 channel at the same moment
+        const int nu = n * 384, rot = nu > 0 ? (int)(((long long)(rb % 32) * nu) / 32) : 0;
         for (int v = vlo; v <= vhi && v - vlo < NVS; v++) {
             const u32x4 *src = a.img[v] + (size_t)kbs * 384;
             u32x4 *d = dst + (size_t)(v - vlo) * NKB * 384;
-            for (int u = threadIdx.x; u < n * 384; u += SEQ_NT) d[u] = src[u];
+            for (int u0 = threadIdx.x; u0 < nu; u0 += SEQ_NT) { int u = u0 + rot; u = u >= nu ? u - nu : u; d[u] = src[u]; }
         }
     };
     if (nchunk > 0) { load_b(0, 0); stage_a(0, 0); }
@@ -584,23 +609,18 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
 #pragma unroll
                 for (int b = 0; b < 3; b++) acc[i][mt][b] = i32x4{0, 0, 0, 0};
     };
-    // per-slice value of tile i, row tile mt (accumulator set ms) -> pk
+    // per-slice value of tile i, row tile mt (accumulator set ms) -> pk, one coalesced 256-byte store per register
     auto emit = [&](int mt, int ms) {
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
             if (!tv[i]) continue;
-            const int id = id0 + i, q = id / CB, ch = 16 * (id % CB) + (lane & 15), row = Q * ch + q;
-            const int v = a.vec_of_q[q];
-            const bool rok = ch < nch && row < N;
-            const unsigned rs = rok ? a.rs8[(size_t)j * N + row] : 0u;
+            const int id = id0 + i;
+            const double *rl = recl + 2 * ((size_t)vi[i] * SEQ_T + mt * 16 + 4 * (lane >> 4));
+            float *dst = a.pk + ((((size_t)j * ntiles + id) * 2 + mt) * 4) * 64 + lane;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int t = mt * 16 + 4 * (lane >> 4) + r;
-                if (t < a.T && rok) {
-                    const SeqPart rc = a.part[((size_t)v * SEQ_T + t) * SEQ_O + j];
-                    const double M = (double)acc[i][ms][0][r] + 256.0 * (double)acc[i][ms][1][r] + 65536.0 * (double)acc[i][ms][2][r];
-                    a.pk[((size_t)j * SEQ_T + t) * N + row] = (float)seq_slice_value(rc, M, rs);
-                }
+                const double M = (double)acc[i][ms][0][r] + 256.0 * (double)acc[i][ms][1][r] + 65536.0 * (double)acc[i][ms][2][r];
+                dst[r * 64] = (float)(rl[2 * r] * (M + rl[2 * r + 1] + SEQ_CU * (double)rsv[i]));   // scale_o (M + cA_o + CU rowsum_o); rows / columns past the end are never read
             }
         }
     };
@@ -656,7 +676,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
                     const int kbs = kb0 + cn * NKB, nu = min(NKB, nkb - cn * NKB) * 384;
                     const u32x4 *src = a.img[vlo] + (size_t)kbs * 384;
 #pragma unroll
-                    for (int q = 0; q < UPT; q++) { const int u = threadIdx.x + q * SEQ_NT; sa[q] = src[u < nu ? u : nu - 1]; }
+                    for (int q = 0; q < UPT; q++) { const int u = threadIdx.x + q * SEQ_NT; sa[q] = src[u < nu ? u : (nu > 0 ? nu - 1 : 0)]; }
                 }
                 if (c & 1) { load_b(0, cn); mult(1, 1, c, 0); } else { load_b(1, cn); mult(0, 0, c, 0); }
                 {
@@ -678,7 +698,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
         emit(1, 1);
     }
 }
-constexpr size_t seq_gemm_smem(int ntw, int nkb, bool mts, int nvs) { return (size_t)((!mts && ntw * nkb <= 16) ? 2 : 1) * nvs * nkb * 384 * 16; }
+constexpr size_t seq_gemm_smem(int ntw, int nkb, bool mts, int nvs) { return (size_t)((!mts && ntw * nkb <= 16) ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
 
 // ------------------------------------------------------------------------------------------
 constexpr int SEQ_TB = 5;        // weight tiles (16 rows each) per workgroup pass of k_seq_gemm_ks
