@@ -400,11 +400,11 @@ struct SeqWkvArgs {
 };
 constexpr int WKV_CH = 16;       // channels per workgroup (512 threads = 16 channels x 32 rows)
 // rwkv.cu:242-255 with the GPT-mode state slot 0.  The exponentials do not depend on the state, so
-// one thread per (row, channel) evaluates them; then one thread per channel runs the recurrence
-// along the chunk (a division and a few fma per step).
+// one thread per (row, channel) evaluates them; then one thread per channel runs the (linear) state
+// recurrence along the chunk and the outputs are finished in parallel.
 __global__ __launch_bounds__(SEQ_T * WKV_CH) void k_seq_wkv(SeqWkvArgs a)
 {
-    __shared__ double e1s[SEQ_T][WKV_CH], eks[SEQ_T][WKV_CH], vs[SEQ_T][WKV_CH], sgs[SEQ_T][WKV_CH];
+    __shared__ double e1s[SEQ_T][WKV_CH], eks[SEQ_T][WKV_CH], vs[SEQ_T][WKV_CH], sgs[SEQ_T][WKV_CH], aas[SEQ_T][WKV_CH];
     const int ch = threadIdx.x & (WKV_CH - 1), t = threadIdx.x / WKV_CH;
     const int i = blockIdx.x * WKV_CH + ch;
     const bool live = i < a.D && t < a.T;
@@ -430,17 +430,25 @@ __global__ __launch_bounds__(SEQ_T * WKV_CH) void k_seq_wkv(SeqWkvArgs a)
         }
         return;
     }
+    // GPT mode: the state recurrences aa' = (aa + e^k v) e^w, bb' = (bb + e^k) e^w are LINEAR -- one thread per channel walks
+    // them along the chunk (two fma per step) and leaves the state every row sees; the divisions of all (row, channel) pairs
+    // then run in parallel (rwkv.cu:242-255 evaluates the same expressions in the same order per row)
     if (threadIdx.x < WKV_CH && i < a.D) {
         double aa = a.saa[i], bb = a.sbb[i];
         const double ew = a.ew[i];
         for (int tt = 0; tt < a.T; tt++) {
-            const double e1 = e1s[tt][ch], ek = eks[tt][ch], vv = vs[tt][ch];
-            const double y = sgs[tt][ch] * ((aa + e1 * vv) / (bb + e1));
+            const double ek = eks[tt][ch], vv = vs[tt][ch];
+            eks[tt][ch] = aa;                 // state before row tt (the slot of e^k is free once read)
+            aas[tt][ch] = bb;
             aa = (aa + ek * vv) * ew;
             bb = (bb + ek) * ew;
-            a.y[(size_t)tt * a.D + i] = (float)y;
         }
         a.saa[i] = aa; a.sbb[i] = bb;
+    }
+    __syncthreads();
+    if (live) {
+        const double e1 = e1s[t][ch];
+        a.y[(size_t)t * a.D + i] = (float)(sgs[t][ch] * ((eks[t][ch] + e1 * vs[t][ch]) / (aas[t][ch] + e1)));
     }
 }
 

@@ -315,3 +315,40 @@ def test_pipeline_processes_with_engine_stages(eng_mod, world):
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert np.array_equal(got, want)
+
+
+def test_config1_169m_reference_converter_file_greedy_decode(eng_mod, oracle, tmp_path):
+    """BASELINE config 1: RWKV-4 169M (L=12, D=768), a model.bin equal to what the REFERENCE CONVERTER writes for the
+    checkpoint (tests/golden/converter_169M.npz holds the sha256 of every tensor of the reference converter's own file;
+    the offset vectors may differ by 4e-7, torch's vs numpy's reduction order), storygen-style greedy decode (out[0]
+    banned) on the CPU path (the oracle = restated reference) and through the engine: same ids, logits within 1e-3."""
+    import test_converter_cpu as tc
+    from rwkv_cpp_accelerated_amd import converter
+    fix = os.path.join(tc.GOLD, "converter_169M.npz")
+    g = np.load(fix)
+    L, D, seed = int(g["L"]), int(g["D"]), int(g["seed"])
+    assert (L, D) == mf.SHAPES["169M"]
+    _, _, t = converter.convert_state_dict(converter.synthetic_state_dict(L, D, seed))
+    assert tc.converted_equals_reference_file(g, t) >= mf.N_TENSORS - 8
+    p = str(tmp_path / "model.bin")
+    mf.write_bin(p, L, D, t)
+    assert os.path.getsize(p) == int(g["file_bytes"])
+    m = eng_mod.RWKV(resident=True); m.loadFile(p, 32)
+    om = oracle.open_file(p)
+    st = om.new_state()
+    prompt = [int(x) for x in np.random.default_rng(169).integers(2, mf.VOCAB, 40)]
+    ref = om.forward(prompt, st)                                   # the reference's loadContext semantics, token by token
+    got = m.forward(prompt[:32], eng_mod.MODE_GPT)                 # the engine: a 32-token chunk, then the rest
+    got = m.forward(prompt[32:], eng_mod.MODE_GPT)[: 8 * mf.VOCAB].reshape(8, mf.VOCAB)[-1]
+    parity.check_logits(got, ref[-1], "169M prompt")
+    tk = parity.argmax_ban0(ref[-1])
+    ids_ref, ids_eng = [], []
+    for step in range(48):                                         # storygen's loop with argmax (storygen.cpp:63-69)
+        lr = om.forward([tk], st)[0]
+        le = m.forward(tk)[: mf.VOCAB]
+        parity.check_logits(le, lr, f"169M step {step}")
+        parity.check_argmax(le, lr, f"169M step {step}")
+        ids_ref.append(parity.argmax_ban0(lr)); ids_eng.append(parity.argmax_ban0(le))
+        tk = ids_ref[-1]
+    assert len(set(ids_ref)) > 8
+    om.close(); m.close()
