@@ -100,6 +100,12 @@ struct Pipe {
     const char *(*GetErrorString)(int) = nullptr;
 };
 
+// decode kernels that stream through the LDS ring: -1 = by model width (measured on MI355X, profiles/r02/ring_sweep.txt):
+// rows of 3-4 KiB gain 4-5 % with k_att, k_ffn_rk and k_ffnv on the ring; 5 KiB rows (few, large slots) ~0; <= 2 KiB rows lose
+#ifndef RWKV_RING
+#define RWKV_RING -1
+#endif
+
 struct rwkv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -108,6 +114,7 @@ struct rwkv_ctx {
     uint64_t L = 0, D = 0, maxT = 1;
     uint64_t l0 = 0, l1 = UINT64_MAX;   // pipeline stage: this context owns layers [l0, l1) (whole model by default)
     int S = 0;               // ceil(D / 1024): 1 KiB row pieces per lane
+    int ring = RWKV_RING;    // decode kernels that stream their weights through the LDS ring (bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv, 4 k_head; env RWKV_RING)
 
     // weights (device)
     float *embed = nullptr;
@@ -182,6 +189,14 @@ size_t smem_attout(int S) { return RED_BYTES + (size_t)S * 3072; }
 size_t smem_frk(int S) { return RED_BYTES + 2 * (size_t)S * 3072; }
 size_t smem_fv(int S) { return RED_BYTES + 4 * (size_t)S * 3072; }
 size_t smem_head(int S) { return RED_BYTES + (size_t)S * 3072 + NW * 8; }
+// ring kernels: slots of R x S KiB behind the staged vectors, as many as fit the CU's 160 KiB
+constexpr size_t LDS_BYTES = 160 * 1024;
+int ring_slots(size_t fixed, int R, int S)
+{
+    const size_t n = (LDS_BYTES - fixed - sizeof(GldsCtl)) / ((size_t)R * S * 1024);
+    return (int)std::min<size_t>(n, GLDS_MAX_SLOTS);
+}
+size_t smem_ring(size_t fixed, int R, int S) { return fixed + sizeof(GldsCtl) + (size_t)ring_slots(fixed, R, S) * R * S * 1024; }
 
 #ifndef RWKV_ATTOUT_R
 #define RWKV_ATTOUT_R 2
@@ -246,7 +261,8 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
         aa.slot_stride = LD; aa.ybuf = c->ybuf; aa.partS = c->partA; aa.partM = c->partMA;
         aa.ctl = c->ctl; aa.D = D; aa.tl = tl_of(1);
-        DISPATCH_S(S, k_att<S_, nb_att(S_)><<<dim3(grid), dim3(NT), smem_att(S), c->stream>>>(aa));
+        if (c->ring & 1) { aa.ns = ring_slots(smem_att(S), 3, S); DISPATCH_S(S, k_att<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_att(S), 3, S), c->stream>>>(aa)); }
+        else DISPATCH_S(S, k_att<S_, nb_att(S_)><<<dim3(grid), dim3(NT), smem_att(S), c->stream>>>(aa));
     } break;
     case 2: {
         AttOutArgs ao;
@@ -254,7 +270,8 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         ao.x = c->x; ao.lnw = c->ln + (4 * l + 2) * D; ao.lnb = c->ln + (4 * l + 3) * D; ao.lnstat = c->lnstat + 0;
         ao.sxy = c->state[0] + lo; ao.st = site_static(1, l); ao.dy = site_dyn(1, grid); ao.sdd = c->state[4] + lo;
         ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.tl = tl_of(2);
-        DISPATCH_S(S, k_attout<S_, ATTOUT_R, nb_attout(S_)><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
+        if (c->ring & 2) { ao.ns = ring_slots(smem_attout(S), ATTOUT_R, S); DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_attout(S), ATTOUT_R, S), c->stream>>>(ao)); }
+        else DISPATCH_S(S, k_attout<S_, ATTOUT_R, nb_attout(S_)><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
     } break;
     case 3: {
         FfnRKArgs fa;
@@ -263,6 +280,8 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.partM = c->partMF; fa.ctl = c->ctl; fa.D = D;
         fa.tl = tl_of(3);
+        if (c->ring & 4) { fa.ns = ring_slots(smem_frk(S), 5, S); DISPATCH_S(S, k_ffn_rk<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_frk(S), 5, S), c->stream>>>(fa)); }
+        else
         DISPATCH_S(S, k_ffn_rk<S_, nb_frk(S_)><<<dim3(grid), dim3(NT), smem_frk(S), c->stream>>>(fa));
     } break;
     case 4: {
@@ -270,11 +289,16 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
         fv.rgate = c->rgate; fv.x = c->x; fv.lnw = c->ln + (4 * l + 4) * D; fv.lnb = c->ln + (4 * l + 5) * D; fv.lnstat = c->lnstat + 2;
         fv.sdd = c->state[4] + lo; fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D; fv.tl = tl_of(4);
+        fv.ns = ring_slots(smem_fv(S), 4, S);
         if (l + 1 < c->l1) {   // next consumer: k_att of layer l+1
             fv.st = site_static(0, l + 1); fv.dy = site_dyn(0, grid); fv.sprev = c->state[0] + lo + D;
+            if (c->ring & 8) { DISPATCH_S(S, k_ffnv<S_, 3, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_fv(S), 4, S), c->stream>>>(fv)); }
+            else
             DISPATCH_S(S, k_ffnv<S_, 3, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
         } else {               // next consumer: k_head (on a non-final pipeline stage nobody reads it: the next stage's k_first re-opens its own site from x)
             fv.st = site_static(2, 0); fv.dy = site_dyn(2, grid); fv.sprev = nullptr;
+            if (c->ring & 8) { DISPATCH_S(S, k_ffnv<S_, 1, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_fv(S), 4, S), c->stream>>>(fv)); }
+            else
             DISPATCH_S(S, k_ffnv<S_, 1, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
         }
     } break;
@@ -282,7 +306,8 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         HeadArgs ha;
         ha.x = c->x; ha.st = site_static(2, 0); ha.dy = site_dyn(2, grid); ha.w = c->w_head; ha.rs = c->rs_head; ha.logits = c->logits;
         ha.blk_val = c->blk_val; ha.blk_idx = c->blk_idx; ha.ctl = c->ctl; ha.D = D;
-        DISPATCH_S(S, k_head<S_, nb_head(S_)><<<dim3(grid), dim3(NT), smem_head(S), c->stream>>>(ha));
+        if (c->ring & 16) { ha.ns = ring_slots(smem_head(S), RWKV_HEAD_RR, S); DISPATCH_S(S, k_head<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_head(S), RWKV_HEAD_RR, S), c->stream>>>(ha)); }
+        else DISPATCH_S(S, k_head<S_, nb_head(S_)><<<dim3(grid), dim3(NT), smem_head(S), c->stream>>>(ha));
     } break;
     default:
         k_argmax_finish<<<dim3(1), dim3(64), 0, c->stream>>>(c->blk_val, c->blk_idx, grid, c->ctl, c->gen, c->gen_cap);
@@ -377,6 +402,12 @@ int set_smem_limits(rwkv_ctx *c)
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, nb_fv(S_)>, smem_fv(S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, nb_fv(S_)>, smem_fv(S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_head<S_, nb_head(S_)>, smem_head(S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_att<S_, 1, true>, smem_ring(smem_att(S), 3, S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R, 1, true>, smem_ring(smem_attout(S), ATTOUT_R, S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_, 1, true>, smem_ring(smem_frk(S), 5, S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, 1, true>, smem_ring(smem_fv(S), 4, S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, true>, smem_ring(smem_fv(S), 4, S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_head<S_, 1, true>, smem_ring(smem_head(S), RWKV_HEAD_RR, S))); if (rc) return rc;
     return 0;
 }
 
@@ -389,6 +420,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if (max_ctx == 0) max_ctx = 1;
     HIPCHK(hipSetDevice(c->device));
     c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
+    if (c->ring < 0) c->ring = (c->S == 3 || c->S == 4) ? 13 : (c->S == 5 ? 5 : 0);
     if (c->l1 == UINT64_MAX) c->l1 = L;
     if (c->l0 >= c->l1 || c->l1 > L) return fail(RWKV_E_ARG, "layer range [%llu, %llu) does not fit a %llu-layer model", (unsigned long long)c->l0, (unsigned long long)c->l1, (unsigned long long)L);
     const uint64_t l0 = c->l0, l1 = c->l1, nl = l1 - l0;
@@ -740,6 +772,7 @@ int rwkv_create(rwkv_ctx **out, int device)
     c->grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char *g = getenv("RWKV_GRID");
     if (g && atoi(g) > 0) c->grid = atoi(g);
+    { const char *e = getenv("RWKV_RING"); if (e) c->ring = atoi(e); }
     if (c->grid > NT / 2) c->grid = NT / 2;   // consumers sum one partial per thread of the prologue waves (half the workgroup)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(RWKV_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }

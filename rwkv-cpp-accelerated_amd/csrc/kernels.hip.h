@@ -558,6 +558,9 @@ constexpr int RED_BC = 96;     // doubles: scalars published by the prologue wav
 #ifndef RWKV_HEAD_R
 #define RWKV_HEAD_R 2      // rows per group in k_head (measured: 2 -> 35.8, 3 -> 36.2, 4 -> 36.8, 5 -> 38.0 us at 7B)
 #endif
+#ifndef RWKV_HEAD_RR
+#define RWKV_HEAD_RR 4     // the same in the ring variant (a group = one LDS slot: larger groups, fewer hand-offs)
+#endif
 // Row-group buffers per wave: 1, or 2 (a wave holds TWO groups of weight registers, A and B, and alternates between
 // them: R*S*2 loads requested ahead).  Measured on MI355X (profiles/r02/decode_variants.txt) two buffers LOSE 8 % at 7B
 // (485 vs 528 tokens/s): the CU's memory pipe accepts only ~16 KB of requests, so a loader wave that asks for two groups
@@ -778,6 +781,244 @@ __device__ __forceinline__ void vec_open(const float *vec, const double *partS, 
 }
 
 // ------------------------------------------------------------------------------------------
+// LDS-DMA streaming ("ring" kernels: template parameter RING of the five decode kernels, RWKV_RING bit per kernel class).
+// Loads into registers top out at ~10 B/clk per CU on this chip whatever is kept in flight;
+// global_load_lds_dwordx4 -- the CU's DMA path from memory into LDS -- does not return through the vector register file.
+// The workgroup's row groups travel through a ring of `ns` LDS slots (one group of R rows x S KiB each):
+//   * the LAST wave of the workgroup is the loader: it issues the DMA of group k into slot k % ns -- R*S wave instructions
+//     of 1 KiB -- keeps up to DEPTH groups (<= 63 instructions, the vmcnt range) in flight and publishes a group
+//     (ready[slot] = k + 1) once its vmcnt says the group has landed (data returns in order);
+//   * the other NW-1 waves consume: group k belongs to wave k % (NW-1); it waits for ready[slot], copies the slot into
+//     registers (R*S ds_read_b128), hands the slot back (freeq[slot] = k + 1) and runs the same group_dot + epilogue as
+//     the register kernels;
+//   * the loader starts at the kernel's first instruction: the ring (>= 90 KiB) holds what HBM delivers during the
+//     prologue, which waves 0..3 run as in the SPLIT kernels.  No workgroup barrier sits between the order barrier and
+//     the closing reduction -- the roles meet on LDS counters only, and every wait loop is bounded.
+// The DMA is inline asm (hipcc would otherwise count it in vmcnt and drain it before every LDS access of the loader);
+// m0 carries the wave-uniform LDS destination and is restored for the compiler.
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ void dma_piece(const uint8_t *src, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+constexpr int GLDS_SPIN = 1 << 18;    // bound of every wait loop (a lost hand-off must end the kernel, not hang the GPU)
+__device__ __forceinline__ void wait_seq(const unsigned *p, unsigned want)
+{
+    for (int it = 0; it < GLDS_SPIN; it++) {
+        if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == want) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void wait_count(const unsigned *p, unsigned least)
+{
+    for (int it = 0; it < GLDS_SPIN; it++) {
+        if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= least) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+constexpr int GLDS_MAX_SLOTS = 24;
+struct GldsCtl {            // LDS control block of the ring (64 dwords)
+    unsigned staged;        // prologue waves that have staged their part of the vector
+    unsigned pad[3];
+    unsigned ready[GLDS_MAX_SLOTS];     // ready[slot] = k + 1: group k has landed in the slot
+    unsigned freeq[GLDS_MAX_SLOTS];     // freeq[slot] = k + 1: group k has been copied out of the slot
+    unsigned pad2[12];
+};
+constexpr int NC = NW - 1;              // consumer waves of a ring kernel
+template <int R, int S> __host__ __device__ constexpr int glds_depth() { return 63 / (R * S) < 7 ? 63 / (R * S) : 7; }
+template <int RS, int D> struct GldsDrain {      // with at most D groups still in flight the others have landed
+    template <class F> static __device__ __forceinline__ void run(int &pend, F &publish)
+    {
+        wait_vm<D * RS>();
+        while (pend > D) publish();
+        GldsDrain<RS, D - 1>::run(pend, publish);
+    }
+};
+template <int RS> struct GldsDrain<RS, -1> { template <class F> static __device__ __forceinline__ void run(int &, F &) {} };
+
+// the loader wave: groups [g0, g1) of the workgroup in order; base(g) = address of group g's first row
+template <int R, int S, class Base>
+__device__ __forceinline__ void glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int ns, unsigned ring, GldsCtl *ctl, int lane)
+{
+    constexpr int RS = R * S, DEPTH = glds_depth<R, S>();
+    static_assert(DEPTH >= 1, "a row group must fit the 6-bit vmcnt");
+    unsigned off[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        int c = lane + 64 * s;
+        c = c < chunks ? c : chunks - 1;
+        off[s] = (unsigned)c << 4;
+    }
+    const int ng = g1 - g0;
+    int pend = 0, pub = 0;        // groups in flight; oldest group in flight
+    auto publish = [&]() {
+        if (lane == 0) __hip_atomic_store(&ctl->ready[pub % ns], (unsigned)pub + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pub++; pend--;
+    };
+    for (int k = 0; k < ng; k++) {
+        const int slot = k % ns;
+        if (pend == DEPTH) { wait_vm<(DEPTH - 1) * RS>(); publish(); }      // at most DEPTH * RS <= 63 pieces in flight
+        if (k >= ns && __hip_atomic_load(&ctl->freeq[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(k - ns) + 1u) {
+            // the consumers are behind: publish everything in flight before blocking (the consumer of the slot's old group
+            // may be queued behind a group this wave has not announced yet)
+            wait_vm<0>();
+            while (pend > 0) publish();
+            wait_seq(&ctl->freeq[slot], (unsigned)(k - ns) + 1u);
+        }
+        const uint8_t *gb = base(g0 + k);
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring + (unsigned)slot * (RS * 1024)));
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+            for (int r = 0; r < R; r++) dma_piece(gb + r * stride + off[s], dst + (r * S + s) * 1024);
+        pend++;
+    }
+    GldsDrain<RS, DEPTH - 1>::run(pend, publish);
+}
+// consumer side of one group: wait, copy the slot into registers, hand the slot back
+template <int R, int S>
+__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int k, int ns, const unsigned char *ring, GldsCtl *ctl, int lane)
+{
+    const int slot = k % ns;
+    wait_seq(&ctl->ready[slot], (unsigned)k + 1u);
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(ring + (size_t)slot * (R * S * 1024)) + lane;
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+        for (int r = 0; r < R; r++) w[r][s] = p[(r * S + s) * 64];
+    if (lane == 0) __hip_atomic_store(&ctl->freeq[slot], (unsigned)k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the consumer waves' streaming loop (wave < NC): same pre / epi contract as stream_groups
+template <int R, int S, int PAT, class Pre, class Epi>
+__device__ __forceinline__ void ring_groups(int g0, int g1, int ns, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
+                                            int chunks, Pre pre, Epi epi)
+{
+    for (int g = g0 + wave; g < g1; g += NC) {
+        const auto in = pre(g);
+        u32x4 w[R][S];
+        glds_take<R, S>(w, g - g0, ns, ring, ctl, lane);
+        unsigned long long T[R];
+        group_dot<R, S, PAT, false>(w, xq, lane, T, nullptr, 0, chunks, false);
+        epi(g, T, in);
+    }
+}
+// ring kernels: the control block is zeroed before the order barrier
+__device__ __forceinline__ void ring_init(GldsCtl *gc)
+{
+    if (threadIdx.x < sizeof(GldsCtl) / 4) reinterpret_cast<unsigned *>(gc)[threadIdx.x] = 0u;
+}
+// LayerNorm-site prologue of a ring kernel, called by the consumer waves (wave < NC): waves 0..3 stage the NV vectors and
+// publish the scalars, the others wait; contains the workgroup's order barrier, which the loader executes once as well
+template <int NV, int S>
+__device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &dy, const double *x, int D, double *red, unsigned *xq,
+                                          SiteRed<NV> &sr, bool publish_stats, GldsCtl *gc, unsigned long long *tl)
+{
+    constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
+    const int nqd = D >> 2;
+    float *bc = reinterpret_cast<float *>(red + RED_BC);
+    unsigned *spin = reinterpret_cast<unsigned *>(bc + 8);
+    if ((int)(threadIdx.x >> 6) < NWP) {
+        double tc[NV];
+        float mc[NV];
+#pragma unroll
+        for (int m = 0; m < NV; m++) { tc[m] = st.TC[m]; mc[m] = st.maxC[m]; }
+        SiteTuple tup;
+        site_tuple_load(dy, tup);
+        double xl[NQP][4];
+        f32x4 Cq[NQP][NV], Bq[NQP][NV];
+#pragma unroll
+        for (int i = 0; i < NQP; i++) {
+            const int qd = threadIdx.x + i * NTP, qc = qd < nqd ? qd : nqd - 1;
+            load_quad_f64(x, qc, xl[i]);
+#pragma unroll
+            for (int m = 0; m < NV; m++) {
+                Cq[i][m] = reinterpret_cast<const f32x4 *>(st.C + (size_t)m * D)[qc];
+                Bq[i][m] = reinterpret_cast<const f32x4 *>(dy.B + (size_t)m * D)[qc];
+            }
+        }
+        tl_stamp(tl, 1);
+        if (threadIdx.x == 0) *spin = 0u;
+        __syncthreads();   // order
+        SiteRed<NV> r;
+        site_reduce<NV, NWP>(st, dy, tup, D, red, r, tc, mc, tl, spin);
+        if (publish_stats && blockIdx.x == 0 && threadIdx.x == 0) { dy.lnstat[0] = r.mean; dy.lnstat[1] = r.rstd; }
+        tl_stamp(tl, 4);
+        site_stage<NV, NQP, S, NTP>(xl, Cq, Bq, r, xq, nqd);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int m = 0; m < NV; m++) { bc[m] = (float)r.S[m]; bc[4 + m] = r.amax[m]; }
+        }
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&gc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __syncthreads();   // order
+    }
+    wait_count(&gc->staged, NWP);
+#pragma unroll
+    for (int m = 0; m < NV; m++) { sr.S[m] = (double)bc[m]; sr.amax[m] = bc[4 + m]; }
+    sr.mean = sr.rstd = 0.0;
+    tl_stamp(tl, 5);
+}
+// plain-vector prologue of a ring kernel (k_attout, k_ffnv), same roles
+template <int NVEC, int S>
+__device__ __forceinline__ void ring_vec(const float *vec, const double *partS, const float *partM, int n_part, int D, double *red, unsigned *xq,
+                                         float &Sf, float &amax, GldsCtl *gc, unsigned long long *tl)
+{
+    constexpr int XVD = xvd<S>();
+    constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nqd = D >> 2;
+    float *bc = reinterpret_cast<float *>(red + RED_BC);
+    unsigned *spin = reinterpret_cast<unsigned *>(bc + 8);
+    if (wave < NWP) {
+        double ps = partS[(int)threadIdx.x < n_part ? threadIdx.x : 0];
+        float pm = partM[(int)threadIdx.x < n_part ? threadIdx.x : 0];
+        float vl[NVEC][NQP][4];
+#pragma unroll
+        for (int q = 0; q < NVEC; q++)
+#pragma unroll
+            for (int i = 0; i < NQP; i++) {
+                const int qd = threadIdx.x + i * NTP, qc = qd < nqd ? qd : nqd - 1;
+                const f32x4 t = reinterpret_cast<const f32x4 *>(vec + (size_t)q * D)[qc];
+                vl[q][i][0] = t[0]; vl[q][i][1] = t[1]; vl[q][i][2] = t[2]; vl[q][i][3] = t[3];
+            }
+        tl_stamp(tl, 1);
+        if (threadIdx.x == 0) *spin = 0u;
+        __syncthreads();   // order
+        if ((int)threadIdx.x >= n_part) { ps = 0.0; pm = 0.f; }
+        float *redf = reinterpret_cast<float *>(red + RED_MAX);
+        const double ws = wave_sum(ps);
+        const float wm = wave_max(pm);
+        if (lane == 0) { red[RED_OFFS + wave] = ws; redf[wave] = wm; }
+        tl_stamp(tl, 3);
+        if (lane == 0) __hip_atomic_fetch_add(spin, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        wait_count(spin, NWP);
+        double ts = 0.0; float tm = 0.f;
+#pragma unroll
+        for (int i = 0; i < NWP; i++) { ts += red[RED_OFFS + i]; tm = fmaxf(tm, redf[i]); }
+        tl_stamp(tl, 4);
+#pragma unroll
+        for (int q = 0; q < NVEC; q++)
+#pragma unroll
+            for (int i = 0; i < NQP; i++) {
+                const int qd = threadIdx.x + i * NTP;
+                if (qd < S * 256) stage_quad(xq + q * XVD, qd, vl[q][i], inv_scale(tm), qd < nqd);
+            }
+        if (threadIdx.x == 0) { bc[0] = (float)ts; bc[4] = tm; }
+        if (lane == 0) __hip_atomic_fetch_add(&gc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __syncthreads();   // order
+    }
+    wait_count(&gc->staged, NWP);
+    Sf = bc[0]; amax = bc[4];
+    tl_stamp(tl, 5);
+}
+
+// ------------------------------------------------------------------------------------------
 struct FirstArgs {
     const float *embed;   // [V][D] f32 (device resident), first stage only
     const double *ln;     // layernorm table; rows 0,1 = ln0 weight, bias
@@ -838,12 +1079,13 @@ struct AttArgs {
     float *partM;                         // [gridDim.x] partial max |ybuf| (k_attout's quantisation scale)
     const Ctl *ctl;
     int D;
+    int ns;                               // ring kernels: LDS slots
     unsigned long long *tl;               // optional phase timeline (see tl_stamp)
 };
 
 // ln1 site -> K,V,R dequant-GEMV -> WKV (rwkv.cu:535-545; kernels :351-392, :58-100, :221-259)
 struct AttIn { unsigned rs[3]; double aa, bb, uw, ew; float ra, oa; };
-template <int S, int NB>
+template <int S, int NB, bool RING = false>
 __global__ __launch_bounds__(NT) void k_att(AttArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -856,49 +1098,69 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
 
     tl_stamp(a.tl, 0);
-    u32x4 wA[3][S], wB[3][S];
-    int gA, gB;
-    unsigned *gctr = group_counter(red);
-    first_groups<NB>(g0, wave, gctr, gA, gB);   // the counter is visible behind the prologue's barriers
     // every wave requests its first groups, even one without work (it re-reads a neighbour's rows): a
     // branch around the loads would make hipcc's waitcnt pass drain the weights early
     auto base = [&](int g) { return a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 3 * D; };
-    SiteRed<3> sr;
-    site_open<3, 3, S, (RWKV_SPLIT & 1) != 0, NB>(a.st, a.dy, a.x, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, sr, true, a.tl);
-    const double sc[3] = {scale_of(sr.amax[0]), scale_of(sr.amax[1]), scale_of(sr.amax[2])};
-    const float S0 = (float)sr.S[0], S1 = (float)sr.S[1], S2 = (float)sr.S[2];
-
+    double sc[3];
+    float S0, S1, S2;
+    auto scalars = [&](const SiteRed<3> &sr) {
+        sc[0] = scale_of(sr.amax[0]); sc[1] = scale_of(sr.amax[1]); sc[2] = scale_of(sr.amax[2]);
+        S0 = (float)sr.S[0]; S1 = (float)sr.S[1]; S2 = (float)sr.S[2];
+    };
     // channel g = one group of three rows (K, V, R); the wave that finished them runs the WKV recurrence and the
     // receptance gate of that channel at once (rwkv.cu:242-255): no staging of k/v/r, no pass after the last row
     double part = 0.0;
     float pmax = 0.f;
-    stream_groups<3, S, PAT_PER_ROW, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base,
-        [&](int g) {
-            AttIn in;
+    auto pre = [&](int g) {
+        AttIn in;
 #pragma unroll
-            for (int m = 0; m < 3; m++) in.rs[m] = a.rs[g * 3 + m];
-            in.aa = a.saa[so + g]; in.bb = a.sbb[so + g]; in.uw = a.uw[g]; in.ew = a.ew[g];
-            in.ra = a.r_att[g]; in.oa = a.o_att[g];
-            return in;
-        },
-        [&](int g, const unsigned long long (&T)[3], const AttIn &in) {
-            if (lane == 0) {
-                const float k = row_value(T[0], in.rs[0], sc[0]) + S0, v = row_value(T[1], in.rs[1], sc[1]) + S1;
-                const float r = row_value(T[2], in.rs[2], sc[2]) + S2;
-                const double vv = (double)v;
-                const double e1 = exp(in.uw + (double)k);
-                double y = (in.aa + e1 * vv) / (in.bb + e1);
-                y = (1.0 / (1.0 + (double)expf(-r))) * y;       // rwkv.cu:250: exp of a float argument
-                const double ek = exp((double)k);
-                a.saa[so + g] = (in.aa + ek * vv) * in.ew;
-                a.sbb[so + g] = (in.bb + ek) * in.ew;
-                const float yf = (float)y;                       // att_out GEMV casts its input to f32 (rwkv.cu:290)
-                const float ys = yf * in.ra;
-                a.ybuf[g] = ys;
-                part += (double)(yf * in.oa);
-                pmax = fmaxf(pmax, fabsf(ys));
-            }
-        });
+        for (int m = 0; m < 3; m++) in.rs[m] = a.rs[g * 3 + m];
+        in.aa = a.saa[so + g]; in.bb = a.sbb[so + g]; in.uw = a.uw[g]; in.ew = a.ew[g];
+        in.ra = a.r_att[g]; in.oa = a.o_att[g];
+        return in;
+    };
+    auto epi = [&](int g, const unsigned long long (&T)[3], const AttIn &in) {
+        if (lane == 0) {
+            const float k = row_value(T[0], in.rs[0], sc[0]) + S0, v = row_value(T[1], in.rs[1], sc[1]) + S1;
+            const float r = row_value(T[2], in.rs[2], sc[2]) + S2;
+            const double vv = (double)v;
+            const double e1 = exp(in.uw + (double)k);
+            double y = (in.aa + e1 * vv) / (in.bb + e1);
+            y = (1.0 / (1.0 + (double)expf(-r))) * y;       // rwkv.cu:250: exp of a float argument
+            const double ek = exp((double)k);
+            a.saa[so + g] = (in.aa + ek * vv) * in.ew;
+            a.sbb[so + g] = (in.bb + ek) * in.ew;
+            const float yf = (float)y;                       // att_out GEMV casts its input to f32 (rwkv.cu:290)
+            const float ys = yf * in.ra;
+            a.ybuf[g] = ys;
+            part += (double)(yf * in.oa);
+            pmax = fmaxf(pmax, fabsf(ys));
+        }
+    };
+    if constexpr (RING) {
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 3 * S * 3072);
+        unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
+        ring_init(gc);
+        if (wave == NC) {
+            __syncthreads();   // order: the control block is zero, the prologue's requests are in the pipe
+            glds_loader<3, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            tl_stamp(a.tl, 2);
+        } else {
+            SiteRed<3> sr;
+            ring_site<3, S>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl);
+            scalars(sr);
+            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi);
+        }
+    } else {
+        u32x4 wA[3][S], wB[3][S];
+        int gA, gB;
+        unsigned *gctr = group_counter(red);
+        first_groups<NB>(g0, wave, gctr, gA, gB);   // the counter is visible behind the prologue's barriers
+        SiteRed<3> sr;
+        site_open<3, 3, S, (RWKV_SPLIT & 1) != 0, NB>(a.st, a.dy, a.x, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, sr, true, a.tl);
+        scalars(sr);
+        stream_groups<3, S, PAT_PER_ROW, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base, pre, epi);
+    }
     tl_stamp(a.tl, 6);
     __syncthreads();   // every wave is past its last read of the reduction scratch
     block_sum_max(part, pmax, red + RED_PART);
@@ -924,13 +1186,14 @@ struct AttOutArgs {
     size_t slot_stride;
     const Ctl *ctl;
     int D;
+    int ns;                // ring kernels: LDS slots
     unsigned long long *tl;
 };
 
 // att_out dequant-GEMV + residual through f32 (rwkv.cu:548-553), R rows per group; commits state xy;
 // opens the ln2 site for the rows it owns
 template <int R> struct AttOutIn { unsigned rsum; double xold, lw, lb, prev2; SitePre<2> pre; int mi, shift; };
-template <int S, int R, int NB>
+template <int S, int R, int NB, bool RING = false>
 __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -945,46 +1208,61 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
 
     const double mean1 = a.lnstat[0], rstd1 = a.lnstat[1];
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
-    u32x4 wA[R][S], wB[R][S];
-    int gA, gB;
-    unsigned *gctr = group_counter(red);
-    first_groups<NB>(g0, wave, gctr, gA, gB);
     auto base = [&](int gg) {
         int row = (gg < g1 ? gg : (g1 > g0 ? g1 - 1 : 0)) * R;
         if (row > D - R) row = D - R;          // the last group may overlap the previous one
         return a.w + (size_t)row * D;
     };
     float Sf, amax;
-    vec_open<1, R, S, (RWKV_SPLIT & 2) != 0, NB>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, Sf, amax, a.tl);
-    const double sc = scale_of(amax);
+    double sc;
     SiteAcc<2> acc;
     acc.clear();
-
-    stream_groups<R, S, PAT_SHARED, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base,
-        [&](int g) {
-            AttOutIn<R> in;
-            int row0 = g * R;
-            in.shift = (row0 > D - R) ? row0 - (D - R) : 0;
-            row0 -= in.shift;
-            in.mi = row0 + (lane < R ? lane : 0);               // lane r owns row row0 + r
-            in.rsum = a.rs[in.mi];
-            in.xold = a.x[in.mi]; in.lw = a.lnw[in.mi]; in.lb = a.lnb[in.mi]; in.prev2 = a.sdd[so + in.mi];
-            site_prefetch<2>(a.st, in.mi, in.pre);
-            return in;
-        },
-        [&](int, const unsigned long long (&T)[R], const AttOutIn<R> &in) {
+    auto pre = [&](int g) {
+        AttOutIn<R> in;
+        int row0 = g * R;
+        in.shift = (row0 > D - R) ? row0 - (D - R) : 0;
+        row0 -= in.shift;
+        in.mi = row0 + (lane < R ? lane : 0);               // lane r owns row row0 + r
+        in.rsum = a.rs[in.mi];
+        in.xold = a.x[in.mi]; in.lw = a.lnw[in.mi]; in.lb = a.lnb[in.mi]; in.prev2 = a.sdd[so + in.mi];
+        site_prefetch<2>(a.st, in.mi, in.pre);
+        return in;
+    };
+    auto epi = [&](int, const unsigned long long (&T)[R], const AttOutIn<R> &in) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                if (lane == r && r >= in.shift) {
-                    const float accf = (float)in.xold + (row_value(T[r], in.rsum, sc) + Sf);   // f32 accumulator pre-loaded with x (:548)
-                    const double xnew = (double)accf;                                           // :553
-                    a.x[in.mi] = xnew;
-                    a.sxy[so + in.mi] = in.lw * ((in.xold - mean1) * rstd1) + in.lb;           // mixatt's state write (:385): ln1 output
-                    site_emit<2>(in.pre, a.dy, D, in.mi, xnew, in.prev2, acc);
-                }
+        for (int r = 0; r < R; r++) {
+            if (lane == r && r >= in.shift) {
+                const float accf = (float)in.xold + (row_value(T[r], in.rsum, sc) + Sf);   // f32 accumulator pre-loaded with x (:548)
+                const double xnew = (double)accf;                                           // :553
+                a.x[in.mi] = xnew;
+                a.sxy[so + in.mi] = in.lw * ((in.xold - mean1) * rstd1) + in.lb;           // mixatt's state write (:385): ln1 output
+                site_emit<2>(in.pre, a.dy, D, in.mi, xnew, in.prev2, acc);
             }
-        });
-    __syncthreads();   // every wave is past its last read of the reduction scratch
+        }
+    };
+    if constexpr (RING) {
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + S * 3072);
+        unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
+        ring_init(gc);
+        if (wave == NC) {
+            __syncthreads();   // order
+            glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            tl_stamp(a.tl, 2);
+        } else {
+            ring_vec<1, S>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl);
+            sc = scale_of(amax);
+            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi);
+        }
+    } else {
+        u32x4 wA[R][S], wB[R][S];
+        int gA, gB;
+        unsigned *gctr = group_counter(red);
+        first_groups<NB>(g0, wave, gctr, gA, gB);
+        vec_open<1, R, S, (RWKV_SPLIT & 2) != 0, NB>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, Sf, amax, a.tl);
+        sc = scale_of(amax);
+        stream_groups<R, S, PAT_SHARED, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base, pre, epi);
+    }
+    __syncthreads();   // every wave is past its last read of the reduction scratch (and of the staged vector / the ring)
     tl_stamp(a.tl, 6);
     site_publish<2, R>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
     tl_stamp(a.tl, 7);
@@ -1004,12 +1282,13 @@ struct FfnRKArgs {
     float *partM;                     // [gridDim.x] partial max |hbuf| (k_ffnv's quantisation scale)
     const Ctl *ctl;
     int D;
+    int ns;                           // ring kernels: LDS slots
     unsigned long long *tl;           // optional phase timeline (see tl_stamp)
 };
 
 // ln2 site -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573)
 struct FfnRKIn { unsigned rsum; float rq, oq; };
-template <int S, int NB>
+template <int S, int NB, bool RING = false>
 __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1021,46 +1300,63 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
     tl_stamp(a.tl, 0);
 
-    u32x4 wA[5][S], wB[5][S];
-    int gA, gB;
-    unsigned *gctr = group_counter(red);
-    first_groups<NB>(g0, wave, gctr, gA, gB);
     auto base = [&](int g) { return a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 5 * D; };
-    SiteRed<2> sr;
-    site_open<2, 5, S, (RWKV_SPLIT & 4) != 0, NB>(a.st, a.dy, a.x, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, sr, true, a.tl);
-    const double sck = scale_of(sr.amax[0]), scr = scale_of(sr.amax[1]);
-    const float Sk = (float)sr.S[0], Sr = (float)sr.S[1];
-
+    double sck, scr;
+    float Sk, Sr;
+    auto scalars = [&](const SiteRed<2> &sr) { sck = scale_of(sr.amax[0]); scr = scale_of(sr.amax[1]); Sk = (float)sr.S[0]; Sr = (float)sr.S[1]; };
     // channel g = the four ffn_k rows 4g..4g+3 and the ffn_r row g; lane q < 4 finishes hidden unit 4g + q (relu^2,
     // pre-scaled for ffn_v), lane 4 the receptance gate -- as soon as the group's sums exist
     double part = 0.0;
     float pmax = 0.f;
-    stream_groups<5, S, PAT_FFN_RK, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base,
-        [&](int g) {
-            FfnRKIn in;
-            in.rsum = a.rs[g * 5 + (lane < 5 ? lane : 0)];
-            const int kk = 4 * g + (lane < 4 ? lane : 0);
-            in.rq = a.r_fv[kk]; in.oq = a.o_fv[kk];
-            return in;
-        },
-        [&](int g, const unsigned long long (&T)[5], const FfnRKIn &in) {
-            float val = 0.f;     // lane r finishes row r (the sums are wave-uniform, the row sums per lane)
+    auto pre = [&](int g) {
+        FfnRKIn in;
+        in.rsum = a.rs[g * 5 + (lane < 5 ? lane : 0)];
+        const int kk = 4 * g + (lane < 4 ? lane : 0);
+        in.rq = a.r_fv[kk]; in.oq = a.o_fv[kk];
+        return in;
+    };
+    auto epi = [&](int g, const unsigned long long (&T)[5], const FfnRKIn &in) {
+        float val = 0.f;     // lane r finishes row r (the sums are wave-uniform, the row sums per lane)
 #pragma unroll
-            for (int r = 0; r < 5; r++) {
-                const float vr = row_value(T[r], in.rsum, r < 4 ? sck : scr) + (r < 4 ? Sk : Sr);
-                val = lane == r ? vr : val;
-            }
-            if (lane < 4) {
-                float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
-                h = h * h;
-                const float hs = h * in.rq;
-                a.hbuf[4 * g + lane] = hs;
-                part += (double)(h * in.oq);
-                pmax = fmaxf(pmax, fabsf(hs));
-            } else if (lane == 4) {
-                a.rgate[g] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
-            }
-        });
+        for (int r = 0; r < 5; r++) {
+            const float vr = row_value(T[r], in.rsum, r < 4 ? sck : scr) + (r < 4 ? Sk : Sr);
+            val = lane == r ? vr : val;
+        }
+        if (lane < 4) {
+            float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
+            h = h * h;
+            const float hs = h * in.rq;
+            a.hbuf[4 * g + lane] = hs;
+            part += (double)(h * in.oq);
+            pmax = fmaxf(pmax, fabsf(hs));
+        } else if (lane == 4) {
+            a.rgate[g] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
+        }
+    };
+    if constexpr (RING) {
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 2 * S * 3072);
+        unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
+        ring_init(gc);
+        if (wave == NC) {
+            __syncthreads();   // order
+            glds_loader<5, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            tl_stamp(a.tl, 2);
+        } else {
+            SiteRed<2> sr;
+            ring_site<2, S>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl);
+            scalars(sr);
+            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi);
+        }
+    } else {
+        u32x4 wA[5][S], wB[5][S];
+        int gA, gB;
+        unsigned *gctr = group_counter(red);
+        first_groups<NB>(g0, wave, gctr, gA, gB);
+        SiteRed<2> sr;
+        site_open<2, 5, S, (RWKV_SPLIT & 4) != 0, NB>(a.st, a.dy, a.x, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, sr, true, a.tl);
+        scalars(sr);
+        stream_groups<5, S, PAT_FFN_RK, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base, pre, epi);
+    }
     tl_stamp(a.tl, 6);
     __syncthreads();   // every wave is past its last read of the reduction scratch
     block_sum_max(part, pmax, red + RED_PART);
@@ -1087,12 +1383,13 @@ struct FfnVArgs {
     size_t slot_stride;
     const Ctl *ctl;
     int D;
+    int ns;                // ring kernels: LDS slots
     unsigned long long *tl;
 };
 
 // ffn_v dequant-GEMV, x += v * sigmoid(r) (rwkv.cu:574-577); commits state dd; opens the next site
 template <int NVN> struct FfnVIn { unsigned rsum; double xold, lw, lb, prevn; float rg; SitePre<NVN> pre; };
-template <int S, int NVN, int NB>
+template <int S, int NVN, int NB, bool RING = false>
 __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1106,36 +1403,51 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
 
     const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
-    u32x4 wA[4][S], wB[4][S];
-    int gA, gB;
-    unsigned *gctr = group_counter(red);
-    first_groups<NB>(g0, wave, gctr, gA, gB);
     auto base = [&](int g) { return a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 4 * D; };
     float Sf, amax;   // one scale for the whole 4D hidden vector
-    vec_open<4, 4, S, (RWKV_SPLIT & 8) != 0, NB>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, Sf, amax, a.tl);
-    const double sc = scale_of(amax);
+    double sc;
     SiteAcc<NVN> acc;
     acc.clear();
-
-    stream_groups<4, S, PAT_PER_ROW, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base,
-        [&](int g) {
-            FfnVIn<NVN> in;
-            in.rsum = a.rs[g];
-            in.xold = a.x[g]; in.lw = a.lnw[g]; in.lb = a.lnb[g];
-            in.prevn = NVN == 3 ? a.sprev[so + g] : 0.0;
-            in.rg = a.rgate[g];
-            site_prefetch<NVN>(a.st, g, in.pre);
-            return in;
-        },
-        [&](int g, const unsigned long long (&T)[4], const FfnVIn<NVN> &in) {
-            if (lane == 0) {
-                const float v = row_value((T[0] + T[1]) + (T[2] + T[3]), in.rsum, sc) + Sf;
-                const double xnew = in.xold + (double)(v * in.rg);               // blockout, rwkv.cu:407 (f32 product)
-                a.x[g] = xnew;
-                a.sdd[so + g] = in.lw * ((in.xold - mean2) * rstd2) + in.lb;     // mixffn's state write (:344): ln2 output
-                site_emit<NVN>(in.pre, a.dy, D, g, xnew, in.prevn, acc);
-            }
-        });
+    auto pre = [&](int g) {
+        FfnVIn<NVN> in;
+        in.rsum = a.rs[g];
+        in.xold = a.x[g]; in.lw = a.lnw[g]; in.lb = a.lnb[g];
+        in.prevn = NVN == 3 ? a.sprev[so + g] : 0.0;
+        in.rg = a.rgate[g];
+        site_prefetch<NVN>(a.st, g, in.pre);
+        return in;
+    };
+    auto epi = [&](int g, const unsigned long long (&T)[4], const FfnVIn<NVN> &in) {
+        if (lane == 0) {
+            const float v = row_value((T[0] + T[1]) + (T[2] + T[3]), in.rsum, sc) + Sf;
+            const double xnew = in.xold + (double)(v * in.rg);               // blockout, rwkv.cu:407 (f32 product)
+            a.x[g] = xnew;
+            a.sdd[so + g] = in.lw * ((in.xold - mean2) * rstd2) + in.lb;     // mixffn's state write (:344): ln2 output
+            site_emit<NVN>(in.pre, a.dy, D, g, xnew, in.prevn, acc);
+        }
+    };
+    if constexpr (RING) {
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 4 * S * 3072);
+        unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
+        ring_init(gc);
+        if (wave == NC) {
+            __syncthreads();   // order
+            glds_loader<4, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            tl_stamp(a.tl, 2);
+        } else {
+            ring_vec<4, S>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl);
+            sc = scale_of(amax);
+            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi);
+        }
+    } else {
+        u32x4 wA[4][S], wB[4][S];
+        int gA, gB;
+        unsigned *gctr = group_counter(red);
+        first_groups<NB>(g0, wave, gctr, gA, gB);
+        vec_open<4, 4, S, (RWKV_SPLIT & 8) != 0, NB>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, Sf, amax, a.tl);
+        sc = scale_of(amax);
+        stream_groups<4, S, PAT_PER_ROW, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base, pre, epi);
+    }
     __syncthreads();   // every wave is past its last read of the reduction scratch
     tl_stamp(a.tl, 6);
     site_publish<NVN, 1>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
@@ -1154,16 +1466,16 @@ struct HeadArgs {
     unsigned *blk_idx;         // [gridDim.x]
     const Ctl *ctl;
     int D;
+    int ns;                    // ring kernels: LDS slots
 };
 
 // ln_out site -> head dequant-GEMV -> logits (rwkv.cu:585-589); also per-workgroup argmax partials
 template <int R> struct HeadIn { unsigned rsr[R]; int row0, shift; };
-template <int S, int NB>
+template <int S, int NB, bool RING = false, int R = RING ? RWKV_HEAD_RR : RWKV_HEAD_R>
 __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int XVD = xvd<S>();
-    constexpr int R = RWKV_HEAD_R;
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     float *bval = reinterpret_cast<float *>(xq + XVD);
@@ -1176,41 +1488,56 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
     const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
     float *lg = a.logits + (size_t)a.ctl->out_row * V;   // read at entry: behind the prologue's barriers it is a cold scalar load
 
-    u32x4 wA[R][S], wB[R][S];
-    int gA, gB;
-    unsigned *gctr = group_counter(red);
-    first_groups<NB>(g0, wave, gctr, gA, gB);
     auto base = [&](int gg) {
         int row = (gg < g1 ? gg : (g1 > g0 ? g1 - 1 : 0)) * R;
         if (row > V - R) row = V - R;
         return a.w + (size_t)row * D;
     };
-    SiteRed<1> sr;
-    site_open<1, R, S, (RWKV_SPLIT & 16) != 0, NB>(a.st, a.dy, a.x, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, sr, false, nullptr);
-    const float Sf = (float)sr.S[0];
-    const double sc = scale_of(sr.amax[0]);
-
+    float Sf;
+    double sc;
     float best = -INFINITY;
     unsigned besti = 0xffffffffu;
-    stream_groups<R, S, PAT_SHARED, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base,
-        [&](int g) {
-            HeadIn<R> in;
-            in.row0 = g * R;
-            in.shift = (in.row0 > V - R) ? in.row0 - (V - R) : 0;
-            in.row0 -= in.shift;
+    auto pre = [&](int g) {
+        HeadIn<R> in;
+        in.row0 = g * R;
+        in.shift = (in.row0 > V - R) ? in.row0 - (V - R) : 0;
+        in.row0 -= in.shift;
 #pragma unroll
-            for (int r = 0; r < R; r++) in.rsr[r] = a.rs[in.row0 + r];
-            return in;
-        },
-        [&](int, const unsigned long long (&T)[R], const HeadIn<R> &in) {
+        for (int r = 0; r < R; r++) in.rsr[r] = a.rs[in.row0 + r];
+        return in;
+    };
+    auto epi = [&](int, const unsigned long long (&T)[R], const HeadIn<R> &in) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int i = in.row0 + r;
-                const float val = row_value(T[r], in.rsr[r], sc) + Sf;
-                if (lane == r && r >= in.shift) lg[i] = val;
-                if (i != 0 && (val > best || (val == best && (unsigned)i < besti))) { best = val; besti = (unsigned)i; }
-            }
-        });
+        for (int r = 0; r < R; r++) {
+            const int i = in.row0 + r;
+            const float val = row_value(T[r], in.rsr[r], sc) + Sf;
+            if (lane == r && r >= in.shift) lg[i] = val;
+            if (i != 0 && (val > best || (val == best && (unsigned)i < besti))) { best = val; besti = (unsigned)i; }
+        }
+    };
+    if constexpr (RING) {
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + S * 3072 + 64);   // behind bval / bidx
+        unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
+        ring_init(gc);
+        if (wave == NC) {
+            __syncthreads();   // order
+            glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+        } else {
+            SiteRed<1> sr;
+            ring_site<1, S>(a.st, a.dy, a.x, D, red, xq, sr, false, gc, nullptr);
+            Sf = (float)sr.S[0]; sc = scale_of(sr.amax[0]);
+            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi);
+        }
+    } else {
+        u32x4 wA[R][S], wB[R][S];
+        int gA, gB;
+        unsigned *gctr = group_counter(red);
+        first_groups<NB>(g0, wave, gctr, gA, gB);
+        SiteRed<1> sr;
+        site_open<1, R, S, (RWKV_SPLIT & 16) != 0, NB>(a.st, a.dy, a.x, D, red, xq, wA, wB, base(gA), base(gB), (size_t)D, sr, false, nullptr);
+        Sf = (float)sr.S[0]; sc = scale_of(sr.amax[0]);
+        stream_groups<R, S, PAT_SHARED, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base, pre, epi);
+    }
     if (lane == 0) { bval[wave] = best; bidx[wave] = besti; }
     __syncthreads();
     if (threadIdx.x == 0) {

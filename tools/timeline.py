@@ -21,6 +21,9 @@ for rep in range(2):
         v = us[:, :, ph][buf[:, :, ph] > 0]
         if v.size:
             print(f"  {names[ph]:14s} min {v.min():7.2f}  mean {v.mean():7.2f}  max {v.max():7.2f}  (n={v.size})")
+    print("  by wave  staged:", np.round([us[:, w, 5][buf[:, w, 5] > 0].mean() if (buf[:, w, 5] > 0).any() else -1 for w in range(8)], 2),
+          " loop end:", np.round([us[:, w, 6][buf[:, w, 6] > 0].mean() for w in range(8)], 2),
+          " ph2:", np.round([us[:, w, 2][buf[:, w, 2] > 0].mean() if (buf[:, w, 2] > 0).any() else -1 for w in range(8)], 2))
 m.close()
 # per-workgroup view of the last repetition: is the spread between workgroups systematic?
 m = engine.RWKV(resident=True); m.loadTensors(L, D, t)
