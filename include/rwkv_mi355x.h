@@ -190,6 +190,14 @@ int rwkv_profile_batched(rwkv_ctx *ctx, uint64_t token, int reps, double *ms, ui
  * kernel; out receives grid*8*8 stamps of the 100 MHz device wall clock ([workgroup][wave][phase]). */
 int rwkv_debug_timeline(rwkv_ctx *ctx, uint64_t token, unsigned long long *out, uint64_t cap);
 
+/* Tuning aid for the one-launch token (csrc/mega.hip.h): one eager launch with its timeline on; out receives
+ * grid * phases * 8 stamps of the 100 MHz wall clock, [workgroup][phase][slot]; *phases = 1 + 4 * layers (+ 1: head). */
+int rwkv_debug_mega_timeline(rwkv_ctx *ctx, uint64_t token, unsigned long long *out, uint64_t cap, uint32_t *phases);
+
+/* 1: a token of this context is ONE kernel launch (persistent workgroups, LDS-DMA weight stream across the phases;
+ * default for whole-model contexts, RWKV_MEGA=0/1 overrides); 0: four launches per layer. */
+int rwkv_one_launch(const rwkv_ctx *ctx);
+
 /* Standalone launch of the engine's dequant-GEMV on caller-provided device buffers
  * (the kernel behind cudac_mm8_one(), rwkv.cu:297-311): w is FILE layout [N][M] u8 (one layer),
  * x f32[N], r/o f32[N]; y f32[M] is overwritten with x . (w*r + o).  Used by the unit tests. */

@@ -59,7 +59,7 @@ def _run(cmd, cwd=None):
 def build_engine(force: bool = False) -> str:
     """csrc/engine.hip (+ kernels.hip.h, seq.hip.h) -> csrc/librwkv_mi355x.so"""
     out = os.path.join(CSRC, "librwkv_mi355x.so")
-    srcs = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "kernels.hip.h"), os.path.join(CSRC, "seq.hip.h"), os.path.join(CSRC, "sampler.hip.h"),
+    srcs = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "kernels.hip.h"), os.path.join(CSRC, "mega.hip.h"), os.path.join(CSRC, "seq.hip.h"), os.path.join(CSRC, "sampler.hip.h"),
             os.path.join(ROOT, "include", "rwkv_mi355x.h")]
     if force or _stale(out, srcs):
         _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",

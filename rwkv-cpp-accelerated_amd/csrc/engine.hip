@@ -5,6 +5,7 @@
 // engine: weights are re-tiled once at load, state and the embedding table stay resident on the
 // device, and one token is a replay of a captured hipGraph (4 launches per layer + 2).
 #include "kernels.hip.h"
+#include "mega.hip.h"
 #include "seq.hip.h"
 #include "sampler.hip.h"
 #include "../../include/rwkv_mi355x.h"
@@ -148,6 +149,13 @@ struct rwkv_ctx {
     unsigned *ts_key = nullptr;
     unsigned gen_cap = 0;
     hipGraphExec_t g_fwd = nullptr, g_greedy = nullptr;
+    // one-launch token (mega.hip.h), experimental: -1 = default (off), 0 off, 1 on; env RWKV_MEGA overrides
+    int mega = -1;
+    bool mega_on = false;
+    MegaSync *msync = nullptr;
+    unsigned *herr = nullptr;            // mapped pinned word the kernel raises when a wait gave up
+    AttArgs *m_att = nullptr; AttOutArgs *m_attout = nullptr; FfnRKArgs *m_frk = nullptr; FfnVArgs *m_fv = nullptr;   // device arrays [l1 - l0]
+    unsigned long long *mtl = nullptr;   // timeline of the one-launch token (debug), [grid][phases][MG_TL]
     unsigned long long *tl = nullptr;   // phase-timeline buffer (debug), [grid][NW][8]
     bool tl_on = false;
     int tl_cls = 3;                     // kernel class the timeline instruments (env RWKV_TL_CLASS, 1..4)
@@ -189,14 +197,14 @@ size_t smem_attout(int S) { return RED_BYTES + (size_t)S * 3072; }
 size_t smem_frk(int S) { return RED_BYTES + 2 * (size_t)S * 3072; }
 size_t smem_fv(int S) { return RED_BYTES + 4 * (size_t)S * 3072; }
 size_t smem_head(int S) { return RED_BYTES + (size_t)S * 3072 + NW * 8; }
-// ring kernels: slots of R x S KiB behind the staged vectors, as many as fit the CU's 160 KiB
+// ring kernels: units of one row (S KiB) behind the staged vectors, as many as fit the CU's 160 KiB (a group of R rows takes R
+// consecutive units, wrapping: every group size shares the same ring)
 constexpr size_t LDS_BYTES = 160 * 1024;
-int ring_slots(size_t fixed, int R, int S)
+int ring_slots(size_t fixed, int, int S)
 {
-    const size_t n = (LDS_BYTES - fixed - sizeof(GldsCtl)) / ((size_t)R * S * 1024);
-    return (int)std::min<size_t>(n, GLDS_MAX_SLOTS);
+    return (int)((LDS_BYTES - fixed - sizeof(GldsCtl)) / ((size_t)S * 1024));
 }
-size_t smem_ring(size_t fixed, int R, int S) { return fixed + sizeof(GldsCtl) + (size_t)ring_slots(fixed, R, S) * R * S * 1024; }
+size_t smem_ring(size_t fixed, int R, int S) { return fixed + sizeof(GldsCtl) + (size_t)ring_slots(fixed, R, S) * S * 1024; }
 
 #ifndef RWKV_ATTOUT_R
 #define RWKV_ATTOUT_R 2
@@ -222,37 +230,43 @@ template <typename K> int allow_smem(K kernel, size_t bytes)
 }
 
 
-// ---- one launch helper per kernel class (0 embed, 1 att, 2 att_out, 3 ffn_rk, 4 ffn_v, 5 head, 6 argmax) ----
-void launch_class(rwkv_ctx *c, int cls, uint64_t l)
-{
-    const int D = (int)c->D, S = c->S, grid = c->grid;
-    const uint64_t L = c->L;
-    const size_t LD = (size_t)L * D, lo = (size_t)l * D;
-    // debug timeline: the kernel of class tl_cls in the stage's middle layer stamps its phases
-    auto tl_of = [&](int k) { return (c->tl_on && k == c->tl_cls && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr; };
-    auto site_static = [&](int k, uint64_t ll) {
+// ---- argument blocks of the decode kernels (shared by the per-class launches and the one-launch token) ----
+// mega: every site is opened by the full grid (the launch path opens the stage's first ln1 site with k_first's few workgroups)
+struct ArgMaker {
+    rwkv_ctx *c;
+    bool mega;
+    int D, grid, n_first;
+    size_t LD;
+    explicit ArgMaker(rwkv_ctx *c_, bool mega_ = false) : c(c_), mega(mega_), D((int)c_->D), grid(c_->grid), LD((size_t)c_->L * c_->D)
+    {
+        n_first = mega ? grid : (grid < 32 ? grid : 32);
+    }
+    unsigned long long *tl_of(int k, uint64_t l) const { return (!mega && c->tl_on && k == c->tl_cls && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr; }
+    SiteStatic site_static(int k, uint64_t ll) const
+    {
         const int nv = SITE_NV[k], pw = SITE_PW[k];
         SiteStatic st;
         st.C = c->siteC[k] + (size_t)ll * nv * D; st.P = c->siteP[k] + (size_t)ll * D * pw;
         st.TC = c->siteTC[k] + (size_t)ll * nv; st.maxC = c->siteMC[k] + (size_t)ll * nv;
         st.invD = 1.0 / (double)D; st.invDm1 = 1.0 / (double)(D - 1);
         return st;
-    };
-    auto site_dyn = [&](int k, int n_part) {
+    }
+    SiteDyn site_dyn(int k, int n_part) const
+    {
         SiteDyn dy;
         dy.B = c->siteB[k]; dy.pd = c->sitePD[k]; dy.pf = c->sitePF[k]; dy.lnstat = c->lnstat + 2 * k; dy.n_part = n_part;
         return dy;
-    };
-    // the ln1 site of the stage's first layer is opened by k_first (a few workgroups), every other site by a full grid
-    const int n_first = grid < 32 ? grid : 32;
-    switch (cls) {
-    case 0: {
+    }
+    FirstArgs first() const
+    {
         FirstArgs fa;
         fa.embed = c->embed; fa.ln = c->ln; fa.x = c->x; fa.x_in = c->x_in ? c->x_in : c->x; fa.st = site_static(0, c->l0); fa.dy = site_dyn(0, n_first);
         fa.sxy = c->state[0] + (size_t)c->l0 * D; fa.slot_stride = LD; fa.ctl = c->ctl; fa.D = D; fa.from_token = c->l0 == 0;
-        k_first<<<dim3(n_first), dim3(NT), 0, c->stream>>>(fa);
-    } break;
-    case 1: {
+        return fa;
+    }
+    AttArgs att(uint64_t l) const
+    {
+        const size_t lo = (size_t)l * D;
         AttArgs aa;
         aa.x = c->x; aa.st = site_static(0, l); aa.dy = site_dyn(0, l == c->l0 ? n_first : grid);
         aa.w = c->w_kvr + (size_t)(l - c->l0) * 3 * D * D; aa.rs = c->rs_kvr + (size_t)(l - c->l0) * D * 3;
@@ -260,52 +274,92 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
         aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
         aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
         aa.slot_stride = LD; aa.ybuf = c->ybuf; aa.partS = c->partA; aa.partM = c->partMA;
-        aa.ctl = c->ctl; aa.D = D; aa.tl = tl_of(1);
-        if (c->ring & 1) { aa.ns = ring_slots(smem_att(S), 3, S); DISPATCH_S(S, k_att<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_att(S), 3, S), c->stream>>>(aa)); }
-        else DISPATCH_S(S, k_att<S_, nb_att(S_)><<<dim3(grid), dim3(NT), smem_att(S), c->stream>>>(aa));
-    } break;
-    case 2: {
+        aa.ctl = c->ctl; aa.D = D; aa.ns = 0; aa.tl = tl_of(1, l);
+        return aa;
+    }
+    AttOutArgs attout(uint64_t l) const
+    {
+        const size_t lo = (size_t)l * D;
         AttOutArgs ao;
         ao.w = c->w_att + (size_t)(l - c->l0) * D * D; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
         ao.x = c->x; ao.lnw = c->ln + (4 * l + 2) * D; ao.lnb = c->ln + (4 * l + 3) * D; ao.lnstat = c->lnstat + 0;
         ao.sxy = c->state[0] + lo; ao.st = site_static(1, l); ao.dy = site_dyn(1, grid); ao.sdd = c->state[4] + lo;
-        ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.tl = tl_of(2);
-        if (c->ring & 2) { ao.ns = ring_slots(smem_attout(S), ATTOUT_R, S); DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_attout(S), ATTOUT_R, S), c->stream>>>(ao)); }
-        else DISPATCH_S(S, k_attout<S_, ATTOUT_R, nb_attout(S_)><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
-    } break;
-    case 3: {
+        ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.ns = 0; ao.tl = tl_of(2, l);
+        return ao;
+    }
+    FfnRKArgs frk(uint64_t l) const
+    {
+        const size_t lo = (size_t)l * D;
         FfnRKArgs fa;
         fa.x = c->x; fa.st = site_static(1, l); fa.dy = site_dyn(1, grid);
         fa.w = c->w_frk + (size_t)(l - c->l0) * 5 * D * D; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5;
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.partM = c->partMF; fa.ctl = c->ctl; fa.D = D;
-        fa.tl = tl_of(3);
-        if (c->ring & 4) { fa.ns = ring_slots(smem_frk(S), 5, S); DISPATCH_S(S, k_ffn_rk<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_frk(S), 5, S), c->stream>>>(fa)); }
-        else
-        DISPATCH_S(S, k_ffn_rk<S_, nb_frk(S_)><<<dim3(grid), dim3(NT), smem_frk(S), c->stream>>>(fa));
-    } break;
-    case 4: {
+        fa.ns = 0; fa.tl = tl_of(3, l);
+        return fa;
+    }
+    // the site ffn_v opens: ln1 of layer l + 1 (3 vectors), or ln_out -> head after the stage's last layer (on a non-final
+    // pipeline stage nobody reads it: the next stage re-opens its own site from x)
+    bool fv_next_att(uint64_t l) const { return l + 1 < c->l1; }
+    FfnVArgs fv(uint64_t l) const
+    {
+        const size_t lo = (size_t)l * D;
         FfnVArgs fv;
         fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
         fv.rgate = c->rgate; fv.x = c->x; fv.lnw = c->ln + (4 * l + 4) * D; fv.lnb = c->ln + (4 * l + 5) * D; fv.lnstat = c->lnstat + 2;
-        fv.sdd = c->state[4] + lo; fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D; fv.tl = tl_of(4);
+        fv.sdd = c->state[4] + lo; fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D; fv.tl = tl_of(4, l);
+        fv.ns = 0;
+        if (fv_next_att(l)) { fv.st = site_static(0, l + 1); fv.dy = site_dyn(0, grid); fv.sprev = c->state[0] + lo + D; }
+        else { fv.st = site_static(2, 0); fv.dy = site_dyn(2, grid); fv.sprev = nullptr; }
+        return fv;
+    }
+    HeadArgs head() const
+    {
+        HeadArgs ha;
+        ha.x = c->x; ha.st = site_static(2, 0); ha.dy = site_dyn(2, grid); ha.w = c->w_head; ha.rs = c->rs_head; ha.logits = c->logits;
+        ha.blk_val = c->blk_val; ha.blk_idx = c->blk_idx; ha.ctl = c->ctl; ha.D = D; ha.ns = 0;
+        return ha;
+    }
+};
+
+// ---- one launch helper per kernel class (0 embed, 1 att, 2 att_out, 3 ffn_rk, 4 ffn_v, 5 head, 6 argmax) ----
+void launch_class(rwkv_ctx *c, int cls, uint64_t l)
+{
+    const int S = c->S, grid = c->grid;
+    const ArgMaker mk(c);
+    switch (cls) {
+    case 0: {
+        FirstArgs fa = mk.first();
+        k_first<<<dim3(mk.n_first), dim3(NT), 0, c->stream>>>(fa);
+    } break;
+    case 1: {
+        AttArgs aa = mk.att(l);
+        if (c->ring & 1) { aa.ns = ring_slots(smem_att(S), 3, S); DISPATCH_S(S, k_att<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_att(S), 3, S), c->stream>>>(aa)); }
+        else DISPATCH_S(S, k_att<S_, nb_att(S_)><<<dim3(grid), dim3(NT), smem_att(S), c->stream>>>(aa));
+    } break;
+    case 2: {
+        AttOutArgs ao = mk.attout(l);
+        if (c->ring & 2) { ao.ns = ring_slots(smem_attout(S), ATTOUT_R, S); DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_attout(S), ATTOUT_R, S), c->stream>>>(ao)); }
+        else DISPATCH_S(S, k_attout<S_, ATTOUT_R, nb_attout(S_)><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
+    } break;
+    case 3: {
+        FfnRKArgs fa = mk.frk(l);
+        if (c->ring & 4) { fa.ns = ring_slots(smem_frk(S), 5, S); DISPATCH_S(S, k_ffn_rk<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_frk(S), 5, S), c->stream>>>(fa)); }
+        else DISPATCH_S(S, k_ffn_rk<S_, nb_frk(S_)><<<dim3(grid), dim3(NT), smem_frk(S), c->stream>>>(fa));
+    } break;
+    case 4: {
+        FfnVArgs fv = mk.fv(l);
         fv.ns = ring_slots(smem_fv(S), 4, S);
-        if (l + 1 < c->l1) {   // next consumer: k_att of layer l+1
-            fv.st = site_static(0, l + 1); fv.dy = site_dyn(0, grid); fv.sprev = c->state[0] + lo + D;
+        if (mk.fv_next_att(l)) {
             if (c->ring & 8) { DISPATCH_S(S, k_ffnv<S_, 3, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_fv(S), 4, S), c->stream>>>(fv)); }
-            else
-            DISPATCH_S(S, k_ffnv<S_, 3, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
-        } else {               // next consumer: k_head (on a non-final pipeline stage nobody reads it: the next stage's k_first re-opens its own site from x)
-            fv.st = site_static(2, 0); fv.dy = site_dyn(2, grid); fv.sprev = nullptr;
+            else DISPATCH_S(S, k_ffnv<S_, 3, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
+        } else {
             if (c->ring & 8) { DISPATCH_S(S, k_ffnv<S_, 1, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_fv(S), 4, S), c->stream>>>(fv)); }
-            else
-            DISPATCH_S(S, k_ffnv<S_, 1, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
+            else DISPATCH_S(S, k_ffnv<S_, 1, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
         }
     } break;
     case 5: {
-        HeadArgs ha;
-        ha.x = c->x; ha.st = site_static(2, 0); ha.dy = site_dyn(2, grid); ha.w = c->w_head; ha.rs = c->rs_head; ha.logits = c->logits;
-        ha.blk_val = c->blk_val; ha.blk_idx = c->blk_idx; ha.ctl = c->ctl; ha.D = D;
+        HeadArgs ha = mk.head();
         if (c->ring & 16) { ha.ns = ring_slots(smem_head(S), RWKV_HEAD_RR, S); DISPATCH_S(S, k_head<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_head(S), RWKV_HEAD_RR, S), c->stream>>>(ha)); }
         else DISPATCH_S(S, k_head<S_, nb_head(S_)><<<dim3(grid), dim3(NT), smem_head(S), c->stream>>>(ha));
     } break;
@@ -314,12 +368,100 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
     }
 }
 
+// ---- the one-launch token (mega.hip.h) ----
+size_t mega_smem(int S)
+{
+    size_t b = 0;
+    DISPATCH_S(S, b = (size_t)MegaLds<S_>::BYTES);
+    return b;
+}
+// set the context up for k_token: argument tables on the device, the synchronisation block, the kernel's LDS limit.
+// Leaves mega_on = false (the launch path stays) when the shape does not fit the kernel's assumptions.
+int mega_setup(rwkv_ctx *c)
+{
+    c->mega_on = false;
+    const char *e = getenv("RWKV_MEGA");
+    int want = c->mega;
+    if (e && e[0]) want = atoi(e);
+    // Off unless asked for (RWKV_MEGA=1).  Measured on MI355X (profiles/r02/mega_*.txt): the ring protocol streams a 7B
+    // layer at 6.8 TB/s when nothing synchronises the chip (32 us against the launches' 53.5), but every edge costs four dependent
+    // trips through a saturated memory system (drain, arrival, poll, hand-off loads) where a kernel boundary costs 1.8 us: 87 us per
+    // layer.  Also: two such kernels of different processes on one GPU would starve each other.
+    if (want < 0) want = 0;
+    if (!want) return 0;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    const int D = (int)c->D, grid = c->grid;
+    const uint64_t nl = c->l1 - c->l0;
+    if (grid > 256 || grid > prop.multiProcessorCount || grid < 8) return 0;          // every workgroup resident, tuples reduced by 256 threads
+    if ((D + grid - 1) / grid + MG_AR > MG_MAXROWS) return 0;
+    if ((size_t)prop.sharedMemPerBlockOptin < mega_smem(c->S) && (size_t)prop.sharedMemPerBlock < mega_smem(c->S)) return 0;
+    const ArgMaker mk(c, true);
+    std::vector<AttArgs> a(nl);
+    std::vector<AttOutArgs> ao(nl);
+    std::vector<FfnRKArgs> fr(nl);
+    std::vector<FfnVArgs> fv(nl);
+    for (uint64_t i = 0; i < nl; i++) { a[i] = mk.att(c->l0 + i); ao[i] = mk.attout(c->l0 + i); fr[i] = mk.frk(c->l0 + i); fv[i] = mk.fv(c->l0 + i); }
+    int rc;
+    if ((rc = dalloc(c, &c->m_att, nl))) return rc;
+    if ((rc = dalloc(c, &c->m_attout, nl))) return rc;
+    if ((rc = dalloc(c, &c->m_frk, nl))) return rc;
+    if ((rc = dalloc(c, &c->m_fv, nl))) return rc;
+    HIPCHK(hipMemcpy(c->m_att, a.data(), nl * sizeof(AttArgs), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->m_attout, ao.data(), nl * sizeof(AttOutArgs), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->m_frk, fr.data(), nl * sizeof(FfnRKArgs), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->m_fv, fv.data(), nl * sizeof(FfnVArgs), hipMemcpyHostToDevice));
+    if ((rc = dalloc(c, &c->msync, 1))) return rc;
+    HIPCHK(hipMemset(c->msync, 0, sizeof(MegaSync)));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->herr), 64, hipHostMallocMapped));
+    *c->herr = 0u;
+    DISPATCH_S(c->S, rc = allow_smem(k_token<S_>, mega_smem(c->S)));
+    if (rc) return rc;
+    c->mega_on = true;
+    return 0;
+}
+MegaArgs mega_args(rwkv_ctx *c, bool with_argmax, unsigned long long *tl)
+{
+    const ArgMaker mk(c, true);
+    MegaArgs m;
+    m.first = mk.first();
+    m.head = mk.head();
+    m.att = c->m_att; m.attout = c->m_attout; m.frk = c->m_frk; m.fv = c->m_fv;
+    m.sync = c->msync;
+    void *dp = nullptr;
+    (void)hipHostGetDevicePointer(&dp, c->herr, 0);
+    m.herr = static_cast<unsigned *>(dp);
+    m.ctl = c->ctl; m.gen = c->gen; m.gen_cap = c->gen_cap;
+    m.nl = (int)(c->l1 - c->l0); m.has_head = c->l1 == c->L ? 1 : 0; m.with_argmax = (with_argmax && c->l1 == c->L) ? 1 : 0; m.D = (int)c->D;
+    m.tl = tl;
+    return m;
+}
+void launch_token(rwkv_ctx *c, bool with_argmax, unsigned long long *tl)
+{
+    const MegaArgs m = mega_args(c, with_argmax, tl);
+    DISPATCH_S(c->S, k_token<S_><<<dim3(c->grid), dim3(NT), mega_smem(c->S), c->stream>>>(m));
+}
+// after a synchronisation: did a wait inside k_token give up?  (resets the block so that the context stays usable)
+int mega_check(rwkv_ctx *c)
+{
+    if (!c->mega_on || !c->herr || *c->herr == 0u) return 0;
+    *c->herr = 0u;
+    (void)hipMemsetAsync(c->msync, 0, sizeof(MegaSync), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    return fail(RWKV_E_DEVICE, "one-launch token: a device-side wait gave up (workgroups not co-resident, or the GPU is shared); set RWKV_MEGA=0");
+}
+
 // enqueue the kernels of one token on the context's stream.  ev: optional array of
 // (4L + 4) events recorded before each launch and after the last (profiling).
 int enqueue_token(rwkv_ctx *c, bool with_argmax, hipEvent_t *ev)
 {
     const bool last = c->l1 == c->L;
     int evi = 0;
+    if (c->mega_on && !ev && !c->tl_on) {   // the whole token as one launch (the per-class path below serves the profilers)
+        launch_token(c, with_argmax, nullptr);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
 #define EV() do { if (ev) HIPCHK(hipEventRecord(ev[evi++], c->stream)); } while (0)
     EV();
     launch_class(c, 0, 0);   // first stage: embed + ln0; every stage: open the ln1 site of its first layer
@@ -622,6 +764,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     HIPCHK(hipStreamSynchronize(c->stream));
     if ((rc = set_smem_limits(c))) return rc;
     if (c->seq_ok && (rc = seq_smem_limits())) return rc;
+    if ((rc = mega_setup(c))) return rc;
     const char *nograph = getenv("RWKV_NO_GRAPH");
     if (!(nograph && nograph[0] == '1')) {
         if ((rc = build_graph(c, false, &c->g_fwd))) return rc;
@@ -850,7 +993,7 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
 
 int rwkv_stage_forward(rwkv_ctx *c, uint64_t token, uint32_t slot, uint64_t *pick)
@@ -867,7 +1010,7 @@ int rwkv_stage_forward(rwkv_ctx *c, uint64_t token, uint32_t slot, uint64_t *pic
     if (rc) return rc;
     if (last && pick) HIPCHK(hipMemcpyAsync(pick, c->gen, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
 
 double *rwkv_x_device(rwkv_ctx *c) { return c ? c->x : nullptr; }
@@ -884,7 +1027,7 @@ int rwkv_set_state(rwkv_ctx *c, const double *xy, const double *aa, const double
     for (int s = 0; s < 5; s++)
         if (h[s]) HIPCHK(hipMemcpyAsync(c->state[s], h[s], bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
 
 int rwkv_get_output(rwkv_ctx *c, float *logits, double *xy, double *aa, double *bb, double *pp, double *dd,
@@ -900,7 +1043,7 @@ int rwkv_get_output(rwkv_ctx *c, float *logits, double *xy, double *aa, double *
     for (int s = 0; s < 5; s++)
         if (h[s]) HIPCHK(hipMemcpyAsync(h[s], c->state[s], bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
 
 int rwkv_reset_state(rwkv_ctx *c)
@@ -911,7 +1054,7 @@ int rwkv_reset_state(rwkv_ctx *c)
     for (int s = 0; s < 5; s++)
         HIPCHK(hipMemsetAsync(c->state[s], 0, c->maxT * c->L * c->D * sizeof(double), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
 
 int rwkv_decode_greedy(rwkv_ctx *c, uint64_t first_token, uint64_t n, uint64_t *out_tokens)
@@ -930,7 +1073,7 @@ int rwkv_decode_greedy(rwkv_ctx *c, uint64_t first_token, uint64_t n, uint64_t *
     }
     HIPCHK(hipMemcpyAsync(out_tokens, c->gen, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
 
 namespace {
@@ -966,7 +1109,7 @@ int rwkv_sample_typical(rwkv_ctx *c, uint64_t row, float temp, float tau, double
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(token, c->pick, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
 
 int rwkv_decode_typical(rwkv_ctx *c, uint64_t first_token, uint64_t n, float temp, float tau, uint64_t seed, int flags, uint64_t *out_tokens)
@@ -987,7 +1130,7 @@ int rwkv_decode_typical(rwkv_ctx *c, uint64_t first_token, uint64_t n, float tem
     }
     HIPCHK(hipMemcpyAsync(out_tokens, c->gen, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
 
 void rwkv_free(rwkv_ctx *c)
@@ -1000,6 +1143,7 @@ void rwkv_free(rwkv_ctx *c)
     if (c->g_greedy) (void)hipGraphExecDestroy(c->g_greedy);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->herr) (void)hipHostFree(c->herr);
     if (c->h_sq_tokens) (void)hipHostFree(c->h_sq_tokens);
     for (int r = 0; r < SQ_RING; r++) if (c->sq_ev[r]) (void)hipEventDestroy(c->sq_ev[r]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1092,7 +1236,7 @@ int rwkv_profile_batched(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint
     for (int st = 0; st < 5; st++)
         HIPCHK(hipMemsetAsync(c->state[st], 0, c->maxT * c->L * c->D * sizeof(double), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
 
 // debug: run one eager token with the phase timeline of the middle layer's ffn_rk kernel enabled;
@@ -1115,8 +1259,34 @@ int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, ui
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, c->tl, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
+
+// debug: one eager k_token launch with its timeline enabled; out receives grid * phases * 8 stamps of the 100 MHz wall
+// clock ([workgroup][phase][slot], slots in mega.hip.h mg_stamp callers); *phases = 1 + 4 layers (+ 1 with the head)
+int rwkv_debug_mega_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, uint64_t cap, uint32_t *phases)
+{
+    if (!c || !out) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (!c->mega_on) return fail(RWKV_E_STATE, "the one-launch token is off for this context");
+    const uint32_t nq = (uint32_t)(1 + 4 * (c->l1 - c->l0) + (c->l1 == c->L ? 1 : 0));
+    const size_t n = (size_t)c->grid * nq * MG_TL;
+    if (phases) *phases = nq;
+    if (cap < n) return fail(RWKV_E_ARG, "need room for %zu stamps", n);
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->mtl) { int rc = dalloc(c, &c->mtl, n); if (rc) return rc; }
+    HIPCHK(hipMemsetAsync(c->mtl, 0, n * 8, c->stream));
+    c->h_ctl[0].token = token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
+    HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+    launch_token(c, false, c->mtl);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->mtl, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return mega_check(c);
+}
+
+// 1 when tokens of this context run as one launch (mega.hip.h), 0 when as 4 launches per layer
+int rwkv_one_launch(const rwkv_ctx *c) { return c && c->mega_on ? 1 : 0; }
 
 int rwkv_mm8_one(rwkv_ctx *c, uint64_t N, uint64_t M, const float *x, const uint8_t *w, const float *r,
                  const float *o, float *y)
@@ -1324,7 +1494,7 @@ int rwkv_sync(rwkv_ctx *c)
     if (!c) return fail(RWKV_E_ARG, "NULL ctx");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return mega_check(c);
 }
 // hand a chunk's residual stream from one stage context to the next ON THE SAME DEVICE (virtual stages: tests, and
 // several stages per GPU); ordered behind src's work, and dst's later work is ordered behind the copy

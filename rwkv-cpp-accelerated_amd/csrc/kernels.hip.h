@@ -806,6 +806,28 @@ __device__ __forceinline__ void dma_piece(const uint8_t *src, unsigned lds_dst)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
+// One row of S KiB as S DMA instructions that share ONE address register pair and one M0 value: the instruction offset advances
+// the global address AND the LDS address (tools/dmabench.hip, modes 2 / 6: every word verified).  A one-wave DMA stream is bounded
+// by the loader wave's instruction count -- at 7 instructions per piece it stood at 5.7 TB/s chip-wide, at 2 per piece 7.0 TB/s.
+template <int S> __device__ __forceinline__ void dma_unit(const uint8_t *src, unsigned lds_dst);
+#define RWKV_DMA_UNIT(S_, BODY)                                                                                                        \
+    template <> __device__ __forceinline__ void dma_unit<S_>(const uint8_t *src, unsigned lds_dst)                                     \
+    {                                                                                                                                  \
+        unsigned keep;                                                                                                                 \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" BODY "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory"); \
+    }
+#define RWKV_DMA_L(OFF) "global_load_lds_dwordx4 %1, off offset:" #OFF " nt\n\t"
+RWKV_DMA_UNIT(1, RWKV_DMA_L(0))
+RWKV_DMA_UNIT(2, RWKV_DMA_L(0) RWKV_DMA_L(1024))
+RWKV_DMA_UNIT(3, RWKV_DMA_L(0) RWKV_DMA_L(1024) RWKV_DMA_L(2048))
+RWKV_DMA_UNIT(4, RWKV_DMA_L(0) RWKV_DMA_L(1024) RWKV_DMA_L(2048) RWKV_DMA_L(3072))
+template <> __device__ __forceinline__ void dma_unit<5>(const uint8_t *src, unsigned lds_dst)      // the offset field ends at 4095
+{
+    dma_unit<4>(src, lds_dst);
+    dma_unit<1>(src + 4096, lds_dst + 4096);
+}
+#undef RWKV_DMA_L
+#undef RWKV_DMA_UNIT
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 constexpr int GLDS_SPIN = 1 << 18;    // bound of every wait loop (a lost hand-off must end the kernel, not hang the GPU)
 __device__ __forceinline__ void wait_seq(const unsigned *p, unsigned want)
@@ -822,87 +844,157 @@ __device__ __forceinline__ void wait_count(const unsigned *p, unsigned least)
         __builtin_amdgcn_s_sleep(1);
     }
 }
-constexpr int GLDS_MAX_SLOTS = 24;
-struct GldsCtl {            // LDS control block of the ring (64 dwords)
+constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
+// DMA pieces (1 KiB) the loader keeps in flight.  By Little's law the queueing delay of EVERY access of the CU is in-flight bytes /
+// stream rate: 63 KiB at 23 KB/us = 2.7 us -- paid by the prologue's loads and, after the last issue, by the kernel's tail --
+// while the stream itself is at full rate from ~24 KiB up (tools/dmabench.hip: depth 63 / 32 / 16 -> 7.3 / 7.3 / 6.0 TB/s).
+#ifndef RWKV_RING_DEPTH
+#define RWKV_RING_DEPTH 32
+#endif
+struct GldsCtl {            // LDS control block of the ring (80 dwords)
     unsigned staged;        // prologue waves that have staged their part of the vector
-    unsigned pad[3];
-    unsigned ready[GLDS_MAX_SLOTS];     // ready[slot] = k + 1: group k has landed in the slot
-    unsigned freeq[GLDS_MAX_SLOTS];     // freeq[slot] = k + 1: group k has been copied out of the slot
+    unsigned landed;        // ring units (rows of S KiB) whose DMA has completed: loader -> consumers, monotonic
+    unsigned pad[2];
+    unsigned freeq[GLDS_FQ];   // freeq[k % FQ] = k + 1: group k has been copied out of the ring
+    unsigned gend[GLDS_FQ];    // the loader's own: end unit of group k
     unsigned pad2[12];
 };
 constexpr int NC = NW - 1;              // consumer waves of a ring kernel
-template <int R, int S> __host__ __device__ constexpr int glds_depth() { return 63 / (R * S) < 7 ? 63 / (R * S) : 7; }
-template <int RS, int D> struct GldsDrain {      // with at most D groups still in flight the others have landed
-    template <class F> static __device__ __forceinline__ void run(int &pend, F &publish)
+
+// The loader wave.  The ring is made of `nu` UNITS of one row (S KiB) each; a group of R rows takes the next R units (wrapping),
+// so slots of every group size share one ring and the LDS is used to the last 4 KiB.  Round 2's first loader handed out whole
+// group slots, counted its groups with blocking s_waitcnt and DRAINED (vmcnt(0)) whenever the consumers were behind -- which in
+// the ring-full regime (every kernel here, once the prologue is over) serialised issue -> land -> announce per group: 17 KB/us per
+// CU.  This one never blocks on a count it could read instead:
+//   * the wave's own vmcnt is READ (s_getreg IB_STS), so "everything but the last vm pieces has landed" is announced as a
+//     monotonic unit count while the wave waits for room -- the consumer that will free the wanted units may be waiting for exactly that;
+//   * consumers free groups out of order (freeq flags); the tail moves over every leading free group with ONE LDS round trip
+//     (lane i looks at group tail + i);
+//   * a row is one asm statement (dma_unit); all state is wave-uniform.  The loader wave's instruction count IS the stream's
+//     ceiling: tools/dmabench.hip, dmabench2.hip (this protocol with the real group_dot: 6.8 TB/s chip-wide, 26 KB/us per CU).
+template <int S> struct RingLoader {
+    GldsCtl *mc;
+    unsigned ring, nu;       // LDS byte address of unit 0, units
+    unsigned off[S];         // lane's byte offset in a row, per step (rows that are not whole KiB: the last pieces are clamped)
+    bool whole;              // rows are whole KiB: a unit is one dma_unit
+    unsigned issued = 0, pub = 0;       // units issued / announced as landed
+    unsigned k = 0, tail = 0;           // groups issued / groups known to be copied out
+    unsigned tailu = 0;                 // first unit still in use
+    unsigned pos = 0;                   // ring position of the next unit
+    int lane;
+    bool dead = false;
+
+    __device__ __forceinline__ RingLoader(GldsCtl *mc_, unsigned ring_, int nu_, int chunks, int lane_)
+        : mc(mc_), ring((unsigned)__builtin_amdgcn_readfirstlane((int)ring_)), nu((unsigned)nu_), lane(lane_)
     {
-        wait_vm<D * RS>();
-        while (pend > D) publish();
-        GldsDrain<RS, D - 1>::run(pend, publish);
+        asm volatile("" : "+s"(ring));      // an opaque SGPR value (else the generic -> LDS address conversion is redone at every use)
+        whole = chunks == 64 * S;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            int c = lane + 64 * s;
+            c = c < chunks ? c : chunks - 1;
+            off[s] = (unsigned)c << 4;
+        }
+    }
+    __device__ __forceinline__ void publish(unsigned units)
+    {
+        if ((int)(units - pub) > 0) {
+            pub = units;
+            if (lane == 0) __hip_atomic_store(&mc->landed, units, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    // DMA instructions of this wave that have not completed: HW_REG_IB_STS holds VM_CNT in bits 3:0 and its two high bits in 23:22.
+    // Loads complete in order and this wave issues no other vector memory instruction.
+    __device__ __forceinline__ unsigned in_flight() const
+    {
+        const unsigned v = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 7);
+        return (v & 0xfu) | ((v >> 18) & 0x30u);
+    }
+    __device__ __forceinline__ void poll_landed() { publish((issued * (unsigned)S - in_flight()) / (unsigned)S); }
+    __device__ __forceinline__ void advance_tail()
+    {
+        const unsigned g = tail + (unsigned)(lane & 31);
+        const unsigned f = __hip_atomic_load(&mc->freeq[g % GLDS_FQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned e = __hip_atomic_load(&mc->gend[g % GLDS_FQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");      // compiler-level ordering is all LDS needs: a consumer's reads precede its flag in the LDS queue
+        const bool ok = lane < 32 && (g - tail) < (k - tail) && f == g + 1u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+        const unsigned n = (unsigned)__builtin_ctzll(~m);          // leading groups that are free (<= 32: bits 32.. are never set)
+        if (n) {
+            tailu = (unsigned)__builtin_amdgcn_readlane((int)e, (int)(n - 1u));
+            tail += n;
+        }
+    }
+    template <int R> __device__ __forceinline__ bool room() const { return !(issued + R - tailu > nu || k - tail >= (unsigned)GLDS_FQ); }
+    // R rows starting at `src` (this lane's first piece of row 0; rows `stride` bytes apart) -> the next R units
+    template <int R> __device__ __forceinline__ void group(const uint8_t *src, size_t stride)
+    {
+        for (int it = 0; !room<R>() && !dead; it++) {
+            advance_tail();
+            if (room<R>()) break;
+            poll_landed();
+            if (it >= GLDS_SPIN) dead = true;       // a lost hand-off must end the kernel, not hang the GPU
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) mc->gend[k % GLDS_FQ] = issued + R;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            wait_vm<(RWKV_RING_DEPTH < 63 ? RWKV_RING_DEPTH : 63) - S>();      // 63: the counter has 6 bits
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring + pos * (unsigned)(S * 1024)));
+            if (whole) dma_unit<S>(src + r * stride, dst);
+            else {
+#pragma unroll
+                for (int s = 0; s < S; s++) dma_piece(src + r * stride + (off[s] - off[0]), dst + s * 1024);
+            }
+            pos = pos + 1 == nu ? 0u : pos + 1;
+        }
+        issued += R;
+        k++;
+        poll_landed();
+    }
+    __device__ __forceinline__ void finish()
+    {
+        for (int it = 0; it < GLDS_SPIN && in_flight() != 0u; it++) { poll_landed(); __builtin_amdgcn_s_sleep(1); }
+        wait_vm<0>();
+        publish(issued);
     }
 };
-template <int RS> struct GldsDrain<RS, -1> { template <class F> static __device__ __forceinline__ void run(int &, F &) {} };
-
-// the loader wave: groups [g0, g1) of the workgroup in order; base(g) = address of group g's first row
+// the loader wave of a launch kernel: groups [g0, g1) of the workgroup in order; base(g) = address of group g's first row
 template <int R, int S, class Base>
-__device__ __forceinline__ void glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int ns, unsigned ring, GldsCtl *ctl, int lane)
+__device__ __forceinline__ void glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int nu, unsigned ring, GldsCtl *ctl, int lane)
 {
-    constexpr int RS = R * S, DEPTH = glds_depth<R, S>();
-    static_assert(DEPTH >= 1, "a row group must fit the 6-bit vmcnt");
-    unsigned off[S];
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        int c = lane + 64 * s;
-        c = c < chunks ? c : chunks - 1;
-        off[s] = (unsigned)c << 4;
-    }
-    const int ng = g1 - g0;
-    int pend = 0, pub = 0;        // groups in flight; oldest group in flight
-    auto publish = [&]() {
-        if (lane == 0) __hip_atomic_store(&ctl->ready[pub % ns], (unsigned)pub + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        pub++; pend--;
-    };
-    for (int k = 0; k < ng; k++) {
-        const int slot = k % ns;
-        if (pend == DEPTH) { wait_vm<(DEPTH - 1) * RS>(); publish(); }      // at most DEPTH * RS <= 63 pieces in flight
-        if (k >= ns && __hip_atomic_load(&ctl->freeq[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(k - ns) + 1u) {
-            // the consumers are behind: publish everything in flight before blocking (the consumer of the slot's old group
-            // may be queued behind a group this wave has not announced yet)
-            wait_vm<0>();
-            while (pend > 0) publish();
-            wait_seq(&ctl->freeq[slot], (unsigned)(k - ns) + 1u);
-        }
-        const uint8_t *gb = base(g0 + k);
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring + (unsigned)slot * (RS * 1024)));
-#pragma unroll
-        for (int s = 0; s < S; s++)
-#pragma unroll
-            for (int r = 0; r < R; r++) dma_piece(gb + r * stride + off[s], dst + (r * S + s) * 1024);
-        pend++;
-    }
-    GldsDrain<RS, DEPTH - 1>::run(pend, publish);
+    RingLoader<S> ld(ctl, ring, nu, chunks, lane);
+    for (int g = g0; g < g1; g++) ld.template group<R>(base(g) + ld.off[0], stride);
+    ld.finish();
 }
-// consumer side of one group: wait, copy the slot into registers, hand the slot back
+// consumer side of one group (kl = its index in the workgroup): wait, copy its R units into registers, hand them back
 template <int R, int S>
-__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int k, int ns, const unsigned char *ring, GldsCtl *ctl, int lane)
+__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, const unsigned char *ring, GldsCtl *ctl, int lane)
 {
-    const int slot = k % ns;
-    wait_seq(&ctl->ready[slot], (unsigned)k + 1u);
-    const u32x4 *p = reinterpret_cast<const u32x4 *>(ring + (size_t)slot * (R * S * 1024)) + lane;
+    const unsigned uend = (unsigned)(kl + 1) * R;
+    for (int it = 0; it < GLDS_SPIN; it++) {
+        if ((int)(__hip_atomic_load(&ctl->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - uend) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    unsigned p0 = (uend - R) % (unsigned)nu;
 #pragma unroll
-    for (int s = 0; s < S; s++)
+    for (int r = 0; r < R; r++) {
+        const u32x4 *p = reinterpret_cast<const u32x4 *>(ring + (size_t)p0 * (S * 1024)) + lane;
 #pragma unroll
-        for (int r = 0; r < R; r++) w[r][s] = p[(r * S + s) * 64];
-    if (lane == 0) __hip_atomic_store(&ctl->freeq[slot], (unsigned)k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int s = 0; s < S; s++) w[r][s] = p[s * 64];
+        p0 = p0 + 1 == (unsigned)nu ? 0u : p0 + 1;
+    }
+    if (lane == 0) __hip_atomic_store(&ctl->freeq[kl % GLDS_FQ], (unsigned)kl + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // the consumer waves' streaming loop (wave < NC): same pre / epi contract as stream_groups
 template <int R, int S, int PAT, class Pre, class Epi>
-__device__ __forceinline__ void ring_groups(int g0, int g1, int ns, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
+__device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
                                             int chunks, Pre pre, Epi epi)
 {
     for (int g = g0 + wave; g < g1; g += NC) {
         const auto in = pre(g);
         u32x4 w[R][S];
-        glds_take<R, S>(w, g - g0, ns, ring, ctl, lane);
+        glds_take<R, S>(w, g - g0, nu, ring, ctl, lane);
         unsigned long long T[R];
         group_dot<R, S, PAT, false>(w, xq, lane, T, nullptr, 0, chunks, false);
         epi(g, T, in);
