@@ -251,8 +251,24 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     stage = pipeline.EngineStage(tensors, L, D, l0, l1, n_slots=world, device=local_rank, prefill=native and args.prefill_chunks > 0)
     del tensors
     torch.cuda.empty_cache()
+    native_note = None
     if native:
-        pipeline.pipe_connect(stage, dist, rank, world)
+        # the engine-side communicator has never met a second GPU before the driver's own multi-GPU run (a gpurun box has one
+        # GPU and RCCL refuses two ranks on one device): if ANY rank fails to join, every rank falls back to the Python
+        # schedule over torch.distributed's own RCCL point-to-point ops, and the bench line says so
+        ok = 1
+        try:
+            pipeline.pipe_connect(stage, dist, rank, world)
+        except Exception as e:          # noqa: BLE001 -- reported below
+            ok = 0
+            native_note = f"rank {rank}: {e}"
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            native = False
+            native_note = native_note or "another rank could not join the engine-side RCCL communicator"
+            if rank == 0:
+                print(f"[bench] native transport unavailable ({native_note}); using torch.distributed P2P", file=sys.stderr, flush=True)
     rng = np.random.default_rng(1)
     first = [int(x) for x in rng.integers(2, mf.VOCAB, world)]
 
@@ -311,7 +327,7 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
                           method="algorithmic bytes of the stage's layers per token x tokens through the stage / wall time of the timed region; "
                                  "the slowest stage is quoted"),
             end_to_end=dict(achieved_GBps=round(B_tok * tok_s / 1e9, 1), frac_of_aggregate_peak=round(B_tok * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)),
-            per_stream_tokens_per_s=round(args.steps / dt, 2), prefill=prefill)), flush=True)
+            per_stream_tokens_per_s=round(args.steps / dt, 2), prefill=prefill, transport_fallback=native_note)), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

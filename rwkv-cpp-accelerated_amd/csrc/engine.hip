@@ -64,21 +64,55 @@ uint64_t tensor_elems(int i, uint64_t a, uint64_t b)
     return s[i];
 }
 
-// where tensor bytes come from during a load
+// where tensor bytes come from during a load, and how they reach the device.  A model.bin (8 GB at 7B) streams through
+// two pinned staging buffers: the file read of piece i + 1 overlaps the host-to-device copy of piece i, nothing waits for
+// the device until the load is complete (round 1 read every tensor into a pageable buffer and synchronised per tensor).
 struct Source {
     FILE *f = nullptr;                  // model.bin, or
     const void *const *ptrs = nullptr;  // 46 pointers in file layout
     bool on_device = false;
     uint64_t off[46];
-    std::vector<unsigned char> scratch;
-    // returns a pointer (host unless on_device) to bytes [o, o+n) of tensor i
-    const void *get(int i, uint64_t o, uint64_t n)
+    static constexpr size_t PIN = 32u << 20;
+    unsigned char *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    int turn = 0;
+    // device pointer of a tensor that already lives on the device (on_device sources), else nullptr
+    const void *device_ptr(int i, uint64_t o) const { return (ptrs && on_device && ptrs[i]) ? static_cast<const unsigned char *>(ptrs[i]) + o : nullptr; }
+    // enqueue bytes [o, o + n) of tensor i -> dst (device) on `stream`; the caller's later work on the stream sees them
+    int to_device(int i, uint64_t o, uint64_t n, void *dst, hipStream_t stream)
     {
-        if (ptrs) return ptrs[i] ? static_cast<const unsigned char *>(ptrs[i]) + o : nullptr;
-        if (scratch.size() < n) scratch.resize(n);
-        if (fseeko(f, (off_t)(off[i] + o), SEEK_SET) != 0) return nullptr;
-        if (fread(scratch.data(), 1, n, f) != n) return nullptr;
-        return scratch.data();
+        if (ptrs) {
+            if (!ptrs[i]) return fail(RWKV_E_IO, "tensor slot %d: missing", i);
+            // caller-owned memory stays valid for the whole load: no staging, no wait
+            HIPCHK(hipMemcpyAsync(dst, static_cast<const unsigned char *>(ptrs[i]) + o, n, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+            return 0;
+        }
+        if (fseeko(f, (off_t)(off[i] + o), SEEK_SET) != 0) return fail(RWKV_E_IO, "tensor slot %d: seek failed", i);
+        for (uint64_t done = 0; done < n;) {
+            const size_t m = (size_t)std::min<uint64_t>(PIN, n - done);
+            const int b = turn;
+            turn ^= 1;
+            if (!pin[b]) {
+                HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&pin[b]), PIN, hipHostMallocDefault));
+                HIPCHK(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+            }
+            if (used[b]) HIPCHK(hipEventSynchronize(ev[b]));          // the copy that last read this buffer has finished
+            if (fread(pin[b], 1, m, f) != m) return fail(RWKV_E_IO, "tensor slot %d: short read", i);
+            HIPCHK(hipMemcpyAsync(static_cast<unsigned char *>(dst) + done, pin[b], m, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipEventRecord(ev[b], stream));
+            used[b] = true;
+            done += m;
+        }
+        return 0;
+    }
+    ~Source()
+    {
+        for (int b = 0; b < 2; b++) {
+            if (used[b]) (void)hipEventSynchronize(ev[b]);
+            if (ev[b]) (void)hipEventDestroy(ev[b]);
+            if (pin[b]) (void)hipHostFree(pin[b]);
+        }
     }
 };
 
@@ -493,12 +527,11 @@ int build_graph(rwkv_ctx *c, bool with_argmax, hipGraphExec_t *out)
 int retile(rwkv_ctx *c, Source &src, int slot, uint64_t layer, uint64_t N, uint64_t M, uint8_t *dst,
            int G, int RS, int off, uint8_t *staging)
 {
-    const void *p = src.get(slot, layer * N * M, N * M);
-    if (!p) return fail(RWKV_E_IO, "tensor slot %d: short read / missing", slot);
-    const uint8_t *dsrc = static_cast<const uint8_t *>(p);
-    if (!src.on_device) {
-        HIPCHK(hipMemcpyAsync(staging, p, N * M, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));   // scratch host buffer is reused by the next get()
+    const uint8_t *dsrc = static_cast<const uint8_t *>(src.device_ptr(slot, layer * N * M));
+    if (!dsrc) {
+        // `staging` is reused by the next matrix: stream order (this copy is enqueued behind the previous re-tile kernel) protects it
+        int rc = src.to_device(slot, layer * N * M, N * M, staging, c->stream);
+        if (rc) return rc;
         dsrc = staging;
     }
     dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
@@ -512,13 +545,9 @@ template <typename T> int upload(rwkv_ctx *c, Source &src, int slot, T **dst)
     const uint64_t n = tensor_elems(slot, c->L, c->D);
     int rc = dalloc(c, dst, n);
     if (rc) return rc;
-    const void *p = src.get(slot, 0, n * sizeof(T));
-    if (!p) return fail(RWKV_E_IO, "tensor slot %d: short read / missing", slot);
     // stream-ordered with the pack / re-tile kernels that read the copy (a default-stream D2D copy
     // would race with them: the engine stream is non-blocking)
-    HIPCHK(hipMemcpyAsync(*dst, p, n * sizeof(T), src.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    if (!src.on_device) HIPCHK(hipStreamSynchronize(c->stream));   // host scratch is reused by the next get()
-    return 0;
+    return src.to_device(slot, 0, n * sizeof(T), *dst, c->stream);
 }
 
 int seq_smem_limits()
