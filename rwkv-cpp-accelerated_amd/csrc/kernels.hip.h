@@ -851,6 +851,16 @@ constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
 #ifndef RWKV_RING_DEPTH
 #define RWKV_RING_DEPTH 32
 #endif
+// The weight stream starts BEFORE the workgroup's order barrier: the loader issues its first RWKV_RING_PRE rows at once, thinly
+// (RWKV_RING_PRE_DEPTH pieces in flight: the prologue's loads, issued ~1.4 us into the kernel, queue behind at most that), and
+// only then joins the barrier that lets the prologue's requests into the pipe ahead of the deep stream.  The cold start of a
+// kernel's stream (first translations, empty memory queues) then overlaps the prologue waves' own start-up.
+#ifndef RWKV_RING_PRE
+#define RWKV_RING_PRE 8
+#endif
+#ifndef RWKV_RING_PRE_DEPTH
+#define RWKV_RING_PRE_DEPTH 16
+#endif
 struct GldsCtl {            // LDS control block of the ring (80 dwords)
     unsigned staged;        // prologue waves that have staged their part of the vector
     unsigned landed;        // ring units (rows of S KiB) whose DMA has completed: loader -> consumers, monotonic
@@ -927,7 +937,7 @@ template <int S> struct RingLoader {
     }
     template <int R> __device__ __forceinline__ bool room() const { return !(issued + R - tailu > nu || k - tail >= (unsigned)GLDS_FQ); }
     // R rows starting at `src` (this lane's first piece of row 0; rows `stride` bytes apart) -> the next R units
-    template <int R> __device__ __forceinline__ void group(const uint8_t *src, size_t stride)
+    template <int R> __device__ __forceinline__ void group(const uint8_t *src, size_t stride, bool thin = false)
     {
         for (int it = 0; !room<R>() && !dead; it++) {
             advance_tail();
@@ -939,7 +949,8 @@ template <int S> struct RingLoader {
         if (lane == 0) mc->gend[k % GLDS_FQ] = issued + R;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            wait_vm<(RWKV_RING_DEPTH < 63 ? RWKV_RING_DEPTH : 63) - S>();      // 63: the counter has 6 bits
+            if (thin) wait_vm<(RWKV_RING_PRE_DEPTH > S ? RWKV_RING_PRE_DEPTH : S) - S>();
+            else wait_vm<(RWKV_RING_DEPTH < 63 ? RWKV_RING_DEPTH : 63) - S>();      // 63: the counter has 6 bits
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring + pos * (unsigned)(S * 1024)));
             if (whole) dma_unit<S>(src + r * stride, dst);
             else {
@@ -963,8 +974,14 @@ template <int S> struct RingLoader {
 template <int R, int S, class Base>
 __device__ __forceinline__ void glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int nu, unsigned ring, GldsCtl *ctl, int lane)
 {
+    // the control block is this wave's to zero: nobody else touches it before the order barrier
+    for (int i = lane; i < (int)(sizeof(GldsCtl) / 4); i += 64) reinterpret_cast<unsigned *>(ctl)[i] = 0u;
     RingLoader<S> ld(ctl, ring, nu, chunks, lane);
-    for (int g = g0; g < g1; g++) ld.template group<R>(base(g) + ld.off[0], stride);
+    int g = g0;
+    const int pre = RWKV_RING_PRE < nu - R ? RWKV_RING_PRE : nu - R;      // never wait for room before the barrier: the consumers are behind it
+    for (; g < g1 && (int)ld.issued < pre; g++) ld.template group<R>(base(g) + ld.off[0], stride, true);
+    __syncthreads();   // order: the control block is zero, the prologue's requests are in the pipe
+    for (; g < g1; g++) ld.template group<R>(base(g) + ld.off[0], stride);
     ld.finish();
 }
 // consumer side of one group (kl = its index in the workgroup): wait, copy its R units into registers, hand them back
@@ -1232,9 +1249,7 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     if constexpr (RING) {
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 3 * S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
-        ring_init(gc);
         if (wave == NC) {
-            __syncthreads();   // order: the control block is zero, the prologue's requests are in the pipe
             glds_loader<3, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
@@ -1335,9 +1350,7 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
     if constexpr (RING) {
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
-        ring_init(gc);
         if (wave == NC) {
-            __syncthreads();   // order
             glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
@@ -1428,9 +1441,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     if constexpr (RING) {
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 2 * S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
-        ring_init(gc);
         if (wave == NC) {
-            __syncthreads();   // order
             glds_loader<5, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
@@ -1521,9 +1532,7 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
     if constexpr (RING) {
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 4 * S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
-        ring_init(gc);
         if (wave == NC) {
-            __syncthreads();   // order
             glds_loader<4, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
@@ -1610,9 +1619,7 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
     if constexpr (RING) {
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + S * 3072 + 64);   // behind bval / bidx
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
-        ring_init(gc);
         if (wave == NC) {
-            __syncthreads();   // order
             glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
         } else {
             SiteRed<1> sr;

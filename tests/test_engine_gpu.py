@@ -352,3 +352,49 @@ def test_config1_169m_reference_converter_file_greedy_decode(eng_mod, oracle, tm
         tk = ids_ref[-1]
     assert len(set(ids_ref)) > 8
     om.close(); m.close()
+
+
+@pytest.mark.parametrize("L,D", [(2, 768), (3, 2048), (2, 4096), (1, 2560)])
+def test_one_launch_token_equals_launch_kernels(eng_mod, oracle, L, D, monkeypatch):
+    """RWKV_MEGA=1: the whole token as one persistent kernel (csrc/mega.hip.h: LDS-DMA ring across the phases, agent-scope
+    hand-offs instead of kernel boundaries) must give what the 4-launches-per-layer path gives -- same staging, same integer
+    dot products, same epilogues -- and both must match the oracle (rwkv.cu:493-593)."""
+    t = mf.synthetic_tensors(L, D, seed=900 + D)
+    ctx = {}
+    for mega in ("0", "1"):
+        monkeypatch.setenv("RWKV_MEGA", mega)
+        m = eng_mod.RWKV(resident=True)
+        m.loadTensors(L, D, t, maxGPT=2)
+        assert m.one_launch() == (mega == "1")
+        ctx[mega] = m
+    om = oracle.from_tensors(L, D, t)
+    st = om.new_state()
+    tk = 11
+    for step in range(6):
+        ref = om.forward([tk], st)[0]
+        a = np.array(ctx["0"].forward(tk)[: mf.VOCAB]); b = np.array(ctx["1"].forward(tk)[: mf.VOCAB])
+        parity.check_logits(b, ref, f"one-launch step {step}")
+        assert np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= 1e-6 * np.abs(a).max(), f"step {step}: the two paths differ"
+        assert parity.argmax_ban0(a) == parity.argmax_ban0(b)
+        tk = parity.argmax_ban0(ref)
+    ga = ctx["0"].decode_greedy(7, 16); gb = ctx["1"].decode_greedy(7, 16)
+    assert list(ga) == list(gb)
+    for m in ctx.values():
+        m.close()
+    om.close()
+
+
+def test_load_file_streams_through_pinned_staging(eng_mod, tmp_path):
+    """rwkv_load_file (rwkv.cu:638-717): a model.bin read through two pinned staging buffers in 32 MiB pieces, no device wait
+    per tensor -- the context must compute exactly what a context loaded from the same tensors in memory computes.  D = 2048,
+    L = 3: the 4D x D matrices (16 MiB) and the embedding table (412 MB) span several pieces."""
+    L, D = 3, 2048
+    t = mf.synthetic_tensors(L, D, seed=77)
+    path = str(tmp_path / "model.bin")
+    mf.write_bin(path, L, D, [np.zeros(n, dtype=dt) if x is None else x for x, n, dt in zip(t, mf.sizes(L, D), mf.DTYPES)])
+    a = eng_mod.RWKV(resident=True); a.loadTensors(L, D, t)
+    b = eng_mod.RWKV(resident=True); b.loadFile(path)
+    for tk in (3, 50000, 17, 17):
+        la = np.array(a.forward(tk)[: mf.VOCAB]); lb = np.array(b.forward(tk)[: mf.VOCAB])
+        assert np.array_equal(la, lb)
+    a.close(); b.close()

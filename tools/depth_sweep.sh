@@ -1,8 +1,8 @@
 cd /root/repo
-for v in base rd63 rd40 rd24 rd16; do
+for v in ${VARIANTS:-base}; do
   echo "######## $v"
   if [ "$v" = base ]; then unset RWKV_LIB; else export RWKV_LIB=$PWD/rwkv-cpp-accelerated_amd/csrc/variants/lib_$v.so; fi
-  for m in 7B 14B; do
+  for m in ${MODELS:-7B 14B}; do
   MODEL=$m timeout 300 python bench.py --steps 128 --warmup 8 --no-cpu-baseline --ref-steps 0 --prefill-chunks 0 --model $m 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
