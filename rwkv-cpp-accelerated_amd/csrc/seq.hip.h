@@ -547,7 +547,10 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     constexpr int CHU = NVS * NKB * 384;                // units of one LDS buffer: [vector][k][row tile][limb][lane]
     u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
     double *recl = reinterpret_cast<double *>(smem + (size_t)(DB ? 2 : 1) * CHU * 16);   // [NVS][SEQ_T]{scale, cA} of this slice
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // in flight per wave at the worst moment: record + row sums, the wave's share of the activation DMA, its weight loads
+    // (x 2 register sets when double-buffered) -- the vmcnt counter has 6 bits
+    static_assert(1 + NTW + (NVS * NKB * 6 + SEQ_NW - 1) / SEQ_NW + (DB ? 2 : 1) * NTW * NKB <= 63, "k_seq_gemm: more than 63 vector memory operations in flight");
     const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
     const int nch = (N + Q - 1) / Q, CB = (nch + 15) >> 4, ntiles = Q * CB;
     const int j = blockIdx.x % SEQ_O, rb = blockIdx.x / SEQ_O;
@@ -560,16 +563,20 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     const int wg0 = rb * SEQ_NW * ntw, wg1 = min(wg0 + SEQ_NW * ntw, ntiles) - 1;
     const int vlo = a.vec_of_q[min(wg0, ntiles - 1) / CB], vhi = a.vec_of_q[max(wg1, 0) / CB];
 
-    // the slice's quantisation records of the vectors this workgroup multiplies: requested now, used by the epilogue
-    if (threadIdx.x < NVS * SEQ_T) {
-        const int v = min(vlo + (int)threadIdx.x / SEQ_T, vhi), t = threadIdx.x % SEQ_T;
-        const SeqPart rc = a.part[((size_t)v * SEQ_T + t) * SEQ_O + j];
-        recl[2 * threadIdx.x] = scale_of(rc.amax); recl[2 * threadIdx.x + 1] = rc.cA;
+    // Nothing below waits for memory until the operands of the first MFMA are due: the kernel used to be a chain of ~25
+    // dependent round trips (record, row sums, the weights, then the activation image 16 bytes per thread at a time).
+    // the slice's quantisation records of the vectors this workgroup multiplies: requested now, written to LDS behind the
+    // activation image, used by the epilogue
+    SeqPart rc;
+    {
+        const int tr = threadIdx.x < NVS * SEQ_T ? (int)threadIdx.x : 0;
+        const int v = min(vlo + tr / SEQ_T, vhi), t = tr % SEQ_T;
+        rc = a.part[((size_t)v * SEQ_T + t) * SEQ_O + j];
     }
     const u32x4 *wt[NTW];
     int vi[NTW];
     bool tv[NTW];
-    unsigned rsv[NTW];          // row sum (this octant) of the row this lane finishes in tile i
+    unsigned rsv[NTW];          // row sum (this octant) of the row this lane finishes in tile i (rows past the end: some row's; never read back)
 #pragma unroll
     for (int i = 0; i < NTW; i++) {
         const int id = id0 + i;
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
         const int idc = tv[i] ? id : 0;
         {
             const int q = idc / CB, ch = 16 * (idc % CB) + (lane & 15), row = Q * ch + q;
-            rsv[i] = (tv[i] && ch < nch && row < N) ? a.rs8[(size_t)j * N + row] : 0u;
+            rsv[i] = a.rs8[(size_t)j * N + ((ch < nch && row < N) ? row : 0)];     // branch-free: a predicated load is waited for where it joins
         }
         wt[i] = a.bimg + ((size_t)idc * KB) * 64 + lane;
         vi[i] = a.vec_of_q[idc / CB] - vlo;
@@ -592,20 +599,35 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
 #pragma unroll
             for (int i = 0; i < NTW; i++) bw[set][i][k] = __builtin_nontemporal_load(wt[i] + (size_t)min(kclamp(c, k), KB - 1) * 64);
     };
-    // activation image of chunk c, vectors vlo .. vhi: units [(kb0 + c NKB) * 384, + n * 384) of each image are contiguous
+    // activation image of chunk c, vectors vlo .. vhi: units [(kb0 + c NKB) * 384, + n * 384) of each image are contiguous --
+    // a straight copy, done by the DMA path (global_load_lds_dwordx4: 1 KiB per wave instruction, no registers, nothing to wait
+    // for until the barrier in front of the MFMAs).  Every workgroup of an XCD copies the same image slice: each starts at
+    // its own offset so that they do not all hit the same L2 channel at the same moment.
+    const unsigned abuf_lds = lds_addr(abuf);
     auto stage_a = [&](int c, int buf) {
         const int kbs = kb0 + c * NKB, n = min(NKB, nkb - c * NKB);
-        u32x4 *dst = abuf + (size_t)buf * CHU;
-        // every workgroup of an XCD copies the same image slice: each starts at its own offset so that they do not all
-        // hit the same L2 channel at the same moment
-        const int nu = n * 384, rot = nu > 0 ? (int)(((long long)(rb % 32) * nu) / 32) : 0;
+        const int np = n * 6, rot = np > 0 ? (int)(((long long)(rb % 32) * np) / 32) : 0;      // pieces of 1 KiB per vector
         for (int v = vlo; v <= vhi && v - vlo < NVS; v++) {
-            const u32x4 *src = a.img[v] + (size_t)kbs * 384;
-            u32x4 *d = dst + (size_t)(v - vlo) * NKB * 384;
-            for (int u0 = threadIdx.x; u0 < nu; u0 += SEQ_NT) { int u = u0 + rot; u = u >= nu ? u - nu : u; d[u] = src[u]; }
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(a.img[v] + (size_t)kbs * 384) + lane * 16;
+            const unsigned dst = abuf_lds + (unsigned)(((size_t)buf * CHU + (size_t)(v - vlo) * NKB * 384) * 16);
+            for (int p0 = wave; p0 < np; p0 += SEQ_NW) {
+                int pc = p0 + rot;
+                pc = pc >= np ? pc - np : pc;
+                dma_piece(src + (size_t)pc * 1024, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)pc * 1024u)));
+            }
         }
     };
-    if (nchunk > 0) { load_b(0, 0); stage_a(0, 0); }
+    // the DMA above is older than the (<= NTW * NKB) weight loads issued after it: once no more than those are outstanding it
+    // has landed (loads complete in order); then the records go to LDS and the workgroup meets
+    auto staged = [&]() {
+        wait_vm<NTW * NKB>();
+        __syncthreads();
+    };
+    // unconditional (an empty slice copies nothing and loads clamped addresses): a branch here would make the compiler wait for
+    // the weights where the record is used -- its count of what may be in flight is the minimum over the paths that join
+    stage_a(0, 0); load_b(0, 0);
+    wait_vm<NTW * NKB>();
+    if (threadIdx.x < NVS * SEQ_T) { recl[2 * threadIdx.x] = scale_of(rc.amax); recl[2 * threadIdx.x + 1] = rc.cA; }
     __syncthreads();
 
     i32x4 acc[NTW][MTS ? 1 : 2][3];
@@ -676,29 +698,17 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
         for (int c = 0; c < nchunk; c++) {
             const int cn = c + 1 < nchunk ? c + 1 : c;
             if (DB) {
-                // next chunk: weights into the other register set, activation image (one vector: att_out / ffn_v) requested
-                // now and written into the other LDS buffer after this chunk's MFMAs (its readers passed the previous barrier)
-                constexpr int UPT = (NKB * 384 + SEQ_NT - 1) / SEQ_NT;
-                u32x4 sa[UPT];
-                {
-                    const int kbs = kb0 + cn * NKB, nu = min(NKB, nkb - cn * NKB) * 384;
-                    const u32x4 *src = a.img[vlo] + (size_t)kbs * 384;
-#pragma unroll
-                    for (int q = 0; q < UPT; q++) { const int u = threadIdx.x + q * SEQ_NT; sa[q] = src[u < nu ? u : (nu > 0 ? nu - 1 : 0)]; }
-                }
+                // next chunk: its activation image (one vector: att_out / ffn_v) straight into the other LDS buffer (whose readers
+                // passed the previous barrier), its weights into the other register set -- both under this chunk's MFMAs
+                if (c + 1 < nchunk) stage_a(c + 1, (c + 1) & 1);
                 if (c & 1) { load_b(0, cn); mult(1, 1, c, 0); } else { load_b(1, cn); mult(0, 0, c, 0); }
-                {
-                    u32x4 *dst = abuf + (size_t)((c + 1) & 1) * CHU;
-#pragma unroll
-                    for (int q = 0; q < UPT; q++) { const int u = threadIdx.x + q * SEQ_NT; if (u < NKB * 384) dst[u] = sa[q]; }
-                }
-                __syncthreads();
+                staged();
             } else {
                 mult(0, 0, c, 0);
                 if (c + 1 < nchunk) {                     // one register set, one buffer: load, then multiply
                     __syncthreads();
-                    load_b(0, c + 1); stage_a(c + 1, 0);
-                    __syncthreads();
+                    stage_a(c + 1, 0); load_b(0, c + 1);
+                    staged();
                 }
             }
         }
