@@ -194,8 +194,9 @@ int rwkv_debug_timeline(rwkv_ctx *ctx, uint64_t token, unsigned long long *out, 
  * grid * phases * 8 stamps of the 100 MHz wall clock, [workgroup][phase][slot]; *phases = 1 + 4 * layers (+ 1: head). */
 int rwkv_debug_mega_timeline(rwkv_ctx *ctx, uint64_t token, unsigned long long *out, uint64_t cap, uint32_t *phases);
 
-/* 1: a token of this context is ONE kernel launch (persistent workgroups, LDS-DMA weight stream across the phases;
- * default for whole-model contexts, RWKV_MEGA=0/1 overrides); 0: four launches per layer. */
+/* 1: a token of this context is ONE kernel launch (persistent workgroups, LDS-DMA weight stream across the phases of the
+ * token; experimental, measured slower than the launches on MI355X: opt-in with RWKV_MEGA=1 at load time);
+ * 0 (default): four launches per layer, one hipGraph replay per token. */
 int rwkv_one_launch(const rwkv_ctx *ctx);
 
 /* Standalone launch of the engine's dequant-GEMV on caller-provided device buffers
