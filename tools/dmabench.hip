@@ -169,9 +169,10 @@ int run(const uint8_t *src, size_t per_wg, unsigned *sink, int grid, const char 
 int main(int argc, char **argv)
 {
     const size_t mib = argc > 1 ? atoi(argv[1]) : 4;
+    const size_t kib = argc > 2 ? atoi(argv[2]) : 0;      // second argument: KiB per workgroup instead (short kernels: what a launch-sized stream costs)
     hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
     const int grid = p.multiProcessorCount;
-    const size_t per_wg = mib << 20;
+    const size_t per_wg = kib ? kib << 10 : mib << 20;
     uint8_t *src; unsigned *sink;
     CHK(hipMalloc(&src, per_wg * grid + (64u << 20))); CHK(hipMalloc(&sink, 8192));
     CHK(hipMemset(sink, 0, 8192));
@@ -182,7 +183,7 @@ int main(int argc, char **argv)
         CHK(hipMemcpy(src, h, tot, hipMemcpyHostToDevice));
         free(h);
     }
-    printf("%d workgroups x %zu MiB\n", grid, mib);
+    printf("%d workgroups x %zu KiB\n", grid, per_wg >> 10);
     if (run<0, 63>(src, per_wg, sink, grid, "issue only")) return 1;
     if (run<0, 32>(src, per_wg, sink, grid, "issue only")) return 1;
     if (run<0, 16>(src, per_wg, sink, grid, "issue only")) return 1;
