@@ -1006,15 +1006,42 @@ __device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, cons
 // the consumer waves' streaming loop (wave < NC): same pre / epi contract as stream_groups
 template <int R, int S, int PAT, class Pre, class Epi>
 __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
-                                            int chunks, Pre pre, Epi epi)
+                                            int chunks, Pre pre, Epi epi, unsigned long long *g_tl_groups = nullptr)
 {
+#ifdef RWKV_TL_GROUPS
+    // debug build (tools/timeline.py): where a consumer wave's time goes.  Stamps of the wave: 1 inputs of its first group requested,
+    // 2 first group taken, 4 its dot products and reductions done, 3 its epilogue done (5 stays "staged", 6 / 7 the kernel's end)
+    int rr = 0;
+#endif
     for (int g = g0 + wave; g < g1; g += NC) {
         const auto in = pre(g);
+#ifdef RWKV_TL_GROUPS
+        if (rr == 0) tl_stamp(g_tl_groups, 1);
+#endif
         u32x4 w[R][S];
         glds_take<R, S>(w, g - g0, nu, ring, ctl, lane);
+#ifdef RWKV_TL_GROUPS
+        asm volatile("" : "+v"(w[R - 1][S - 1]));
+        if (rr < 1) tl_stamp(g_tl_groups, 2);
+#endif
         unsigned long long T[R];
+#ifdef RWKV_RING_NODOT      // experiment (WRONG results): what the dot products and reductions cost
+#pragma unroll
+        for (int r = 0; r < R; r++) T[r] = (unsigned long long)__builtin_amdgcn_readfirstlane((int)w[r][0][0]);
+#else
         group_dot<R, S, PAT, false>(w, xq, lane, T, nullptr, 0, chunks, false);
+#endif
+#ifdef RWKV_TL_GROUPS
+        asm volatile("" : "+s"(T[R - 1]));
+        if (rr < 1) tl_stamp(g_tl_groups, 4);
+#endif
+#ifndef RWKV_RING_NOEPI     // experiment (WRONG results): what the epilogues cost
         epi(g, T, in);
+#endif
+#ifdef RWKV_TL_GROUPS
+        if (rr < 1) tl_stamp(g_tl_groups, 3);
+        rr++;
+#endif
     }
 }
 // ring kernels: the control block is zeroed before the order barrier
@@ -1256,7 +1283,7 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
             SiteRed<3> sr;
             ring_site<3, S>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl);
             scalars(sr);
-            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi);
+            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, a.tl);
         }
     } else {
         u32x4 wA[3][S], wB[3][S];
@@ -1448,7 +1475,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
             SiteRed<2> sr;
             ring_site<2, S>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl);
             scalars(sr);
-            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi);
+            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, a.tl);
         }
     } else {
         u32x4 wA[5][S], wB[5][S];
@@ -1538,7 +1565,7 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
         } else {
             ring_vec<4, S>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl);
             sc = scale_of(amax);
-            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi);
+            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, a.tl);
         }
     } else {
         u32x4 wA[4][S], wB[4][S];
