@@ -43,6 +43,7 @@ def main():
                     "timed on this GPU and used as the parity gate of the engine (north_star: 1024); 0 = skip")
     ap.add_argument("--ref-seconds", type=float, default=150.0, help="wall-time bound of the reference-kernel leg")
     ap.add_argument("--profile-reps", type=int, default=16)
+    ap.add_argument("--long-prompt", type=int, default=512, help="tokens of the one-call prompt of the prefill report (0 = skip)")
     ap.add_argument("--prefill-chunks", type=int, default=4, help="32-token prompt chunks timed for the prefill report (0 = skip)")
     ap.add_argument("--parallel", choices=["pipeline", "replicas"], default=os.environ.get("RWKV_BENCH_PARALLEL", "pipeline"),
                     help="N > 1: layer pipeline over RCCL send/recv with N streams in flight (default), or N independent replicas")
@@ -84,7 +85,7 @@ def main():
     torch.cuda.synchronize()
     m = engine.RWKV(device=local_rank, resident=True)
     t0 = time.time()
-    m.loadTensors(L, D, tensors, maxGPT=32 if args.prefill_chunks > 0 else 1)
+    m.loadTensors(L, D, tensors, maxGPT=max(32, args.long_prompt) if args.prefill_chunks > 0 else 1)
     load_s = time.time() - t0
 
     rng = np.random.default_rng(1)
@@ -207,6 +208,26 @@ def main():
         line["prefill"] = dict(tokens_per_chunk=len(prompt), ms_per_chunk=round(dtc * 1e3, 3), tokens_per_s=round(len(prompt) / dtc, 1),
                                weight_GBps=round(wbytes / dtc / 1e9, 1), int8_mfma_TOPS=round(2 * 3 * wbytes * len(prompt) / dtc / 1e12, 1),
                                note="GPT-mode chunk (RWKV::loadContext path): v_mfma_i32_16x16x64_i8 over three activation limbs; includes logits for all 32 positions")
+        if args.long_prompt >= 64:
+            # a prompt of several chunks handed over in ONE call (RWKV::loadContext with maxContext >= the prompt, rwkv.h:395-413):
+            # still 32 rows per mm8_seq pass, but the chunks run as a two-stage software pipeline on two streams (engine.hip
+            # rwkv_forward).  Timed without the download of the T x V logits (only the last row matters to loadContext).
+            import ctypes as C
+            lp = [int(x) for x in np.random.default_rng(11).integers(2, mf.VOCAB, args.long_prompt)]
+            arr = (C.c_uint64 * len(lp))(*lp)
+            def run_lp():
+                rc = engine.lib().rwkv_forward(m._h, arr, len(lp), engine.MODE_GPT)
+                if rc != 0:
+                    raise RuntimeError(engine.lib().rwkv_last_error().decode())
+            run_lp()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                run_lp()
+            dtl = (time.perf_counter() - t0) / 2
+            line["prefill"]["long_prompt"] = dict(prompt_tokens=len(lp), tokens_per_s=round(len(lp) / dtl, 1), ms=round(dtl * 1e3, 2),
+                                                  weight_GBps=round(wbytes * (len(lp) / 32) / dtl / 1e9, 1),
+                                                  note="one rwkv_forward call, 32-row chunks pipelined over two streams (layers [0, mid) of chunk i + 1 under "
+                                                       "layers [mid, L) + head of chunk i); RWKV_SEQ_SPLIT=0 gives the one-stream schedule")
         # the same kernels as a batched decode step: 32 independent streams (MODE PARRALEL, state slot per stream)
         m.reset_state()
         m.forward(prompt, engine.MODE_PARRALEL)

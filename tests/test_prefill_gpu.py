@@ -126,3 +126,34 @@ def test_adversarial_statistics_decode_and_chunk(eng_mod, oracle, L, D):
     for name, g, r in zip("xy aa bb pp dd".split(), m.state.arrays(), st):
         assert np.abs(g[: L * D] - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), name
     om.close(); m.close()
+
+
+@pytest.mark.parametrize("L,D,T,mode", [(4, 768, 200, "gpt"), (3, 1024, 97, "gpt"), (2, 768, 70, "par")])
+def test_long_prompt_two_stage_pipeline_is_bit_identical(eng_mod, oracle, L, D, T, mode, monkeypatch):
+    """A forward call of several chunks runs as a two-stage software pipeline on two streams (engine.hip rwkv_forward: layers
+    [0, mid) of chunk i + 1 under layers [mid, L) + head of chunk i).  Same kernels on the same data: every logits row and the
+    whole recurrent state must equal the one-stream schedule (RWKV_SEQ_SPLIT=0) bit for bit -- and the oracle within tolerance."""
+    t = mf.synthetic_tensors(L, D, seed=700 + D + T)
+    toks = _toks(T, 5 * D + T)
+    md = eng_mod.MODE_GPT if mode == "gpt" else eng_mod.MODE_PARRALEL
+    outs = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("RWKV_SEQ_SPLIT", split)
+        m = eng_mod.RWKV(resident=True)
+        m.loadTensors(L, D, t, maxGPT=T)
+        lg = m.forward(toks, md)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+        lg2 = m.forward(toks, md)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()      # a second call: the pipeline's buffers and events are reused
+        m.pull_state(T if mode == "par" else 1)
+        outs[split] = (lg, lg2, [a.copy() for a in m.state.arrays()])
+        m.close()
+    assert np.array_equal(outs["0"][0], outs["1"][0])
+    assert np.array_equal(outs["0"][1], outs["1"][1])
+    for a, b in zip(outs["0"][2], outs["1"][2]):
+        assert np.array_equal(a, b)
+    if mode == "gpt":
+        om = oracle.from_tensors(L, D, t)
+        st = om.new_state()
+        ref = om.forward(toks, st)
+        for i in (0, 31, 32, 63, 64, T - 1):
+            parity.check_logits(outs["1"][0][i], ref[i], f"pos {i}")
+        om.close()
