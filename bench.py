@@ -210,7 +210,7 @@ def main():
                                note="GPT-mode chunk (RWKV::loadContext path): v_mfma_i32_16x16x64_i8 over three activation limbs; includes logits for all 32 positions")
         if args.long_prompt >= 64:
             # a prompt of several chunks handed over in ONE call (RWKV::loadContext with maxContext >= the prompt, rwkv.h:395-413):
-            # still 32 rows per mm8_seq pass, but the chunks run as a two-stage software pipeline on two streams (engine.hip
+            # still 32 rows per mm8_seq pass, but the chunks run as a three-stage software pipeline on three streams (engine.hip
             # rwkv_forward).  Timed without the download of the T x V logits (only the last row matters to loadContext).
             import ctypes as C
             lp = [int(x) for x in np.random.default_rng(11).integers(2, mf.VOCAB, args.long_prompt)]
@@ -226,8 +226,8 @@ def main():
             dtl = (time.perf_counter() - t0) / 2
             line["prefill"]["long_prompt"] = dict(prompt_tokens=len(lp), tokens_per_s=round(len(lp) / dtl, 1), ms=round(dtl * 1e3, 2),
                                                   weight_GBps=round(wbytes * (len(lp) / 32) / dtl / 1e9, 1),
-                                                  note="one rwkv_forward call, 32-row chunks pipelined over two streams (layers [0, mid) of chunk i + 1 under "
-                                                       "layers [mid, L) + head of chunk i); RWKV_SEQ_SPLIT=0 gives the one-stream schedule")
+                                                  note="one rwkv_forward call, 32-row chunks as a software pipeline over RWKV_SEQ_STAGES (default 3) streams on the one GPU "
+                                                       "(stage k on chunk i while stage k - 1 is on chunk i + 1); RWKV_SEQ_STAGES=1 gives the one-stream schedule")
         # the same kernels as a batched decode step: 32 independent streams (MODE PARRALEL, state slot per stream)
         m.reset_state()
         m.forward(prompt, engine.MODE_PARRALEL)
