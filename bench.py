@@ -239,6 +239,22 @@ def main():
         dtb = (time.perf_counter() - t0) / args.prefill_chunks
         line["batched_decode"] = dict(streams=len(prompt), ms_per_step=round(dtb * 1e3, 3), aggregate_tokens_per_s=round(len(prompt) / dtb, 1),
                                       note="MODE PARRALEL: one token of each of 32 independent sequences per step, weights read once per step")
+        if args.long_prompt >= 96:
+            # 96 streams per step = three 32-row passes, pipelined over the stages like the chunks of a long prompt
+            import ctypes as C
+            many = [int(x) for x in np.random.default_rng(12).integers(2, mf.VOCAB, 96)]
+            arrm = (C.c_uint64 * len(many))(*many)
+            def run_many():
+                if engine.lib().rwkv_forward(m._h, arrm, len(many), engine.MODE_PARRALEL) != 0:
+                    raise RuntimeError(engine.lib().rwkv_last_error().decode())
+            m.reset_state()
+            run_many()
+            t0 = time.perf_counter()
+            for _ in range(args.prefill_chunks):
+                run_many()
+            dtm = (time.perf_counter() - t0) / args.prefill_chunks
+            line["batched_decode"]["streams_96"] = dict(ms_per_step=round(dtm * 1e3, 3), aggregate_tokens_per_s=round(len(many) / dtm, 1),
+                                                        note="three 32-row passes per step as a software pipeline over the stages (RWKV_SEQ_STAGES)")
 
     # ---- the reference's OWN kernel on this GPU, same tensors, same prompt: parity gate + baseline ----
     if rank == 0 and args.ref_steps > 0:
