@@ -259,6 +259,14 @@ def main():
     # ---- the reference's OWN kernel on this GPU, same tensors, same prompt: parity gate + baseline ----
     if rank == 0 and args.ref_steps > 0:
         line.update(ref_kernel_leg(mf, tensors, L, D, prompt, m, args.ref_steps, args.ref_seconds, B_tok))
+        # BASELINE config 5 at its stated size: the 32-token prompt as ONE GPT-mode call of the reference kernel (and one
+        # 32-slot PARRALEL step) vs the chunk path that the `prefill` / `batched_decode` legs above timed
+        if args.prefill_chunks > 0:
+            g = chunk_gate_leg(mf, tensors, L, D, prompt, m)
+            if "prefill" in line:
+                line["prefill"]["parity_vs_reference_kernel"] = g.get("gpt_chunk", g)
+            if "batched_decode" in line:
+                line["batched_decode"]["parity_vs_reference_kernel"] = g.get("parralel_step", g)
 
     # ---- CPU baseline: the oracle (CPU restatement of rwkv.cu:493-593) on this box's host cores ----
     if rank == 0 and not args.no_cpu_baseline:
@@ -396,6 +404,36 @@ def ref_kernel_leg(mf, tensors, L, D, prompt, engine_model, steps, budget_s, B_t
                                         first_divergence=g["first_divergence"], steps_outside_tolerance=g["steps_outside_tolerance"],
                                         tolerance=1e-3, note="engine teacher-forced with the reference kernel's greedy ids; logits compared at every step "
                                                              "(max|d| <= 1e-3 max|ref| and |d| <= 1e-3|ref| + 1e-3 rms)"))
+
+
+def chunk_gate_leg(mf, tensors, L, D, prompt, engine_model):
+    """rank 0, N=1: full-depth parity of the CHUNK path (mm8_seq on the int8 matrix cores) against the reference's own kernel
+    run with T = 32 tokens in one call -- GPT mode (RWKV::loadContext's shape, rwkv.h:339-376,395-413; in-kernel token loops
+    rwkv.cu:227,279): all 32 logits rows, the five state arrays, then 8 greedy decode steps from that state; PARRALEL mode
+    (rwkv.cu:236-240): two 32-slot steps, all rows, all slots of the state.  tests/refgate.run_chunk_gate."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import refgate
+    from rwkv_cpp_accelerated_amd import engine
+    if not os.path.exists(oracle_lib.REF_SO):
+        return dict(skipped="oracle/_ref/libref.so not built")
+    ref = oracle_lib.Ref()
+    rm = refgate.ref_model_from_torch(ref, mf, tensors, L, D, len(prompt))
+    was = engine_model.resident
+    engine_model.resident = True
+    g = refgate.run_chunk_gate(rm, engine_model, mf, engine, prompt, decode_steps=8)
+    engine_model.resident = was
+    tol = dict(tolerance=1e-3, state_tolerance=1e-4,
+               note="engine chunk path vs reference include/rwkv/cuda/rwkv.cu (built unmodified for gfx950) called with T=32 tokens; "
+                    "logits: max|d| <= 1e-3 max|ref| and |d| <= 1e-3|ref| + 1e-3 rms per row; state: max|d| / max(1, max|ref|)")
+    for k in g:
+        for kk, v in list(g[k].items()):
+            if isinstance(v, float):
+                g[k][kk] = float(f"{v:.3e}")
+            elif isinstance(v, dict):
+                g[k][kk] = {a: float(f"{b:.3e}") for a, b in v.items()}
+        g[k].update(tol)
+    return g
 
 
 def cpu_baseline(pkg, mf, tensors, L, D, prompt, budget_s, engine_model=None):

@@ -71,3 +71,87 @@ def run_gate(rm, em, mf, prompt, steps, budget_s=None, strict=False, what=""):
             break
     return dict(steps=done, max_rel=worst, steps_outside_tolerance=bad_steps, ids_identical=first_div is None,
                 first_divergence=first_div, ref_seconds=n_ref_s, ids=ids_ref)
+
+
+def _rows(le, lr, strict, what):
+    """compare [T][V] logits row by row; returns (max_rel, rows outside tolerance, rows whose greedy id differs)"""
+    worst, bad, diff = 0.0, 0, 0
+    for i in range(lr.shape[0]):
+        r = lr[i].astype(np.float64); e = le[i].astype(np.float64)
+        d = np.abs(e - r)
+        mx = float(np.abs(r).max()); rms = float(np.sqrt((r ** 2).mean()))
+        rel = float(d.max() / mx)
+        ok = bool(np.isfinite(e).all()) and rel <= parity.REL and not bool((d > parity.REL * np.abs(r) + parity.REL * rms).any())
+        worst = max(worst, rel)
+        bad += 0 if ok else 1
+        diff += 0 if parity.argmax_ban0(lr[i]) == parity.argmax_ban0(le[i]) else 1
+        if strict:
+            parity.check_logits(le[i], lr[i], f"{what} row {i}")
+            parity.check_argmax(le[i], lr[i], f"{what} row {i}")
+    return worst, bad, diff
+
+
+def _state_err(em, rm, n):
+    """max |engine - reference| over the first n entries of each of the five state arrays, relative to max(1, max|ref|)"""
+    out = {}
+    for name, g, which in zip("xy aa bb pp dd".split(), em.state.arrays(), range(5)):
+        r = rm.state(which)[:n]
+        out[name] = float(np.abs(g[:n] - r).max() / max(1.0, float(np.abs(r).max())))
+    return out
+
+
+def run_chunk_gate(rm, em, mf, engine_mod, prompt, decode_steps=8, strict=False, what="", state_tol=1e-4):
+    """BASELINE config 5 at its stated size.  rm: RefModel made with maxGPT >= len(prompt); em: engine.RWKV (resident state,
+    maxGPT >= len(prompt)).
+    (a) GPT mode: the prompt as ONE multi-token call of the reference (RWKV::forward with T tokens, rwkv.h:339-376; the in-kernel
+        token loops rwkv.cu:227,279 -- what RWKV::loadContext drives, rwkv.h:395-413) against the engine's chunk path (mm8_seq on
+        the int8 matrix cores): every logits row, the five state arrays, then `decode_steps` greedy single-token steps from that
+        state, teacher-forced with the reference's ids.
+    (b) PARRALEL mode (rwkv.cu:236-240): one step of len(prompt) independent sequences, two rounds so the per-slot state carries
+        over, every logits row and all slots of the five state arrays."""
+    T = len(prompt)
+    LD = rm.L_ * rm.D
+    res = {}
+    # ---- (a) GPT chunk ----
+    em.reset_state()
+    for s in range(5):
+        rm.state(s)[:] = 0.0
+    t0 = time.perf_counter()
+    lr = rm.forward(prompt, oracle_lib.MODE_GPT)
+    ref_s = time.perf_counter() - t0
+    le = em.forward(prompt, engine_mod.MODE_GPT)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+    worst, bad, diff = _rows(le, lr, strict, f"{what} GPT chunk")
+    em.pull_state(1)
+    serr = _state_err(em, rm, LD)
+    if strict:
+        assert max(serr.values()) <= state_tol, serr
+    tk = parity.argmax_ban0(lr[T - 1])
+    dworst, dbad, ddiff = 0.0, 0, 0
+    for step in range(decode_steps):
+        l1 = rm.forward([tk])
+        e1 = em.forward(int(tk))[: mf.VOCAB].reshape(1, mf.VOCAB)
+        w, b, d = _rows(e1, l1, strict, f"{what} decode after chunk, step {step}")
+        dworst = max(dworst, w); dbad += b; ddiff += d
+        tk = parity.argmax_ban0(l1[0])
+    res["gpt_chunk"] = dict(rows=T, max_rel=worst, rows_outside_tolerance=bad, rows_greedy_id_differs=diff, state_max_rel=serr,
+                            decode_steps_after=decode_steps, decode_max_rel=dworst, decode_steps_outside_tolerance=dbad,
+                            decode_ids_identical=ddiff == 0, ref_chunk_seconds=ref_s)
+    # ---- (b) PARRALEL step ----
+    em.reset_state()
+    for s in range(5):
+        rm.state(s)[:] = 0.0
+    rng = np.random.default_rng(4321)
+    worst, bad, diff = 0.0, 0, 0
+    for rnd in range(2):
+        toks = prompt if rnd == 0 else [int(x) for x in rng.integers(2, mf.VOCAB, T)]
+        lr = rm.forward(toks, oracle_lib.MODE_PARRALEL)
+        le = em.forward(toks, engine_mod.MODE_PARRALEL)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+        w, b, d = _rows(le, lr, strict, f"{what} PARRALEL round {rnd}")
+        worst = max(worst, w); bad += b; diff += d
+    em.pull_state(T)
+    serr = _state_err(em, rm, T * LD)
+    if strict:
+        assert max(serr.values()) <= state_tol, serr
+    res["parralel_step"] = dict(slots=T, rounds=2, max_rel=worst, rows_outside_tolerance=bad, rows_greedy_id_differs=diff, state_max_rel=serr)
+    em.reset_state()
+    return res

@@ -84,3 +84,26 @@ def test_full_depth_gate_vs_reference_kernel(built, ref, name, steps):
     em.close()
     del t
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name,T", [("14B", 32), ("1B5", 32)])
+def test_chunk_path_full_depth_vs_reference_kernel(built, ref, name, T):
+    """BASELINE config 5's shape at FULL depth (the 7B / L=32 instance runs inside bench.py: prefill.parity_vs_reference_kernel):
+    a T-token prompt as ONE GPT-mode call of the reference's own kernel (rwkv.h:339-376; in-kernel token loops rwkv.cu:227,279)
+    against the engine's chunk path -- all T logits rows, the five state arrays, 8 greedy decode steps from that state -- and two
+    T-slot PARRALEL steps (rwkv.cu:236-240), all rows, all slots of the state."""
+    import torch
+    from rwkv_cpp_accelerated_amd import engine
+    import refgate
+    L, D = mf.SHAPES[name]
+    t = mf.synthetic_tensors_torch(L, D, seed=6, device="cuda")
+    torch.cuda.synchronize()
+    em = engine.RWKV(resident=True); em.loadTensors(L, D, t, maxGPT=T)
+    rm = refgate.ref_model_from_torch(ref, mf, t, L, D, T)
+    prompt = [int(x) for x in np.random.default_rng(8).integers(2, mf.VOCAB, T)]
+    g = refgate.run_chunk_gate(rm, em, mf, engine, prompt, decode_steps=8, strict=True, what=name)
+    assert g["gpt_chunk"]["rows_outside_tolerance"] == 0 and g["gpt_chunk"]["decode_steps_outside_tolerance"] == 0
+    assert g["parralel_step"]["rows_outside_tolerance"] == 0
+    em.close()
+    del t
+    torch.cuda.empty_cache()
