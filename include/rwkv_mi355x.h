@@ -25,6 +25,13 @@
 extern "C" {
 #endif
 
+/* Version of this C-ABI: bumped whenever an existing entry point changes its argument list or meaning (additions alone do
+ * not bump it).  3: rwkv_decode_typical / rwkv_sample_typical take `flags`; the one-launch-token hooks (rwkv_one_launch,
+ * rwkv_debug_mega_timeline) are gone; bounded device-side waits report RWKV_E_DEVICE.  rwkv_abi_version() returns the value the
+ * library was built with: a binding compares it with the header it was compiled against. */
+#define RWKV_MI355X_ABI_VERSION 3
+int rwkv_abi_version(void);
+
 #define RWKV_VOCAB 50277u /* hard-wired in the reference: rwkv.h:126, rwkv.cu:471,589 */
 #define RWKV_N_TENSORS 46 /* tensor slots of model.bin: enums/enum.h:7-55 */
 
@@ -168,6 +175,10 @@ float *rwkv_logits_device(rwkv_ctx *ctx);
 double *rwkv_state_device(rwkv_ctx *ctx, int which);
 /* The HIP stream (hipStream_t) all engine work is enqueued on. */
 void *rwkv_stream(rwkv_ctx *ctx);
+/* Device bytes this context holds: decode-layout weights + row sums + site tables + embedding + state + scratch and, when
+ * max_ctx > 1 on a whole-model context, the SECOND resident copy of the matrices in the MFMA B-operand image of the chunk
+ * path (+7.2 GB at 7B, +13.9 GB at 14B). */
+uint64_t rwkv_resident_bytes(const rwkv_ctx *ctx);
 /* Algorithmic HBM bytes of one token (13*L*D^2 + V*D uint8 weight bytes
  * + 168*L*D + 40*D bytes of vectors/state). */
 uint64_t rwkv_bytes_per_token(const rwkv_ctx *ctx);
@@ -189,15 +200,6 @@ int rwkv_profile_batched(rwkv_ctx *ctx, uint64_t token, int reps, double *ms, ui
 /* Tuning aid: run one eager token with phase timestamps enabled in the middle layer's ffn r+k
  * kernel; out receives grid*8*8 stamps of the 100 MHz device wall clock ([workgroup][wave][phase]). */
 int rwkv_debug_timeline(rwkv_ctx *ctx, uint64_t token, unsigned long long *out, uint64_t cap);
-
-/* Tuning aid for the one-launch token (csrc/mega.hip.h): one eager launch with its timeline on; out receives
- * grid * phases * 8 stamps of the 100 MHz wall clock, [workgroup][phase][slot]; *phases = 1 + 4 * layers (+ 1: head). */
-int rwkv_debug_mega_timeline(rwkv_ctx *ctx, uint64_t token, unsigned long long *out, uint64_t cap, uint32_t *phases);
-
-/* 1: a token of this context is ONE kernel launch (persistent workgroups, LDS-DMA weight stream across the phases of the
- * token; experimental, measured slower than the launches on MI355X: opt-in with RWKV_MEGA=1 at load time);
- * 0 (default): four launches per layer, one hipGraph replay per token. */
-int rwkv_one_launch(const rwkv_ctx *ctx);
 
 /* Standalone launch of the engine's dequant-GEMV on caller-provided device buffers
  * (the kernel behind cudac_mm8_one(), rwkv.cu:297-311): w is FILE layout [N][M] u8 (one layer),

@@ -9,9 +9,15 @@
 //
 // Like rwkv.cu (which only includes enums/enum.h, rwkv.cu:14) it does not include rwkv.h itself: that header defines
 // non-inline functions (getSize, Mtypes, getName) that may live in one translation unit only.
-// The device tensors stay behind the engine handle, so ptrs[] is filled with NULL and the 44 tensor arguments of the
-// forward call are ignored -- RWKV only ever passes back what load() put there.
-// Compiled and linked by oracle/Makefile (targets storygen_l2) and exercised by tests/test_dropin_*.py.
+// The device tensors stay behind an engine handle PER MODEL: every RWKV object owns its tensors[] table (rwkv.h:248,288; the
+// pybind module hands out a fresh RWKV per initRwkv, c_binding.cpp:28-33), so load() creates one engine context per call and
+// parks it in the table it is given -- ptrs[X] and ptrs[STATEXY] point to a small tagged block that holds the context; the
+// header passes exactly those two slots back into every other backend function (tensors[X] as `x` of cuda_rwkv_parralel,
+// tensors[STATEXY] as the first state pointer of setState / getOutput, the whole table to freeTensors).  The remaining slots
+// are filled with the device pointers the engine keeps in file layout (rwkv_tensor_device; NULL for the re-tiled matrices):
+// RWKV only ever passes them back, and the 44 tensor arguments of the forward call are ignored.
+// Compiled and linked by oracle/Makefile (targets storygen_l2, vectordb_l2, terminalchat_l2, two_models_l2) and exercised
+// by tests/test_dropin_*.py.
 #include <cstdint>
 #include <cstdlib>
 #include <iostream>
@@ -21,9 +27,15 @@
 #include "rwkv/enums/enum.h"   // the reference's MODE + slot enum
 #include "rwkv_mi355x.h"
 
-static rwkv_ctx *g_ctx = nullptr;
+namespace {
 
-static void die_on(int rc)
+struct Parked {                       // what ptrs[X] / ptrs[STATEXY] point to
+    uint64_t magic;
+    rwkv_ctx *ctx;
+};
+constexpr uint64_t kMagic = 0x4d49333535585f52ull;   // "R_X553IM"
+
+void die_on(int rc)
 {
     if (rc != RWKV_OK) {   // the reference's backend has no error channel either: missing file -> message + exit(1), rwkv.cu:641-645
         std::cout << rwkv_last_error() << std::endl;
@@ -31,41 +43,59 @@ static void die_on(int rc)
     }
 }
 
+rwkv_ctx *ctx_of(const void *slot)
+{
+    const Parked *p = static_cast<const Parked *>(slot);
+    if (!p || p->magic != kMagic || !p->ctx) {
+        std::cout << "rwkv_backend_mi355x: this pointer did not come from load() (tensors[X] / tensors[STATEXY] carry the engine handle)" << std::endl;
+        exit(1);
+    }
+    return p->ctx;
+}
+
+} // namespace
+
 std::tuple<unsigned long long, unsigned long long> load(const std::string &filename, int **ptrs, unsigned long long maxGPT)
 {
-    if (!g_ctx) {
-        const char *dev = getenv("RWKV_DEVICE");
-        die_on(rwkv_create(&g_ctx, dev ? atoi(dev) : 0));
-    }
-    die_on(rwkv_load_file(g_ctx, filename.c_str(), maxGPT));
-    for (int i = 0; i < 46; i++) ptrs[i] = nullptr;
-    std::cout << "n_layers: " << rwkv_n_layers(g_ctx) << std::endl << "n_embed: " << rwkv_n_embed(g_ctx) << std::endl;   // rwkv.cu:653-654
-    return std::make_tuple((unsigned long long)rwkv_n_layers(g_ctx), (unsigned long long)rwkv_n_embed(g_ctx));
+    rwkv_ctx *ctx = nullptr;
+    const char *dev = getenv("RWKV_DEVICE");
+    die_on(rwkv_create(&ctx, dev ? atoi(dev) : 0));
+    die_on(rwkv_load_file(ctx, filename.c_str(), maxGPT));
+    for (int i = 0; i < 46; i++) ptrs[i] = static_cast<int *>(rwkv_tensor_device(ctx, i));
+    Parked *park = new Parked{kMagic, ctx};
+    ptrs[X] = reinterpret_cast<int *>(park);
+    ptrs[STATEXY] = reinterpret_cast<int *>(park);
+    std::cout << "n_layers: " << rwkv_n_layers(ctx) << std::endl << "n_embed: " << rwkv_n_embed(ctx) << std::endl;   // rwkv.cu:653-654
+    return std::make_tuple((unsigned long long)rwkv_n_layers(ctx), (unsigned long long)rwkv_n_embed(ctx));
 }
 
 // rwkv.cu:479-490.  (The header's callers pass (num_layers, num_embed) into (n_embed, n_layers): only the product matters.)
-void setState(unsigned long long, unsigned long long, double *, double *, double *, double *, double *,
+// dev_xy = tensors[STATEXY] = the parked handle
+void setState(unsigned long long, unsigned long long, double *dev_xy, double *, double *, double *, double *,
               double *xy, double *aa, double *bb, double *pp, double *dd, unsigned long long tokenlength)
 {
-    die_on(rwkv_set_state(g_ctx, xy, aa, bb, pp, dd, tokenlength));
+    die_on(rwkv_set_state(ctx_of(dev_xy), xy, aa, bb, pp, dd, tokenlength));
 }
 
-// rwkv.cu:467-477
-void getOutput(unsigned long long, unsigned long long, float *, double *, double *, double *, double *, double *,
+// rwkv.cu:467-477; dev_xy = tensors[STATEXY]
+void getOutput(unsigned long long, unsigned long long, float *, double *dev_xy, double *, double *, double *, double *,
                float *logitsout, double *xy, double *aa, double *bb, double *pp, double *dd, unsigned long long tokenlength)
 {
-    die_on(rwkv_get_output(g_ctx, logitsout, xy, aa, bb, pp, dd, tokenlength));
+    die_on(rwkv_get_output(ctx_of(dev_xy), logitsout, xy, aa, bb, pp, dd, tokenlength));
 }
 
 // rwkv.cu:719-730
-void freeTensors(int **)
+void freeTensors(int **ptrs)
 {
-    rwkv_free(g_ctx);
-    g_ctx = nullptr;
+    Parked *park = reinterpret_cast<Parked *>(ptrs[X]);
+    rwkv_free(ctx_of(park));
+    park->magic = 0; park->ctx = nullptr;
+    delete park;
+    for (int i = 0; i < 46; i++) ptrs[i] = nullptr;
 }
 
-// rwkv.cu:493-593
-void cuda_rwkv_parralel(unsigned long long, unsigned long long, unsigned long long *token, double *,
+// rwkv.cu:493-593; x = tensors[X] = the parked handle
+void cuda_rwkv_parralel(unsigned long long, unsigned long long, unsigned long long *token, double *x,
                         float *, double *,
                         double *, double *, double *, double *, double *,
                         double *, float *, float *, float *,
@@ -84,7 +114,7 @@ void cuda_rwkv_parralel(unsigned long long, unsigned long long, unsigned long lo
                         unsigned long long tokenlength, MODE mode)
 {
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "token ids are 64-bit");
-    die_on(rwkv_forward(g_ctx, reinterpret_cast<const uint64_t *>(token), tokenlength, mode == PARRALEL ? RWKV_MODE_PARRALEL : RWKV_MODE_GPT));
+    die_on(rwkv_forward(ctx_of(x), reinterpret_cast<const uint64_t *>(token), tokenlength, mode == PARRALEL ? RWKV_MODE_PARRALEL : RWKV_MODE_GPT));
 }
 
 // rwkv.cu:595-628

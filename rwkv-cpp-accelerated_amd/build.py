@@ -59,7 +59,7 @@ def _run(cmd, cwd=None):
 def build_engine(force: bool = False) -> str:
     """csrc/engine.hip (+ kernels.hip.h, seq.hip.h) -> csrc/librwkv_mi355x.so"""
     out = os.path.join(CSRC, "librwkv_mi355x.so")
-    srcs = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "kernels.hip.h"), os.path.join(CSRC, "mega.hip.h"), os.path.join(CSRC, "seq.hip.h"), os.path.join(CSRC, "sampler.hip.h"),
+    srcs = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "kernels.hip.h"), os.path.join(CSRC, "seq.hip.h"), os.path.join(CSRC, "sampler.hip.h"),
             os.path.join(ROOT, "include", "rwkv_mi355x.h")]
     if force or _stale(out, srcs):
         _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -80,11 +80,17 @@ def build_pybind(force: bool = False):
     ext = sysconfig.get_config_var("EXT_SUFFIX")
     out = os.path.join(CSRC, "rwkv" + ext)
     hdrs = [os.path.join(ROOT, "include", f) for f in ("rwkv.h", "rwkv_mi355x.h", "rwkv_sampler.h")]
-    # with the reference's include directory on the path include/rwkv.h pulls in the reference's own tokenizer and the
-    # module gains initTokenizer / tokenizerEncode / tokenizerDecode; a box without the reference keeps the module it was
-    # shipped (a rebuild there would silently drop the three functions)
+    # With the reference's include directory on the path include/rwkv.h pulls in the reference's own tokenizer and the module
+    # gains initTokenizer / tokenizerEncode / tokenizerDecode (c_binding.cpp:158-175): the upstream headers are a BUILD
+    # dependency of the full module surface.  A stale module is always rebuilt (a stale one next to a rebuilt engine would call
+    # the C-ABI with an old argument list); where the headers are absent that rebuild would silently drop the three tokenizer
+    # forwards, so it is refused unless asked for (RWKV_PYBIND_NO_TOKENIZER=1).
     ref = reference_root()
-    if force or (_stale(out, [src] + hdrs) and (ref or not os.path.exists(out))):
+    if force or _stale(out, [src] + hdrs):
+        if not ref and os.environ.get("RWKV_PYBIND_NO_TOKENIZER") != "1":
+            raise RuntimeError(f"{out} is stale and the reference's tokenizer headers (RWKV_REFERENCE, default /root/reference) are not here: "
+                               "rebuild in the authoring container, or set RWKV_PYBIND_NO_TOKENIZER=1 to build the module without "
+                               "initTokenizer / tokenizerEncode / tokenizerDecode")
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + os.path.join(ROOT, "include")] +
              (["-I" + os.path.join(ref, "include")] if ref else []) +
              ["-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src, "-o", out,
@@ -106,7 +112,7 @@ def build_oracle(force: bool = False):
             _run(["make", "-C", odir, "ref", f"REF={ref_root}"])
         # the reference's sampler and the reference's own caller (storygen) built against the drop-in: checkers / evidence
         # that only the authoring container can compile (they read /root/reference at BUILD time, never at run time)
-        _run(["make", "-C", odir, "typical", "storygen", "storygen_l2", f"REF={ref_root}", f"ROOT={ROOT}"])
+        _run(["make", "-C", odir, "typical", "storygen", "storygen_l2", "callers", f"REF={ref_root}", f"ROOT={ROOT}"])
     return so, (ref_so if os.path.exists(ref_so) else None)
 
 

@@ -5,7 +5,6 @@
 // engine: weights are re-tiled once at load, state and the embedding table stay resident on the
 // device, and one token is a replay of a captured hipGraph (4 launches per layer + 2).
 #include "kernels.hip.h"
-#include "mega.hip.h"
 #include "seq.hip.h"
 #include "sampler.hip.h"
 #include "../../include/rwkv_mi355x.h"
@@ -193,13 +192,9 @@ struct rwkv_ctx {
     unsigned *ts_key = nullptr;
     unsigned gen_cap = 0;
     hipGraphExec_t g_fwd = nullptr, g_greedy = nullptr;
-    // one-launch token (mega.hip.h), experimental: -1 = default (off), 0 off, 1 on; env RWKV_MEGA overrides
-    int mega = -1;
-    bool mega_on = false;
-    MegaSync *msync = nullptr;
-    unsigned *herr = nullptr;            // mapped pinned word the kernel raises when a wait gave up
-    AttArgs *m_att = nullptr; AttOutArgs *m_attout = nullptr; FfnRKArgs *m_frk = nullptr; FfnVArgs *m_fv = nullptr;   // device arrays [l1 - l0]
-    unsigned long long *mtl = nullptr;   // timeline of the one-launch token (debug), [grid][phases][MG_TL]
+    // device error word: a mapped pinned word that a kernel raises when one of its bounded waits gave up (LDS ring hand-offs);
+    // checked after every stream synchronisation (device_check)
+    unsigned *herr = nullptr, *d_herr = nullptr;
     unsigned long long *tl = nullptr;   // phase-timeline buffer (debug), [grid][NW][8]
     bool tl_on = false;
     int tl_cls = 3;                     // kernel class the timeline instruments (env RWKV_TL_CLASS, 1..4)
@@ -221,6 +216,8 @@ struct rwkv_ctx {
     hipEvent_t sp_end = nullptr;
     double *x_in = nullptr;                       // decode: residual vector received from the previous stage (nullptr: c->x)
     struct Pipe *pipe = nullptr;                  // RCCL transport of the layer pipeline (rwkv_pipe_init)
+    Ctl *pipe_ring = nullptr;                     // pinned control blocks of rwkv_pipe_decode's items (grown on demand, kept)
+    uint64_t pipe_ring_cap = 0;
     double *sq_state = nullptr;                   // [D] LayerNorm output of the chunk's last token
     float *sq_y = nullptr;                        // gated wkv output [SEQ_T][D]
     unsigned *sq_img[3] = {nullptr, nullptr, nullptr}, *sq_imgh = nullptr;   // MFMA A-operand images (K = D; K = 4D)
@@ -231,6 +228,7 @@ struct rwkv_ctx {
     uint8_t *b_kvr = nullptr, *b_att = nullptr, *b_frk = nullptr, *b_fv = nullptr, *b_head = nullptr;
     unsigned *r8_kvr = nullptr, *r8_att = nullptr, *r8_frk = nullptr, *r8_fv = nullptr, *r8_head = nullptr;
     std::vector<void *> allocs;
+    size_t alloc_bytes = 0;                       // device bytes behind `allocs` (rwkv_resident_bytes)
 };
 
 namespace {
@@ -240,6 +238,7 @@ template <typename T> int dalloc(rwkv_ctx *c, T **p, size_t count)
     void *q = nullptr;
     HIPCHK(hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16)));
     c->allocs.push_back(q);
+    c->alloc_bytes += std::max<size_t>(count * sizeof(T), 16);
     *p = static_cast<T *>(q);
     return 0;
 }
@@ -284,17 +283,16 @@ template <typename K> int allow_smem(K kernel, size_t bytes)
 
 
 // ---- argument blocks of the decode kernels (shared by the per-class launches and the one-launch token) ----
-// mega: every site is opened by the full grid (the launch path opens the stage's first ln1 site with k_first's few workgroups)
+// (the stage's first ln1 site is opened by k_first's few workgroups, every other site by the full grid)
 struct ArgMaker {
     rwkv_ctx *c;
-    bool mega;
     int D, grid, n_first;
     size_t LD;
-    explicit ArgMaker(rwkv_ctx *c_, bool mega_ = false) : c(c_), mega(mega_), D((int)c_->D), grid(c_->grid), LD((size_t)c_->L * c_->D)
+    explicit ArgMaker(rwkv_ctx *c_) : c(c_), D((int)c_->D), grid(c_->grid), LD((size_t)c_->L * c_->D)
     {
-        n_first = mega ? grid : (grid < 32 ? grid : 32);
+        n_first = grid < 32 ? grid : 32;
     }
-    unsigned long long *tl_of(int k, uint64_t l) const { return (!mega && c->tl_on && k == c->tl_cls && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr; }
+    unsigned long long *tl_of(int k, uint64_t l) const { return (c->tl_on && k == c->tl_cls && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr; }
     SiteStatic site_static(int k, uint64_t ll) const
     {
         const int nv = SITE_NV[k], pw = SITE_PW[k];
@@ -327,7 +325,7 @@ struct ArgMaker {
         aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
         aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
         aa.slot_stride = LD; aa.ybuf = c->ybuf; aa.partS = c->partA; aa.partM = c->partMA;
-        aa.ctl = c->ctl; aa.D = D; aa.ns = 0; aa.tl = tl_of(1, l);
+        aa.ctl = c->ctl; aa.D = D; aa.ns = 0; aa.tl = tl_of(1, l); aa.herr = c->d_herr;
         return aa;
     }
     AttOutArgs attout(uint64_t l) const
@@ -337,7 +335,7 @@ struct ArgMaker {
         ao.w = c->w_att + (size_t)(l - c->l0) * D * D; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
         ao.x = c->x; ao.lnw = c->ln + (4 * l + 2) * D; ao.lnb = c->ln + (4 * l + 3) * D; ao.lnstat = c->lnstat + 0;
         ao.sxy = c->state[0] + lo; ao.st = site_static(1, l); ao.dy = site_dyn(1, grid); ao.sdd = c->state[4] + lo;
-        ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.ns = 0; ao.tl = tl_of(2, l);
+        ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.ns = 0; ao.tl = tl_of(2, l); ao.herr = c->d_herr;
         return ao;
     }
     FfnRKArgs frk(uint64_t l) const
@@ -348,7 +346,7 @@ struct ArgMaker {
         fa.w = c->w_frk + (size_t)(l - c->l0) * 5 * D * D; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5;
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.partM = c->partMF; fa.ctl = c->ctl; fa.D = D;
-        fa.ns = 0; fa.tl = tl_of(3, l);
+        fa.ns = 0; fa.tl = tl_of(3, l); fa.herr = c->d_herr;
         return fa;
     }
     // the site ffn_v opens: ln1 of layer l + 1 (3 vectors), or ln_out -> head after the stage's last layer (on a non-final
@@ -361,7 +359,7 @@ struct ArgMaker {
         fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
         fv.rgate = c->rgate; fv.x = c->x; fv.lnw = c->ln + (4 * l + 4) * D; fv.lnb = c->ln + (4 * l + 5) * D; fv.lnstat = c->lnstat + 2;
         fv.sdd = c->state[4] + lo; fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D; fv.tl = tl_of(4, l);
-        fv.ns = 0;
+        fv.ns = 0; fv.herr = c->d_herr;
         if (fv_next_att(l)) { fv.st = site_static(0, l + 1); fv.dy = site_dyn(0, grid); fv.sprev = c->state[0] + lo + D; }
         else { fv.st = site_static(2, 0); fv.dy = site_dyn(2, grid); fv.sprev = nullptr; }
         return fv;
@@ -370,7 +368,7 @@ struct ArgMaker {
     {
         HeadArgs ha;
         ha.x = c->x; ha.st = site_static(2, 0); ha.dy = site_dyn(2, grid); ha.w = c->w_head; ha.rs = c->rs_head; ha.logits = c->logits;
-        ha.blk_val = c->blk_val; ha.blk_idx = c->blk_idx; ha.ctl = c->ctl; ha.D = D; ha.ns = 0;
+        ha.blk_val = c->blk_val; ha.blk_idx = c->blk_idx; ha.ctl = c->ctl; ha.D = D; ha.ns = 0; ha.herr = c->d_herr;
         return ha;
     }
 };
@@ -421,87 +419,15 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
     }
 }
 
-// ---- the one-launch token (mega.hip.h) ----
-size_t mega_smem(int S)
+// after a synchronisation: did a bounded wait inside a kernel give up?  (a ring hand-off that never arrived: the GPU is shared
+// or preempted, or a workgroup died.)  The token's results are not to be trusted: fail loudly instead of returning them.
+int device_check(rwkv_ctx *c)
 {
-    size_t b = 0;
-    DISPATCH_S(S, b = (size_t)MegaLds<S_>::BYTES);
-    return b;
-}
-// set the context up for k_token: argument tables on the device, the synchronisation block, the kernel's LDS limit.
-// Leaves mega_on = false (the launch path stays) when the shape does not fit the kernel's assumptions.
-int mega_setup(rwkv_ctx *c)
-{
-    c->mega_on = false;
-    const char *e = getenv("RWKV_MEGA");
-    int want = c->mega;
-    if (e && e[0]) want = atoi(e);
-    // Off unless asked for (RWKV_MEGA=1).  Measured on MI355X (profiles/r02/mega_*.txt): the ring protocol streams a 7B
-    // layer at 6.8 TB/s when nothing synchronises the chip (32 us against the launches' 53.5), but every edge costs four dependent
-    // trips through a saturated memory system (drain, arrival, poll, hand-off loads) where a kernel boundary costs 1.8 us: 87 us per
-    // layer.  Also: two such kernels of different processes on one GPU would starve each other.
-    if (want < 0) want = 0;
-    if (!want) return 0;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, c->device));
-    const int D = (int)c->D, grid = c->grid;
-    const uint64_t nl = c->l1 - c->l0;
-    if (grid > 256 || grid > prop.multiProcessorCount || grid < 8) return 0;          // every workgroup resident, tuples reduced by 256 threads
-    if ((D + grid - 1) / grid + MG_AR > MG_MAXROWS) return 0;
-    if ((size_t)prop.sharedMemPerBlockOptin < mega_smem(c->S) && (size_t)prop.sharedMemPerBlock < mega_smem(c->S)) return 0;
-    const ArgMaker mk(c, true);
-    std::vector<AttArgs> a(nl);
-    std::vector<AttOutArgs> ao(nl);
-    std::vector<FfnRKArgs> fr(nl);
-    std::vector<FfnVArgs> fv(nl);
-    for (uint64_t i = 0; i < nl; i++) { a[i] = mk.att(c->l0 + i); ao[i] = mk.attout(c->l0 + i); fr[i] = mk.frk(c->l0 + i); fv[i] = mk.fv(c->l0 + i); }
-    int rc;
-    if ((rc = dalloc(c, &c->m_att, nl))) return rc;
-    if ((rc = dalloc(c, &c->m_attout, nl))) return rc;
-    if ((rc = dalloc(c, &c->m_frk, nl))) return rc;
-    if ((rc = dalloc(c, &c->m_fv, nl))) return rc;
-    HIPCHK(hipMemcpy(c->m_att, a.data(), nl * sizeof(AttArgs), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->m_attout, ao.data(), nl * sizeof(AttOutArgs), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->m_frk, fr.data(), nl * sizeof(FfnRKArgs), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->m_fv, fv.data(), nl * sizeof(FfnVArgs), hipMemcpyHostToDevice));
-    if ((rc = dalloc(c, &c->msync, 1))) return rc;
-    HIPCHK(hipMemset(c->msync, 0, sizeof(MegaSync)));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->herr), 64, hipHostMallocMapped));
+    if (!c->herr || *c->herr == 0u) return 0;
+    const unsigned code = *c->herr;
     *c->herr = 0u;
-    DISPATCH_S(c->S, rc = allow_smem(k_token<S_>, mega_smem(c->S)));
-    if (rc) return rc;
-    c->mega_on = true;
-    return 0;
-}
-MegaArgs mega_args(rwkv_ctx *c, bool with_argmax, unsigned long long *tl)
-{
-    const ArgMaker mk(c, true);
-    MegaArgs m;
-    m.first = mk.first();
-    m.head = mk.head();
-    m.att = c->m_att; m.attout = c->m_attout; m.frk = c->m_frk; m.fv = c->m_fv;
-    m.sync = c->msync;
-    void *dp = nullptr;
-    (void)hipHostGetDevicePointer(&dp, c->herr, 0);
-    m.herr = static_cast<unsigned *>(dp);
-    m.ctl = c->ctl; m.gen = c->gen; m.gen_cap = c->gen_cap;
-    m.nl = (int)(c->l1 - c->l0); m.has_head = c->l1 == c->L ? 1 : 0; m.with_argmax = (with_argmax && c->l1 == c->L) ? 1 : 0; m.D = (int)c->D;
-    m.tl = tl;
-    return m;
-}
-void launch_token(rwkv_ctx *c, bool with_argmax, unsigned long long *tl)
-{
-    const MegaArgs m = mega_args(c, with_argmax, tl);
-    DISPATCH_S(c->S, k_token<S_><<<dim3(c->grid), dim3(NT), mega_smem(c->S), c->stream>>>(m));
-}
-// after a synchronisation: did a wait inside k_token give up?  (resets the block so that the context stays usable)
-int mega_check(rwkv_ctx *c)
-{
-    if (!c->mega_on || !c->herr || *c->herr == 0u) return 0;
-    *c->herr = 0u;
-    (void)hipMemsetAsync(c->msync, 0, sizeof(MegaSync), c->stream);
-    (void)hipStreamSynchronize(c->stream);
-    return fail(RWKV_E_DEVICE, "one-launch token: a device-side wait gave up (workgroups not co-resident, or the GPU is shared); set RWKV_MEGA=0");
+    return fail(RWKV_E_DEVICE, "a device-side wait gave up (code %u: LDS ring hand-off timed out; is the GPU shared or preempted?) -- "
+                               "the results of this call are invalid; RWKV_RING=0 selects the register kernels", code);
 }
 
 // enqueue the kernels of one token on the context's stream.  ev: optional array of
@@ -510,11 +436,6 @@ int enqueue_token(rwkv_ctx *c, bool with_argmax, hipEvent_t *ev)
 {
     const bool last = c->l1 == c->L;
     int evi = 0;
-    if (c->mega_on && !ev && !c->tl_on) {   // the whole token as one launch (the per-class path below serves the profilers)
-        launch_token(c, with_argmax, nullptr);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
 #define EV() do { if (ev) HIPCHK(hipEventRecord(ev[evi++], c->stream)); } while (0)
     EV();
     launch_class(c, 0, 0);   // first stage: embed + ln0; every stage: open the ln1 site of its first layer
@@ -540,6 +461,15 @@ int build_graph(rwkv_ctx *c, bool with_argmax, hipGraphExec_t *out)
     HIPCHK(e);
     HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
     HIPCHK(hipGraphDestroy(g));
+    return 0;
+}
+
+// (re)capture the token graphs around the context's current argument blocks (x_in changes with rwkv_pipe_init / rwkv_pipe_free)
+int rebuild_graphs(rwkv_ctx *c)
+{
+    int rc = 0;
+    if (c->g_fwd) { (void)hipGraphExecDestroy(c->g_fwd); c->g_fwd = nullptr; rc = build_graph(c, false, &c->g_fwd); if (rc) { c->g_fwd = nullptr; return rc; } }
+    if (c->g_greedy) { (void)hipGraphExecDestroy(c->g_greedy); c->g_greedy = nullptr; rc = build_graph(c, true, &c->g_greedy); if (rc) { c->g_greedy = nullptr; return rc; } }
     return 0;
 }
 
@@ -608,6 +538,8 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         return fail(RWKV_E_ARG, "unsupported model shape n_layers=%llu n_embed=%llu (n_embed must be a multiple of 16, <= 5120)",
                     (unsigned long long)L, (unsigned long long)D);
     if (max_ctx == 0) max_ctx = 1;
+    if ((uint64_t)c->grid * 512 < D)      // every decode kernel hands a workgroup its share of the D channels in groups of <= 512
+        return fail(RWKV_E_ARG, "RWKV_GRID=%d is too small for n_embed=%llu (need >= %llu workgroups)", c->grid, (unsigned long long)D, (unsigned long long)((D + 511) / 512));
     HIPCHK(hipSetDevice(c->device));
     c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
     if (c->ring < 0) c->ring = (c->S == 3 || c->S == 4) ? 13 : (c->S == 5 ? 5 : 0);
@@ -812,7 +744,6 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     HIPCHK(hipStreamSynchronize(c->stream));
     if ((rc = set_smem_limits(c))) return rc;
     if (c->seq_ok && (rc = seq_smem_limits())) return rc;
-    if ((rc = mega_setup(c))) return rc;
     const char *nograph = getenv("RWKV_NO_GRAPH");
     if (!(nograph && nograph[0] == '1')) {
         if ((rc = build_graph(c, false, &c->g_fwd))) return rc;
@@ -1040,6 +971,15 @@ int rwkv_create(rwkv_ctx **out, int device)
     if (c->grid > NT / 2) c->grid = NT / 2;   // consumers sum one partial per thread of the prologue waves (half the workgroup)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(RWKV_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    void *dp = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->herr), 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, c->herr, 0) != hipSuccess) {
+        if (c->herr) (void)hipHostFree(c->herr);
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(RWKV_E_DEVICE, "cannot map the device error word");
+    }
+    *c->herr = 0u;
+    c->d_herr = static_cast<unsigned *>(dp);
     *out = c;
     return 0;
 }
@@ -1151,7 +1091,7 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
 
 int rwkv_stage_forward(rwkv_ctx *c, uint64_t token, uint32_t slot, uint64_t *pick)
@@ -1168,7 +1108,7 @@ int rwkv_stage_forward(rwkv_ctx *c, uint64_t token, uint32_t slot, uint64_t *pic
     if (rc) return rc;
     if (last && pick) HIPCHK(hipMemcpyAsync(pick, c->gen, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
 
 double *rwkv_x_device(rwkv_ctx *c) { return c ? c->x : nullptr; }
@@ -1185,7 +1125,7 @@ int rwkv_set_state(rwkv_ctx *c, const double *xy, const double *aa, const double
     for (int s = 0; s < 5; s++)
         if (h[s]) HIPCHK(hipMemcpyAsync(c->state[s], h[s], bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
 
 int rwkv_get_output(rwkv_ctx *c, float *logits, double *xy, double *aa, double *bb, double *pp, double *dd,
@@ -1201,7 +1141,7 @@ int rwkv_get_output(rwkv_ctx *c, float *logits, double *xy, double *aa, double *
     for (int s = 0; s < 5; s++)
         if (h[s]) HIPCHK(hipMemcpyAsync(h[s], c->state[s], bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
 
 int rwkv_reset_state(rwkv_ctx *c)
@@ -1212,7 +1152,7 @@ int rwkv_reset_state(rwkv_ctx *c)
     for (int s = 0; s < 5; s++)
         HIPCHK(hipMemsetAsync(c->state[s], 0, c->maxT * c->L * c->D * sizeof(double), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
 
 int rwkv_decode_greedy(rwkv_ctx *c, uint64_t first_token, uint64_t n, uint64_t *out_tokens)
@@ -1231,7 +1171,7 @@ int rwkv_decode_greedy(rwkv_ctx *c, uint64_t first_token, uint64_t n, uint64_t *
     }
     HIPCHK(hipMemcpyAsync(out_tokens, c->gen, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
 
 namespace {
@@ -1267,7 +1207,7 @@ int rwkv_sample_typical(rwkv_ctx *c, uint64_t row, float temp, float tau, double
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(token, c->pick, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
 
 int rwkv_decode_typical(rwkv_ctx *c, uint64_t first_token, uint64_t n, float temp, float tau, uint64_t seed, int flags, uint64_t *out_tokens)
@@ -1288,7 +1228,7 @@ int rwkv_decode_typical(rwkv_ctx *c, uint64_t first_token, uint64_t n, float tem
     }
     HIPCHK(hipMemcpyAsync(out_tokens, c->gen, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
 
 void rwkv_free(rwkv_ctx *c)
@@ -1296,9 +1236,9 @@ void rwkv_free(rwkv_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    rwkv_pipe_free(c);
-    if (c->g_fwd) (void)hipGraphExecDestroy(c->g_fwd);
-    if (c->g_greedy) (void)hipGraphExecDestroy(c->g_greedy);
+    if (c->g_fwd) { (void)hipGraphExecDestroy(c->g_fwd); c->g_fwd = nullptr; }
+    if (c->g_greedy) { (void)hipGraphExecDestroy(c->g_greedy); c->g_greedy = nullptr; }
+    rwkv_pipe_free(c);        // (no graphs left to re-capture)
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->herr) (void)hipHostFree(c->herr);
@@ -1315,6 +1255,8 @@ void rwkv_free(rwkv_ctx *c)
 float *rwkv_logits_device(rwkv_ctx *c) { return c ? c->logits : nullptr; }
 double *rwkv_state_device(rwkv_ctx *c, int which) { return (c && which >= 0 && which < 5) ? c->state[which] : nullptr; }
 void *rwkv_stream(rwkv_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int rwkv_abi_version(void) { return RWKV_MI355X_ABI_VERSION; }
+uint64_t rwkv_resident_bytes(const rwkv_ctx *c) { return c ? (uint64_t)c->alloc_bytes : 0; }
 
 uint64_t rwkv_bytes_per_token(const rwkv_ctx *c)
 {
@@ -1398,7 +1340,7 @@ int rwkv_profile_batched(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint
     for (int st = 0; st < 5; st++)
         HIPCHK(hipMemsetAsync(c->state[st], 0, c->maxT * c->L * c->D * sizeof(double), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
 
 // debug: run one eager token with the phase timeline of the middle layer's ffn_rk kernel enabled;
@@ -1421,34 +1363,8 @@ int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, ui
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, c->tl, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
-
-// debug: one eager k_token launch with its timeline enabled; out receives grid * phases * 8 stamps of the 100 MHz wall
-// clock ([workgroup][phase][slot], slots in mega.hip.h mg_stamp callers); *phases = 1 + 4 layers (+ 1 with the head)
-int rwkv_debug_mega_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, uint64_t cap, uint32_t *phases)
-{
-    if (!c || !out) return fail(RWKV_E_ARG, "NULL argument");
-    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
-    if (!c->mega_on) return fail(RWKV_E_STATE, "the one-launch token is off for this context");
-    const uint32_t nq = (uint32_t)(1 + 4 * (c->l1 - c->l0) + (c->l1 == c->L ? 1 : 0));
-    const size_t n = (size_t)c->grid * nq * MG_TL;
-    if (phases) *phases = nq;
-    if (cap < n) return fail(RWKV_E_ARG, "need room for %zu stamps", n);
-    HIPCHK(hipSetDevice(c->device));
-    if (!c->mtl) { int rc = dalloc(c, &c->mtl, n); if (rc) return rc; }
-    HIPCHK(hipMemsetAsync(c->mtl, 0, n * 8, c->stream));
-    c->h_ctl[0].token = token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
-    HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
-    launch_token(c, false, c->mtl);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, c->mtl, n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
-}
-
-// 1 when tokens of this context run as one launch (mega.hip.h), 0 when as 4 launches per layer
-int rwkv_one_launch(const rwkv_ctx *c) { return c && c->mega_on ? 1 : 0; }
 
 int rwkv_mm8_one(rwkv_ctx *c, uint64_t N, uint64_t M, const float *x, const uint8_t *w, const float *r,
                  const float *o, float *y)
@@ -1563,11 +1479,21 @@ int rwkv_pipe_init(rwkv_ctx *c, const void *id128, int rank, int world)
     int r = p->CommInitRank(&p->comm, world, id, rank);
     if (r != 0) { rc = pipe_fail(p, r, "ncclCommInitRank"); delete p; return rc; }
     p->rank = rank; p->world = world;
+    // every failure from here on gives the communicator back and leaves the context as it was (hop read from c->x)
+    auto undo = [&](int code) {
+        if (p->CommDestroy) (void)p->CommDestroy(p->comm);
+        delete p;
+        c->x_in = nullptr;
+        return code;
+    };
     if (rank > 0) {
-        if ((rc = dalloc(c, &c->x_in, c->D))) { delete p; return rc; }
+        if ((rc = dalloc(c, &c->x_in, c->D))) return undo(rc);
         // the stage graphs captured at load time read the hop from c->x: rebuild them around x_in
-        if (c->g_fwd) { (void)hipGraphExecDestroy(c->g_fwd); c->g_fwd = nullptr; if ((rc = build_graph(c, false, &c->g_fwd))) return rc; }
-        if (c->g_greedy) { (void)hipGraphExecDestroy(c->g_greedy); c->g_greedy = nullptr; if ((rc = build_graph(c, true, &c->g_greedy))) return rc; }
+        if ((rc = rebuild_graphs(c))) {
+            c->x_in = nullptr;
+            (void)rebuild_graphs(c);          // back to the graphs that read c->x (on failure: no graphs, eager launches)
+            return undo(rc);
+        }
     }
     c->pipe = p;
     return 0;
@@ -1591,14 +1517,21 @@ int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps
     if ((uint64_t)S > c->maxT) return fail(RWKV_E_ARG, "needs max_ctx >= %d state slots (one per stream in flight)", S);
     if (rank == 0 && !first_tokens) return fail(RWKV_E_ARG, "rank 0 needs first_tokens");
     if (lastr && !picks) return fail(RWKV_E_ARG, "the last rank needs picks");
+    // A bad id must not strand the other ranks in their ncclRecv: rank 0 runs the schedule with id 0 in its place and reports
+    // the error when the schedule has drained (the argument checks above depend only on values every rank shares).
+    bool bad_id = false;
     if (rank == 0)
-        for (int k = 0; k < S; k++) if (first_tokens[k] >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
+        for (int k = 0; k < S; k++) bad_id = bad_id || first_tokens[k] >= RWKV_VOCAB;
     HIPCHK(hipSetDevice(c->device));
-    Ctl *ring = nullptr;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ring), sizeof(Ctl) * n_items, hipHostMallocDefault));
+    if (c->pipe_ring_cap < n_items) {
+        if (c->pipe_ring) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->pipe_ring); c->pipe_ring = nullptr; c->pipe_ring_cap = 0; }
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->pipe_ring), sizeof(Ctl) * n_items, hipHostMallocDefault));
+        c->pipe_ring_cap = n_items;
+    }
+    Ctl *ring = c->pipe_ring;
     for (uint64_t j = 0; j < n_items; j++) {
         const uint64_t stream = j % S, step = j / S;
-        ring[j].token = (rank == 0 && step == 0) ? first_tokens[stream] : 0;
+        ring[j].token = (rank == 0 && step == 0) ? (first_tokens[stream] < RWKV_VOCAB ? first_tokens[stream] : 0) : 0;
         ring[j].slot = (unsigned)stream; ring[j].out_row = (unsigned)stream; ring[j].step = (unsigned)j; ring[j].pad = 0;
     }
     auto has_work = [&](int r, uint64_t t) { return t >= (uint64_t)r && t - r < n_items; };
@@ -1629,7 +1562,8 @@ int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps
         if (hipMemcpy(g.data(), c->gen, n_items * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RWKV_E_DEVICE, "copy of the picks failed");
         else for (uint64_t j = 0; j < n_items; j++) picks[(j % S) * n_steps + j / S] = g[j];
     }
-    (void)hipHostFree(ring);
+    if (!rc) rc = device_check(c);
+    if (!rc && bad_id) rc = fail(RWKV_E_ARG, "token id out of range (the schedule ran with id 0 in its place)");
     return rc;
 }
 
@@ -1656,7 +1590,7 @@ int rwkv_sync(rwkv_ctx *c)
     if (!c) return fail(RWKV_E_ARG, "NULL ctx");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    return device_check(c);
 }
 // hand a chunk's residual stream from one stage context to the next ON THE SAME DEVICE (virtual stages: tests, and
 // several stages per GPU); ordered behind src's work, and dst's later work is ordered behind the copy
@@ -1682,8 +1616,9 @@ int rwkv_xseq_copy(rwkv_ctx *dst, int dbuf, rwkv_ctx *src, int sbuf, uint64_t ro
 // Pipelined prompt ingestion (RWKV::loadContext, rwkv.h:395-413, across the stages): the prompt's 32-token chunks are
 // micro-batches, rank r works on chunk t - r at tick t.  Per tick: ONE RCCL group { send the finished chunk's residual
 // stream [rows][D] to r+1 | recv the next chunk's from r-1 into the other buffer }, then the chunk through this stage's
-// layers.  tokens: the whole prompt (read on rank 0; other ranks only need n_tokens).  Logits of every position land in
-// the last stage's logits buffer, rows (position % max_ctx); returns after the stage's stream has drained.
+// layers.  tokens: the whole prompt (read on rank 0; other ranks only need n_tokens).  Every chunk writes its logits to rows
+// [0, rows) of the last stage's logits buffer (position % 32): after the call the buffer holds the LAST chunk's rows, which is
+// what RWKV::loadContext's caller reads; returns after the stage's stream has drained.
 int rwkv_pipe_prefill(rwkv_ctx *c, const uint64_t *tokens, uint64_t n_tokens)
 {
     if (!c) return fail(RWKV_E_ARG, "NULL ctx");
@@ -1694,6 +1629,18 @@ int rwkv_pipe_prefill(rwkv_ctx *c, const uint64_t *tokens, uint64_t n_tokens)
     const int S = p->world, rank = p->rank;
     if (n_tokens == 0 || (rank == 0 && !tokens)) return fail(RWKV_E_ARG, "empty prompt");
     HIPCHK(hipSetDevice(c->device));
+    // k_seq_embed indexes the table with the id: validate the whole prompt on rank 0.  A bad id must not strand the other ranks in
+    // their ncclRecv, so the schedule runs with id 0 in its place and the error is reported once it has drained.
+    std::vector<uint64_t> clean;
+    bool bad_id = false;
+    if (rank == 0) {
+        for (uint64_t t = 0; t < n_tokens; t++) bad_id = bad_id || tokens[t] >= RWKV_VOCAB;
+        if (bad_id) {
+            clean.assign(tokens, tokens + n_tokens);
+            for (auto &t : clean) if (t >= RWKV_VOCAB) t = 0;
+            tokens = clean.data();
+        }
+    }
     const uint64_t n_chunks = (n_tokens + SEQ_T - 1) / SEQ_T;
     auto rows_of = [&](uint64_t ci) { return ci + 1 < n_chunks ? (uint64_t)SEQ_T : n_tokens - ci * SEQ_T; };
     auto has_work = [&](int r, uint64_t t) { return t >= (uint64_t)r && t - r < n_chunks; };
@@ -1712,15 +1659,21 @@ int rwkv_pipe_prefill(rwkv_ctx *c, const uint64_t *tokens, uint64_t n_tokens)
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (!rc && e != hipSuccess) rc = fail(RWKV_E_DEVICE, "pipeline prefill: %s", hipGetErrorString(e));
+    if (!rc && bad_id) rc = fail(RWKV_E_ARG, "token id out of range (the schedule ran with id 0 in its place)");
     return rc;
 }
 
 void rwkv_pipe_free(rwkv_ctx *c)
 {
     if (!c || !c->pipe) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->pipe->comm && c->pipe->CommDestroy) (void)c->pipe->CommDestroy(c->pipe->comm);
     delete c->pipe;
     c->pipe = nullptr;
+    if (c->pipe_ring) { (void)hipHostFree(c->pipe_ring); c->pipe_ring = nullptr; c->pipe_ring_cap = 0; }
+    // a later rank read the hop from x_in: any other transport (rwkv_stage_forward callers write rwkv_x_device()) needs the
+    // graphs back on c->x, or it would compute on a stale x_in
+    if (c->x_in) { c->x_in = nullptr; (void)rebuild_graphs(c); }
 }
 
 // Device pointer behind tensor slot `slot` of the reference's `tensors[]` table (rwkv.h:248, enums/enum.h:7-55) where the

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("RWKV_LIB") or os.path.join(_HERE, "csrc", "librwkv_mi
 MODE_PARRALEL, MODE_GPT = 0, 1   # reference enums/enum.h:2-5
 SAMPLE_BAN0, SAMPLE_RECIPE = 1, 2   # include/rwkv_mi355x.h
 N_KCLASS = 7
+ABI_VERSION = 3                   # RWKV_MI355X_ABI_VERSION of include/rwkv_mi355x.h
 KCLASS_NAMES = ["first", "att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head", "argmax"]
 
 # every entry point declared in include/rwkv_mi355x.h (tests check the library exports all of them)
@@ -26,7 +27,7 @@ ABI_SYMBOLS = [
     "rwkv_create", "rwkv_load_file", "rwkv_load_tensors", "rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx",
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
-    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_debug_mega_timeline", "rwkv_one_launch", "rwkv_profile_batched", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
+    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
     "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode",
     "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device",
 ]
@@ -70,8 +71,10 @@ def lib():
     L.rwkv_x_device.argtypes = [vp]; L.rwkv_x_device.restype = vp
     L.rwkv_profile_batched.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]; L.rwkv_profile_batched.restype = i32
     L.rwkv_debug_timeline.argtypes = [vp, u64, vp, u64]; L.rwkv_debug_timeline.restype = i32
-    L.rwkv_debug_mega_timeline.argtypes = [vp, u64, vp, u64, vp]; L.rwkv_debug_mega_timeline.restype = i32
-    L.rwkv_one_launch.argtypes = [vp]; L.rwkv_one_launch.restype = i32
+    L.rwkv_abi_version.argtypes = []; L.rwkv_abi_version.restype = i32
+    L.rwkv_resident_bytes.argtypes = [vp]; L.rwkv_resident_bytes.restype = u64
+    if L.rwkv_abi_version() != ABI_VERSION:
+        raise RWKVError(f"{LIB_PATH} has C-ABI version {L.rwkv_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
     L.rwkv_sample_typical.argtypes = [vp, u64, C.c_float, C.c_float, C.c_double, i32, C.POINTER(u64)]; L.rwkv_sample_typical.restype = i32
     L.rwkv_decode_typical.argtypes = [vp, u64, u64, C.c_float, C.c_float, u64, i32, C.POINTER(u64)]; L.rwkv_decode_typical.restype = i32
     L.rwkv_stage_chunk.argtypes = [vp, C.POINTER(u64), u64, u64, i32]; L.rwkv_stage_chunk.restype = i32
@@ -343,15 +346,8 @@ class RWKV:
         _chk(lib().rwkv_debug_timeline(self._h, token, _ptr(buf), buf.size))
         return buf
 
-    def mega_timeline(self, token: int = 1, grid: int = 256):
-        """stamps of one eager one-launch token: uint64 [workgroup][phase][8] (100 MHz wall clock; 0 = not stamped)"""
-        nq = C.c_uint32(0)
-        buf = np.zeros(grid * (4 * 64 + 2) * 8, dtype=np.uint64)
-        _chk(lib().rwkv_debug_mega_timeline(self._h, token, _ptr(buf), buf.size, C.byref(nq)))
-        return buf[: grid * nq.value * 8].reshape(grid, nq.value, 8)
-
-    def one_launch(self) -> bool:
-        return bool(lib().rwkv_one_launch(self._h))
+    def resident_bytes(self) -> int:
+        return int(lib().rwkv_resident_bytes(self._h))
 
     def stream(self) -> int:
         return int(lib().rwkv_stream(self._h) or 0)

@@ -27,7 +27,7 @@ def test_cpp_header_compiles_and_links(app):
 
 
 def test_pybind_module_surface(built):
-    """same 8 model functions as bindings/pybind/c_binding.cpp:158-175 (tokenizer entry points stay with the app)"""
+    """all 11 names of bindings/pybind/c_binding.cpp:158-175: the 8 model functions and the 3 tokenizer forwards"""
     assert built["pybind"], "pybind module not built"
     sys.path.insert(0, CSRC)
     import rwkv

@@ -36,6 +36,22 @@ def test_reference_storygen_builds_against_the_dropin(built, exe):
 
 
 @needs_ref
+@pytest.mark.parametrize("exe", ["vectordb_mi355x", "vectordb_l2", "terminalchat_mi355x", "terminalchat_l2", "two_models_mi355x", "two_models_l2"])
+def test_the_other_reference_callers_build_against_the_dropin(built, exe):
+    """reference examples/vectordb/vectordb.cpp (the only user of loadFile(.., 5), emptyState(), raw state->statedd,
+    vectordb.cpp:15-59) and examples/terminalchat/chat.cpp (chat.cpp:50-85), from where they lie, at both boundary levels; and
+    the two-models test program (tests/cpp/two_models_app.cpp).  oracle/Makefile target `callers`."""
+    p = os.path.join(ROOT, "oracle", "_ref", exe)
+    assert os.path.exists(p), "oracle/Makefile did not produce it"
+    out = subprocess.run(["ldd", p], capture_output=True, text=True).stdout
+    assert "librwkv_mi355x.so" in out and "cuda" not in out.lower()
+    assert "not found" not in out, out
+    syms = subprocess.run(["nm", "-D", "--undefined-only", p], capture_output=True, text=True).stdout
+    for s in ("rwkv_load_file", "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_free"):
+        assert s in syms, s
+
+
+@needs_ref
 def test_backend_tu_defines_every_prototype_of_the_reference_header(built, tmp_path):
     """integration/rwkv_backend_mi355x.cpp vs the declarations in the reference's rwkv.h:63-122: a TU that includes the
     reference header and takes the address of each declared function with its exact type must link against it"""

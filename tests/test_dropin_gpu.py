@@ -146,3 +146,113 @@ def test_reference_storygen_runs_on_the_engine(world, exe):
     assert probs.min() > 1e-9, f"id {got[int(probs.argmin())]} at step {int(probs.argmin())} has probability {probs.min():.2e} under the engine's logits"
     assert top.mean() > 0.7, f"only {top.mean():.2f} of the sampled ids are the argmax of peaked logits"
     assert len(set(got)) > 20
+
+
+def _run_interactive(binp, cwd, stdin_line, until, timeout=240):
+    p = subprocess.Popen([binp], cwd=cwd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, RWKV_SAMPLER_SEED="1"))
+    p.stdin.write((stdin_line + "\n").encode()); p.stdin.flush()
+    buf, t0 = b"", time.time()
+    os.set_blocking(p.stdout.fileno(), False)
+    try:
+        while not until(buf) and time.time() - t0 < timeout and p.poll() is None:
+            chunk = p.stdout.read()
+            if chunk:
+                buf += chunk
+            else:
+                time.sleep(0.05)
+    finally:
+        p.kill(); p.wait()
+    return buf, p.stderr.read()
+
+
+@pytest.fixture(scope="module")
+def flat_world(built, tmp_path_factory):
+    """vectordb / terminalchat look for ./vocab/{vocab.json,merges.txt} and ./model.bin in the working directory"""
+    root = tmp_path_factory.mktemp("callers")
+    write_vocab(str(root / "vocab"))
+    L, D = 4, 768
+    t = mf.synthetic_tensors(L, D, seed=170, head_scale=120.0)
+    mf.write_bin(str(root / "model.bin"), L, D, t)
+    return dict(cwd=str(root), model=str(root / "model.bin"), L=L, D=D)
+
+
+@pytest.mark.parametrize("exe", ["vectordb_mi355x", "vectordb_l2"])
+def test_reference_vectordb_runs_on_the_engine(flat_world, exe):
+    """RUN reference examples/vectordb/vectordb.cpp (vectordb.cpp:15-59: loadFile("./model.bin", 5), emptyState(), loadContext per
+    fact in 5-token GPT chunks, getSubState / setSubState, then the distances between raw state->statedd arrays) and recompute
+    the distances it prints with the Python engine along the same call sequence."""
+    binp = os.path.join(ROOT, "oracle", "_ref", exe)
+    if not os.path.exists(binp):
+        pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference at build time)")
+    question = "Who is Alice"
+    facts = ["Alice is a person", "Nvidia is a company", "The grand canyon is a place"]     # vectordb.cpp:21-25
+    buf, err = _run_interactive(binp, flat_world["cwd"], question, lambda b: b.count(b"Diff: ") >= 3 and b.rstrip().endswith(b"Question:>"))
+    assert b"Loaded model" in buf and buf.count(b"Diff: ") >= 3, (buf[-600:], err[-400:])
+    got = [(float(a), float(b)) for a, b in re.findall(rb"Diff: '[^']*' is ([-+0-9.eE]+|nan|inf):([-+0-9.eE]+|nan|inf)", buf)][:3]
+    from rwkv_cpp_accelerated_amd import engine
+    m = engine.RWKV(resident=False)
+    m.loadFile(flat_world["model"], 5)
+    n = flat_world["L"] * flat_world["D"]
+
+    def load_context(text):                       # RWKV::loadContext, rwkv.h:395-413: chunks of maxContext tokens, GPT mode
+        ids = encode(text)
+        for i in range(0, len(ids), 5):
+            m.forward(ids[i:i + 5], engine.MODE_GPT)
+        dd = m.state.statedd[:n].copy()
+        for a in m.state.arrays():                # Rwkv.state->setSubState(emptyState)
+            a[:n] = 0
+        return dd
+    fact_dd = [load_context(f) for f in facts]
+    q = load_context(question)
+    for (gd, ge), dd in zip(got, fact_dd):
+        diff = float(np.sum(np.abs(dd - q).astype(np.float32) / np.float32(flat_world["D"]), dtype=np.float32))      # float accumulation, vectordb.cpp:47-55
+        eu = float(np.sqrt(np.sum(((dd - q) ** 2).astype(np.float32) / np.float32(flat_world["D"]), dtype=np.float32)))
+        assert abs(gd - diff) <= 2e-3 * max(1.0, abs(diff)), (gd, diff)
+        assert abs(ge - eu) <= 2e-3 * max(1.0, abs(eu)), (ge, eu)
+    assert len({round(g[0], 3) for g in got}) == 3, "the three facts must be at three different distances"
+    m.close()
+
+
+@pytest.mark.parametrize("exe", ["terminalchat_mi355x", "terminalchat_l2"])
+def test_reference_terminalchat_starts_on_the_engine(flat_world, exe):
+    """reference examples/terminalchat/chat.cpp: loads ./model.bin, ingests its built-in chat record token by token, prompts,
+    takes one user line and starts to answer (typical sampling; an endless loop: killed once it has printed something)"""
+    binp = os.path.join(ROOT, "oracle", "_ref", exe)
+    if not os.path.exists(binp):
+        pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference at build time)")
+    buf, err = _run_interactive(binp, flat_world["cwd"], "hello", lambda b: b"User:>" in b and len(b.split(b"User:>", 1)[1]) > 24)
+    assert b"Loaded model" in buf and b"User:>" in buf, (buf[-400:], err[-400:])
+    tail = buf.split(b"User:>", 1)[1]
+    assert len(decode_stream(tail)) >= 8, tail[:80]
+
+
+@pytest.mark.parametrize("exe", ["two_models_mi355x", "two_models_l2"])
+def test_two_models_in_one_process(built, tmp_path, exe):
+    """every RWKV owns its tensors[] (rwkv.h:248,288; c_binding.cpp:28-33 hands out one per initRwkv): two models loaded side by
+    side through the drop-in header (level 1) and through the reference's own header + backend TU (level 2, the engine handle
+    travels in tensors[X] / tensors[STATEXY]); interleaved greedy decode, then one model is destroyed and the other goes on"""
+    binp = os.path.join(ROOT, "oracle", "_ref", exe)
+    if not os.path.exists(binp):
+        pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference at build time)")
+    from rwkv_cpp_accelerated_amd import engine
+    shapes = [(2, 768, 41), (3, 1024, 42)]
+    paths = []
+    for L, D, seed in shapes:
+        p = str(tmp_path / f"m{seed}.bin")
+        mf.write_bin(p, L, D, mf.synthetic_tensors(L, D, seed=seed))
+        paths.append(p)
+    n = 10
+    out = subprocess.run([binp, paths[0], paths[1], str(n)], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-400:] + out.stderr[-400:]
+    lines = [l for l in out.stdout.splitlines() if l.strip() and not l.startswith(("n_layers", "n_embed"))]
+    ia, ib, ic = ([int(x) for x in l.split()] for l in lines[-4:-1])
+    assert lines[-1].split() == ["layers", "3", "1024"]
+    want = []
+    for (L, D, seed), p, steps in zip(shapes, paths, (n, 2 * n)):
+        m = engine.RWKV(resident=True); m.loadFile(p, 1)
+        tk, ids = 11, []
+        for _ in range(steps):
+            tk = parity.argmax_ban0(m.forward(tk)[: mf.VOCAB]); ids.append(tk)
+        want.append(ids)
+        m.close()
+    assert ia == want[0] and ib + ic == want[1]

@@ -1,7 +1,7 @@
 // dmabench2.hip -- the one-launch token's REAL loader and consumer group loop (csrc/mega.hip.h: MegaLoader, mg_groups) streaming the
 // weights of NL synthetic 7B-shaped layers, with the prologue / hand-off replaced by LDS counter bumps: what the ring protocol
 // itself sustains, phase after phase, without any chip-wide synchronisation.  Build with the same -DRWKV_MG_* knobs as the engine.
-#include "../rwkv-cpp-accelerated_amd/csrc/mega.hip.h"
+#include "mega.hip.h"
 #include <cstdio>
 #include <cstdlib>
 using namespace rwkvk;

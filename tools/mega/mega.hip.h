@@ -21,7 +21,7 @@
 // All 256 workgroups must be co-resident: grid <= compute units, one workgroup per CU (the LDS footprint guarantees it).
 // Numerics are those of the launch kernels (same staging, same integer dot products, same epilogues, same tuple order).
 #pragma once
-#include "kernels.hip.h"
+#include "../../rwkv-cpp-accelerated_amd/csrc/kernels.hip.h"
 
 namespace rwkvk {
 
