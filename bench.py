@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--profile-reps", type=int, default=16)
     ap.add_argument("--long-prompt", type=int, default=512, help="tokens of the one-call prompt of the prefill report (0 = skip)")
     ap.add_argument("--prefill-chunks", type=int, default=4, help="32-token prompt chunks timed for the prefill report (0 = skip)")
+    ap.add_argument("--config2-steps", type=int, default=256, help="greedy steps of the 1B5 leg (BASELINE config 2) reported beside the 7B headline; 0 = skip")
     ap.add_argument("--parallel", choices=["pipeline", "replicas"], default=os.environ.get("RWKV_BENCH_PARALLEL", "pipeline"),
                     help="N > 1: layer pipeline over RCCL send/recv with N streams in flight (default), or N independent replicas")
     args = ap.parse_args()
@@ -155,13 +156,18 @@ def main():
                 method="algorithmic uint8 weight bytes of one launch / average launch duration; duration = one hipEvent pair "
                        "around a batch of back-to-back launches of the kernel (all layers x reps) on the engine stream, "
                        "right after the timed region; `traffic` is NOT a counter of this run: it is the committed figure of the "
-                       "separate rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction) in profiles/hbm_traffic.json")
-    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # filled from rocprofv3 --pmc passes (see profiles/)
-    if os.path.exists(traffic_file):
-        try:
-            roof["traffic"] = json.load(open(traffic_file)).get(args.model, {}).get(dom)
-        except Exception:
-            pass
+                       "separate rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), see traffic_source")
+    # `traffic`: HBM read bytes per launch of the dominant kernel from the round's own rocprofv3 --pmc FETCH_SIZE pass
+    # (tools/gpu_round.sh writes profiles/<round>/hbm_traffic.json together with the sha256 of the kernel source it profiled);
+    # a figure collected for ANOTHER kernels.hip.h is not quoted
+    roof.update(traffic_lookup(args.model, dom))
+    # the north_star's target is stated per mm8_one shape: every weight-streaming kernel of the token with the reference
+    # mm8 calls it absorbs (rwkv.cu:267-311 / :58-142), algorithmic uint8 bytes, launch duration, GB/s, fraction of 8 TB/s
+    absorbs = dict(att_kvr_wkv="kernel_mm8_threec K+V+R (3 x D->D)", att_out="mm8_one att_out D->D", ffn_rk="mm8_one ffn_k D->4D + ffn_r D->D",
+                   ffn_v="mm8_one<float> ffn_v 4D->D", head="mm8_one head D->V")
+    shapes = [dict(kernel=k, reference_calls=absorbs[k], bytes=per_launch[k]["bytes"], us=round(per_launch[k]["us"], 3),
+                   GBps=round(per_launch[k]["gbps"], 1), frac_of_8TBps=round(per_launch[k]["gbps"] / HBM_PEAK_GBPS, 4),
+                   launches_per_token=per_launch[k]["launches_per_token"]) for k in absorbs if k in per_launch]
 
     line = dict(
         metric="tokens/sec single-stream RWKV-4 uint8 greedy decode",
@@ -174,11 +180,16 @@ def main():
                     parallelism=("1 GPU" if world == 1 else f"{world} independent replicas, one stream per GPU (replicas only)"),
                     launches_per_token=4 * L + 3, bytes_per_token=B_tok),
         roofline=roof,
+        mm8_one_shapes=shapes,
         end_to_end=dict(achieved_GBps=round(B_tok * tok_s / world / 1e9, 1),
                         frac_of_8TBps=round(B_tok * tok_s / world / 1e9 / HBM_PEAK_GBPS, 4)),
         kernels={k: dict(us=round(v["us"], 3), GBps=round(v["gbps"], 1), us_event_pair=round(v["us_event_pair"], 3))
                  for k, v in per_launch.items()},
         load_s=round(load_s, 2),
+        hbm_resident_bytes=dict(total=m.resident_bytes(),
+                                note="device bytes of this context: decode-layout weights + embedding + state + scratch"
+                                     + (", plus the SECOND copy of the matrices in the MFMA B-operand image of the chunk path "
+                                        f"(13*L*D^2 + V*D = {13 * L * D * D + mf.VOCAB * D} bytes; loaded because max_ctx > 1)" if args.prefill_chunks > 0 else "")),
     )
 
     if drop_in is not None:
@@ -255,6 +266,10 @@ def main():
             dtm = (time.perf_counter() - t0) / args.prefill_chunks
             line["batched_decode"]["streams_96"] = dict(ms_per_step=round(dtm * 1e3, 3), aggregate_tokens_per_s=round(len(many) / dtm, 1),
                                                         note="three 32-row passes per step as a software pipeline over the stages (RWKV_SEQ_STAGES)")
+
+    # ---- BASELINE config 2 beside the headline: RWKV-4-Raven-1B5 single-stream decode on the same GPU ----
+    if rank == 0 and args.model == "7B" and args.config2_steps > 0:
+        line["config2_1B5"] = small_model_leg(mf, engine, "1B5", args.config2_steps, local_rank, dev)
 
     # ---- the reference's OWN kernel on this GPU, same tensors, same prompt: parity gate + baseline ----
     if rank == 0 and args.ref_steps > 0:
@@ -404,6 +419,60 @@ def ref_kernel_leg(mf, tensors, L, D, prompt, engine_model, steps, budget_s, B_t
                                         first_divergence=g["first_divergence"], steps_outside_tolerance=g["steps_outside_tolerance"],
                                         tolerance=1e-3, note="engine teacher-forced with the reference kernel's greedy ids; logits compared at every step "
                                                              "(max|d| <= 1e-3 max|ref| and |d| <= 1e-3|ref| + 1e-3 rms)"))
+
+
+def traffic_lookup(model, kernel):
+    """HBM bytes per launch of `kernel` from the newest profiles/rNN/hbm_traffic.json whose recorded kernel-source digest matches
+    the kernels.hip.h in the tree (tools/gpu_round.sh records it); {traffic: None, traffic_source: why} otherwise."""
+    import glob
+    import hashlib
+    src = os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", "kernels.hip.h")
+    digest = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    stale = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        rel = os.path.relpath(f, ROOT)
+        if d.get("kernels_hip_h_sha256") != digest:
+            stale.append(rel)
+            continue
+        v = d.get(model, {}).get(kernel)
+        if v is not None:
+            return dict(traffic=v, traffic_source=f"{rel} (rocprofv3 --pmc FETCH_SIZE x 2, per launch; same kernels.hip.h as this run)")
+    return dict(traffic=None, traffic_source="no PMC pass on record for this kernels.hip.h" + (f" (stale: {', '.join(stale[:2])})" if stale else ""))
+
+
+def small_model_leg(mf, engine, name, steps, device, dev):
+    """BASELINE config 2 (RWKV-4-Raven-1B5 uint8 single-stream decode, 1 GPU): same measurement as the headline on a second
+    context -- greedy decode after a 32-token prompt, per-kernel batched-event durations, fraction of the HBM roofline."""
+    import numpy as np
+    import torch
+    L, D = mf.SHAPES[name]
+    t = mf.synthetic_tensors_torch(L, D, seed=2, device=dev)
+    torch.cuda.synchronize()
+    m = engine.RWKV(device=device, resident=True)
+    m.loadTensors(L, D, t, maxGPT=1)
+    for tk in np.random.default_rng(1).integers(2, mf.VOCAB, 32):
+        m.forward(int(tk))
+    first = int(np.argmax(m.out[1:mf.VOCAB])) + 1
+    first = int(m.decode_greedy(first, 16)[-1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ids = m.decode_greedy(first, steps)
+    dt = time.perf_counter() - t0
+    B = m.bytes_per_token()
+    tps = steps / dt
+    by = {p["name"]: p["bytes_per_launch"] for p in m.profile_token(token=int(ids[-1]), reps=1)}
+    kern = {p["name"]: dict(us=round(p["us"], 3), GBps=round(by[p["name"]] / (p["us"] * 1e-6) / 1e9, 1) if p["us"] > 0 else 0.0)
+            for p in m.profile_batched(token=int(ids[-1]), reps=4) if by.get(p["name"], 0) > 0 and p["name"] != "first"}
+    m.close()
+    del t
+    torch.cuda.empty_cache()
+    return dict(workload=f"RWKV-4-Raven-{name} uint8 single-stream greedy decode (L={L}, D={D}), {steps} tokens", tokens_per_s=round(tps, 1),
+                ms_per_step=round(1e3 * dt / steps, 5), bytes_per_token=B, achieved_GBps=round(B * tps / 1e9, 1),
+                frac_of_8TBps=round(B * tps / 1e9 / HBM_PEAK_GBPS, 4), kernels=kern)
 
 
 def chunk_gate_leg(mf, tensors, L, D, prompt, engine_model):

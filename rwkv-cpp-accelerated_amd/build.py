@@ -116,8 +116,23 @@ def build_oracle(force: bool = False):
     return so, (ref_so if os.path.exists(ref_so) else None)
 
 
+def build_test_helpers(force: bool = False):
+    """tests/fake_rccl.cpp -> tests/_build/libfake_rccl.so: the eight librccl entry points the pipeline transport resolves, over
+    shared memory, so that the native schedule runs with world > 1 on a one-GPU box (RWKV_RCCL_LIB).  Test infrastructure."""
+    src = os.path.join(ROOT, "tests", "fake_rccl.cpp")
+    out = os.path.join(ROOT, "tests", "_build", "libfake_rccl.so")
+    if not os.path.exists(src):
+        return None
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if force or _stale(out, [src]):
+        _run([HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-x", "hip", f"--offload-arch={ARCH}", src, "-o", out, "-lrt", "-lpthread"])
+        _stamp(out, [src])
+    return out
+
+
 def build_all(force: bool = False):
     eng = build_engine(force)
     pyb = build_pybind(force)
     ora = build_oracle(force)
-    return dict(engine=eng, pybind=pyb, oracle=ora[0], ref=ora[1])
+    fake = build_test_helpers(force)
+    return dict(engine=eng, pybind=pyb, oracle=ora[0], ref=ora[1], fake_rccl=fake)

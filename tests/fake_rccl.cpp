@@ -1,0 +1,211 @@
+// fake_rccl.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// A stand-in for the eight librccl entry points the engine's layer-pipeline transport resolves with dlopen
+// (csrc/engine.hip pipe_open: ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclSend, ncclRecv, ncclGroupStart,
+// ncclGroupEnd, ncclGetErrorString), so that rwkv_pipe_decode / rwkv_pipe_prefill EXECUTE with world > 1 on a box with ONE
+// GPU: real RCCL refuses two ranks on one device, and a gpurun box has one.  Point RWKV_RCCL_LIB at the built library
+// (tests/_build/libfake_rccl.so, rwkv-cpp-accelerated_amd/build.py build_test_helpers); every rank is its own process.
+//
+// Transport: one POSIX shared-memory segment per communicator (its name travels in the 128-byte unique id), one channel per
+// (source, destination) pair: a ring of SLOTS staging slots with a produced / consumed sequence pair.  All of it STREAM
+// ORDERED like the real calls:
+//   send  = hipMemcpyAsync device -> slot (the segment is hipHostRegister'ed), then a host function that publishes the slot
+//   recv  = a host function that waits for the slot, hipMemcpyAsync slot -> device, then a host function that frees it
+// Inside ncclGroupStart / ncclGroupEnd the operations are queued and issued at GroupEnd, sends first -- a send never waits for
+// its peer unless SLOTS messages of that channel are unconsumed -- so a group that sends to one peer and receives from another
+// cannot deadlock, which is the property of an RCCL group the engine's tick relies on.
+// Bounded waits (30 s): a lost peer ends the test with an error instead of hanging the box.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+constexpr int SLOTS = 4;
+constexpr size_t SLOT_BYTES = 2u << 20;       // largest message: a 32-row chunk of the residual stream at D = 5120 (1.25 MiB)
+constexpr int MAX_RANKS = 8;
+constexpr int WAIT_MS = 30000;
+
+struct Channel {
+    std::atomic<uint64_t> produced, consumed;
+    uint64_t bytes[SLOTS];
+    char pad[64];
+};
+struct Segment {
+    std::atomic<uint32_t> joined, left;
+    uint32_t nranks;
+    char pad[52];
+    Channel ch[MAX_RANKS][MAX_RANKS];          // [src][dst]
+    // followed by the slots: [src][dst][SLOTS][SLOT_BYTES]
+};
+size_t seg_bytes(int n) { return sizeof(Segment) + (size_t)n * n * SLOTS * SLOT_BYTES; }
+
+struct Comm {
+    Segment *seg = nullptr;
+    size_t bytes = 0;
+    int rank = 0, nranks = 1;
+    std::string name;
+    uint64_t sent[MAX_RANKS] = {}, recvd[MAX_RANKS] = {};     // messages enqueued so far per peer
+    std::atomic<int> failed{0};
+    char *slot(int src, int dst, uint64_t seq) const
+    {
+        return reinterpret_cast<char *>(seg) + sizeof(Segment) + ((((size_t)src * nranks + dst) * SLOTS) + seq % SLOTS) * SLOT_BYTES;
+    }
+};
+
+struct Op { bool send; void *buf; size_t bytes; int peer; Comm *c; hipStream_t st; };
+thread_local int g_depth = 0;
+thread_local std::vector<Op> g_queue;
+
+struct Note { Comm *c; int src, dst; uint64_t seq; size_t bytes; int what; };   // what: 0 publish, 1 wait for data, 2 free, 3 wait for room
+
+bool wait_until(const std::atomic<uint64_t> &v, uint64_t least, Comm *c)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    while (v.load(std::memory_order_acquire) < least) {
+        if (c->failed.load()) return false;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(WAIT_MS)) {
+            fprintf(stderr, "[fake_rccl] rank %d: peer did not show up within %d ms\n", c->rank, WAIT_MS);
+            c->failed.store(1);
+            return false;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    return true;
+}
+void host_note(void *p)
+{
+    Note *n = static_cast<Note *>(p);
+    Channel &ch = n->c->seg->ch[n->src][n->dst];
+    switch (n->what) {
+    case 0: ch.bytes[n->seq % SLOTS] = n->bytes; ch.produced.store(n->seq + 1, std::memory_order_release); break;
+    case 1:
+        if (wait_until(ch.produced, n->seq + 1, n->c) && ch.bytes[n->seq % SLOTS] != n->bytes) {
+            fprintf(stderr, "[fake_rccl] rank %d: message %llu from %d has %llu bytes, receiver asked for %zu\n", n->c->rank,
+                    (unsigned long long)n->seq, n->src, (unsigned long long)ch.bytes[n->seq % SLOTS], n->bytes);
+            n->c->failed.store(1);
+        }
+        break;
+    case 2: ch.consumed.store(n->seq + 1, std::memory_order_release); break;
+    case 3: if (n->seq >= (uint64_t)SLOTS) wait_until(ch.consumed, n->seq - SLOTS + 1, n->c); break;
+    }
+    delete n;
+}
+int enqueue(const Op &o)
+{
+    Comm *c = o.c;
+    if (o.bytes > SLOT_BYTES || o.peer < 0 || o.peer >= c->nranks || o.peer == c->rank) return 4;   // ncclInvalidArgument
+    if (o.send) {
+        const uint64_t seq = c->sent[o.peer]++;
+        if (hipLaunchHostFunc(o.st, host_note, new Note{c, c->rank, o.peer, seq, o.bytes, 3}) != hipSuccess) return 1;
+        if (hipMemcpyAsync(c->slot(c->rank, o.peer, seq), o.buf, o.bytes, hipMemcpyDeviceToHost, o.st) != hipSuccess) return 1;
+        if (hipLaunchHostFunc(o.st, host_note, new Note{c, c->rank, o.peer, seq, o.bytes, 0}) != hipSuccess) return 1;
+    } else {
+        const uint64_t seq = c->recvd[o.peer]++;
+        if (hipLaunchHostFunc(o.st, host_note, new Note{c, o.peer, c->rank, seq, o.bytes, 1}) != hipSuccess) return 1;
+        if (hipMemcpyAsync(o.buf, c->slot(o.peer, c->rank, seq), o.bytes, hipMemcpyHostToDevice, o.st) != hipSuccess) return 1;
+        if (hipLaunchHostFunc(o.st, host_note, new Note{c, o.peer, c->rank, seq, o.bytes, 2}) != hipSuccess) return 1;
+    }
+    return c->failed.load() ? 2 : 0;
+}
+size_t type_bytes(int t)
+{
+    switch (t) { case 0: case 1: return 1; case 2: case 3: case 7: return 4; case 4: case 5: case 8: return 8; case 6: case 9: return 2; default: return 0; }
+}
+int submit(bool send, void *buf, size_t count, int type, int peer, void *comm, hipStream_t st)
+{
+    const size_t tb = type_bytes(type);
+    if (!comm || !buf || !tb) return 4;
+    Op o{send, buf, count * tb, peer, static_cast<Comm *>(comm), st};
+    if (g_depth > 0) { g_queue.push_back(o); return 0; }
+    return enqueue(o);
+}
+
+} // namespace
+
+extern "C" {
+
+struct ncclUniqueId { char internal[128]; };
+
+int ncclGetUniqueId(ncclUniqueId *id)
+{
+    static std::atomic<unsigned> counter{0};
+    memset(id->internal, 0, sizeof(id->internal));
+    snprintf(id->internal, sizeof(id->internal), "/fake_rccl_%d_%u_%llx", (int)getpid(), counter++,
+             (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+    return 0;
+}
+
+int ncclCommInitRank(void **comm, int nranks, ncclUniqueId id, int rank)
+{
+    if (!comm || nranks < 1 || nranks > MAX_RANKS || rank < 0 || rank >= nranks) return 4;
+    Comm *c = new Comm();
+    c->rank = rank; c->nranks = nranks; c->name.assign(id.internal, strnlen(id.internal, sizeof(id.internal)));
+    c->bytes = seg_bytes(nranks);
+    const int fd = shm_open(c->name.c_str(), O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) { if (fd >= 0) close(fd); delete c; return 2; }      // zero-filled by the kernel: all counters start at 0
+    void *p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { delete c; return 2; }
+    c->seg = static_cast<Segment *>(p);
+    if (hipHostRegister(p, c->bytes, hipHostRegisterPortable) != hipSuccess) { munmap(p, c->bytes); delete c; return 1; }
+    c->seg->nranks = (uint32_t)nranks;
+    c->seg->joined.fetch_add(1);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (c->seg->joined.load() < (uint32_t)nranks) {       // like the real call: returns once every rank has joined
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(WAIT_MS)) {
+            (void)hipHostUnregister(p); munmap(p, c->bytes); shm_unlink(c->name.c_str()); delete c;
+            return 2;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    *comm = c;
+    return 0;
+}
+
+int ncclCommDestroy(void *comm)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c) return 4;
+    (void)hipDeviceSynchronize();
+    const bool last = c->seg->left.fetch_add(1) + 1 == (uint32_t)c->nranks;
+    (void)hipHostUnregister(c->seg);
+    munmap(c->seg, c->bytes);
+    if (last) shm_unlink(c->name.c_str());
+    delete c;
+    return 0;
+}
+
+int ncclSend(const void *buf, size_t count, int type, int peer, void *comm, hipStream_t st) { return submit(true, const_cast<void *>(buf), count, type, peer, comm, st); }
+int ncclRecv(void *buf, size_t count, int type, int peer, void *comm, hipStream_t st) { return submit(false, buf, count, type, peer, comm, st); }
+int ncclGroupStart() { g_depth++; return 0; }
+int ncclGroupEnd()
+{
+    if (g_depth <= 0) return 4;
+    if (--g_depth > 0) return 0;
+    int rc = 0;
+    for (int pass = 0; pass < 2; pass++)                      // sends first: they do not wait for their peer
+        for (const Op &o : g_queue)
+            if (o.send == (pass == 0) && !rc) rc = enqueue(o);
+    g_queue.clear();
+    return rc;
+}
+const char *ncclGetErrorString(int rc)
+{
+    switch (rc) { case 0: return "no error"; case 1: return "fake_rccl: HIP call failed"; case 2: return "fake_rccl: peer missing / shared memory failure";
+                  case 4: return "fake_rccl: invalid argument"; default: return "fake_rccl: error"; }
+}
+
+} // extern "C"

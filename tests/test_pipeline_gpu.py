@@ -122,8 +122,13 @@ def test_native_transport_single_rank(eng_mod):
     a.close(); b.close()
 
 
-def _native_worker(rank, world, port, first_tokens, L, D, seed, steps, prompt, q):
+FAKE_RCCL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "_build", "libfake_rccl.so")
+
+
+def _native_worker(rank, world, port, first_tokens, L, D, seed, steps, prompt, q, rccl_lib):
     try:
+        if rccl_lib:
+            os.environ["RWKV_RCCL_LIB"] = rccl_lib          # engine.hip pipe_open: dlopen()s this instead of librccl.so
         import torch
         import torch.distributed as dist
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -132,56 +137,72 @@ def _native_worker(rank, world, port, first_tokens, L, D, seed, steps, prompt, q
         dist.init_process_group("gloo", rank=rank, world_size=world)
         l0, l1 = pipeline.partition_layers(L, world, D)[rank]
         st = pipeline.EngineStage(mf.synthetic_tensors(L, D, seed=seed), L, D, l0, l1, n_slots=world, device=0, prefill=True)
-        try:
-            pipeline.pipe_connect(st, dist, rank, world)
-        except Exception as e:                     # RCCL refuses two ranks on one device: nothing more to test on this box
-            q.put(("refused", rank, str(e)))
-            dist.barrier(); dist.destroy_process_group()
-            return
+        pipeline.pipe_connect(st, dist, rank, world)
         pipeline.run_prefill_native(st, rank, prompt, len(prompt))
         lg = st.m.logits(32)[: mf.VOCAB * ((len(prompt) - 1) % 32 + 1)].reshape(-1, mf.VOCAB)[-1].copy() if rank == world - 1 else None
         picks = pipeline.run_pipeline_native(st, rank, world, first_tokens, steps)
+        bad = None
+        if rank == 0:                                    # a bad id must fail on rank 0 WITHOUT stranding the other ranks
+            try:
+                pipeline.run_prefill_native(st, rank, [5, mf.VOCAB + 7, 9] + prompt[:40], 43)
+            except Exception as e:                       # noqa: BLE001
+                bad = str(e)
+        else:
+            pipeline.run_prefill_native(st, rank, None, 43)
+        if rank == 0:
+            q.put(("rank0", bad))
         if rank == world - 1:
             q.put(("ok", picks, lg))
         dist.barrier()
+        st.m.close()
         dist.destroy_process_group()
     except Exception as e:                         # pragma: no cover
         q.put(("error", rank, repr(e)))
 
 
-def test_native_rccl_two_ranks_on_one_gpu_if_rccl_permits(eng_mod):
-    """the real thing, as far as a single-GPU box allows: two processes, both on cuda:0, ncclSend / ncclRecv between them
-    inside the engines.  RCCL normally refuses a duplicate device; then the test records that and skips (the transport's
-    multi-GPU run is the driver's)."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_native_transport_with_several_ranks_on_one_gpu(eng_mod, world):
+    """rwkv_pipe_init / rwkv_pipe_prefill / rwkv_pipe_decode EXECUTED with world = 2 and 4: one process per rank, all on cuda:0,
+    the engine's ncclSend / ncclRecv groups served by tests/fake_rccl.cpp (shared-memory channels, stream ordered; real RCCL
+    refuses two ranks on one device and a gpurun box has one GPU).  Exercises what world = 1 cannot: the composition of the
+    per-tick group, the (ci - 1) & 1 / ci & 1 buffer parity of the prefill hop, the recv of the fed-back id into the control
+    block behind its memcpy, the item order of the picks.  Picks and last-chunk logits must be bit-identical to a single
+    whole-model context; a bad token id fails on rank 0 without stranding the other ranks."""
     import torch.multiprocessing as mp
-    world, L, D, seed, steps = 2, 6, 768, 93, 5
-    first = [11, 222]
-    prompt = [int(x) for x in np.random.default_rng(5).integers(2, mf.VOCAB, 80)]
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/_build/libfake_rccl.so is missing: run __graft_entry__.build()")
+    L, D, seed, steps = 8, 768, 93, 5
+    first = [11, 222, 3333, 44444][:world]
+    prompt = [int(x) for x in np.random.default_rng(5).integers(2, mf.VOCAB, 150)]        # 5 chunks: more chunks than stages, ragged tail
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_native_worker, args=(r, world, port, first, L, D, seed, steps, prompt, q)) for r in range(world)]
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, first, L, D, seed, steps, prompt, q, FAKE_RCCL)) for r in range(world)]
     [p.start() for p in procs]
+    res = {}
     try:
-        res = q.get(timeout=300)
+        for _ in range(2):
+            r = q.get(timeout=420)
+            res[r[0]] = r
+            if r[0] == "error":
+                break
     finally:
-        [p.join(timeout=60) for p in procs]
+        [p.join(timeout=90) for p in procs]
         for p in procs:
             if p.is_alive():
                 p.kill()
-    if res[0] == "refused":
-        pytest.skip(f"RCCL does not allow two ranks on one device: {res[2][:200]}")
-    assert res[0] == "ok", res
-    _, picks, lg = res
+    assert "error" not in res, res["error"]
+    assert "out of range" in (res["rank0"][1] or ""), res["rank0"]
+    _, picks, lg = res["ok"]
     t = mf.synthetic_tensors(L, D, seed=seed)
     m = eng_mod.RWKV(resident=True); m.loadTensors(L, D, t, maxGPT=32)
     for i in range(0, len(prompt), 32):
         ref = m.forward(prompt[i:i + 32], eng_mod.MODE_GPT)[: len(prompt[i:i + 32]) * mf.VOCAB].reshape(-1, mf.VOCAB)[-1].copy()
     assert np.array_equal(lg, ref)
-    # the streams of the native decode started from slot k's state: slot 0 holds the prompt, slot 1 is fresh
+    # the streams of the native decode started from slot k's state: slot 0 holds the prompt, the others are fresh
     for k, tk in enumerate(first):
-        if k == 1:
+        if k >= 1:
             m.reset_state()
         cur, ids = tk, []
         for _ in range(steps):

@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU-box session that produces everything profiles/rNN/ holds: GPU tests, the full bench line (reference-kernel
 # gate + CPU baseline legs included), rocprofv3 kernel-trace stats of the bench command, a separate PMC pass (FETCH_SIZE
-# only, no trace domains), the prefill report with per-kernel statistics, the other model sizes.  usage: tools/gpu_round.sh [r02]
+# only, no trace domains), the prefill report with per-kernel statistics, the other model sizes.  usage: tools/gpu_round.sh [r03]
 cd "$(dirname "$0")/.."
-R=$PWD; TAG=${1:-r02}; O=$R/gpurun_out/$TAG
+R=$PWD; TAG=${1:-r03}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 export PYTHONUNBUFFERED=1
 if [ -z "$SKIP_TESTS" ]; then
@@ -55,8 +55,31 @@ with open(O + "/bench7b_pmc_fetch_size_summary.csv", "w") as fo:
         traffic[k] = b
         fo.write(f"{k},{len(v)},{mean:.1f},{b},{a},{b / a:.4f}\n")
 print(open(O + "/bench7b_pmc_fetch_size_summary.csv").read())
-json.dump({"7B": traffic, "_note": "HBM read bytes per launch = mean FETCH_SIZE [KB] x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section); "
+import hashlib
+json.dump({"7B": traffic, "kernels_hip_h_sha256": hashlib.sha256(open("rwkv-cpp-accelerated_amd/csrc/kernels.hip.h", "rb").read()).hexdigest(), "_note": "HBM read bytes per launch = mean FETCH_SIZE [KB] x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section); "
            "own rocprofv3 --pmc FETCH_SIZE pass of `bench.py --steps 8 --warmup 2` (tools/gpu_round.sh)"}, open(O + "/hbm_traffic.json", "w"), indent=1)
 PY
 rm -rf $O/kt $O/pmc
+# chunk path (BASELINE config 5): HBM read and write traffic of the k_seq_* kernels, one counter per pass
+cd /tmp
+for CTR in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $O/pmcs
+  timeout 300 rocprofv3 --pmc $CTR --output-format csv -d $O/pmcs -- python $R/tools/prefill_bench.py --chunks 2 > /dev/null 2>&1
+  python - "$O" $CTR <<'PY'
+import csv, glob, sys, collections
+O, ctr = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(list)
+for f in glob.glob(O + "/pmcs/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == ctr and "k_seq" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"].split("(")[0][:90]].append(float(r["Counter_Value"]))
+with open(f"{O}/prefill7b_pmc_{ctr.lower()}.csv", "w") as fo:
+    fo.write(f"kernel,dispatches,mean_{ctr}_KB,total_{ctr}_MB_per_chunk_pass_uncorrected\n")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        fo.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.1f},{sum(v) / 1024 / 3:.1f}\n")      # 3 passes (warm-up + 2 chunks)
+print(open(f"{O}/prefill7b_pmc_{ctr.lower()}.csv").read()[:1500])
+PY
+done
+rm -rf $O/pmcs
+cd $R
 ls $O
