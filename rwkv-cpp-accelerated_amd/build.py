@@ -19,7 +19,7 @@ def _digest(sources, extra="") -> str:
     h = hashlib.sha256(extra.encode())
     for s in sources:
         if os.path.exists(s):
-            h.update(s.encode()[-64:])
+            h.update(os.path.relpath(s, ROOT).encode())      # not the absolute path: the tree is copied to another root on the GPU box
             with open(s, "rb") as f:
                 h.update(f.read())
     return h.hexdigest()
@@ -33,7 +33,10 @@ def _stale(target: str, sources, extra="") -> bool:
     stamp = target + ".stamp"
     if not os.path.exists(stamp):
         t = os.path.getmtime(target)
-        return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+        if any(os.path.getmtime(s) > t for s in sources if os.path.exists(s)):
+            return True
+        _stamp(target, sources, extra)      # fresh by mtime (authoring container): record the digest for the copies of this tree
+        return False
     with open(stamp) as f:
         return f.read().strip() != _digest(sources, extra)
 

@@ -12,7 +12,7 @@ for spec in "$@"; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result $flags $CS/engine.hip -o $CS/variants/lib_$name.so &
   else
     echo "== $name ($flags)"
-    RWKV_LIB=$PWD/$CS/variants/lib_$name.so timeout 300 python bench.py --steps ${STEPS:-128} --warmup 8 --no-cpu-baseline --ref-steps 0 --prefill-chunks 0 --model ${MODEL:-7B} 2>/dev/null | tail -1 | python -c "
+    RWKV_LIB=$PWD/$CS/variants/lib_$name.so timeout 300 python bench.py --steps ${STEPS:-128} --warmup 8 --no-cpu-baseline --ref-steps 0 --prefill-chunks 0 --config2-steps 0 --model ${MODEL:-7B} 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('  tok/s %.1f  ms/step %.4f  e2e %.0f GB/s' % (d['value'], d['ms_per_step'], d['end_to_end']['achieved_GBps']))
