@@ -148,9 +148,6 @@ struct SeqScratch {
     SeqPart *qpart = nullptr, *qparta = nullptr, *qparth = nullptr;
     SeqStat *stat = nullptr;
     float *pk3 = nullptr, *pk5 = nullptr, *pk1 = nullptr;
-    unsigned *fcnt = nullptr;           // [SEQ_T] arrival counters of the fused resid + site launches (monotonic)
-    unsigned *fepoch = nullptr;         // host: fused launches enqueued on this scratch set so far
-    unsigned fepoch_own = 0;
 };
 
 struct rwkv_ctx {
@@ -226,8 +223,6 @@ struct rwkv_ctx {
     unsigned *sq_img[3] = {nullptr, nullptr, nullptr}, *sq_imgh = nullptr;   // MFMA A-operand images (K = D; K = 4D)
     SeqPart *sq_qpart = nullptr, *sq_qparta = nullptr, *sq_qparth = nullptr;   // quantisation records: site vectors [3][SEQ_T][SEQ_O], att_out input [SEQ_T][SEQ_O], ffn_v input [SEQ_T][SEQ_O]
     SeqStat *sq_stat = nullptr;                          // [SEQ_T][SEQ_O] LayerNorm partial statistics
-    unsigned *sq_fcnt = nullptr; unsigned sq_fepoch = 0;             // fused resid + site launches: arrival counters [SEQ_T], launches so far
-    int seq_fuse = 1;                                                // env RWKV_SEQ_FUSE (0: one launch per element-wise step, as in round 2)
     float *sq_pk3 = nullptr, *sq_pk5 = nullptr, *sq_pk1 = nullptr;   // per-slice partial values [SEQ_O][SEQ_T][3D / 5D / D] of the K/V/R, ffn k/r, att_out | ffn_v GEMMs
     // second resident copy of the matrices (chunked path only): MFMA B-operand images, row sums per octant of K
     uint8_t *b_kvr = nullptr, *b_att = nullptr, *b_frk = nullptr, *b_fv = nullptr, *b_head = nullptr;
@@ -716,9 +711,6 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
             HIPCHK(hipMemsetAsync(c->sq_qparta, 0, sizeof(SeqPart) * SEQ_T * SEQ_O, c->stream));
             HIPCHK(hipMemsetAsync(c->sq_qparth, 0, sizeof(SeqPart) * SEQ_T * SEQ_O, c->stream));
             if ((rc = dalloc(c, &c->sq_stat, (size_t)SEQ_T * SEQ_O))) return rc;
-            if ((rc = dalloc(c, &c->sq_fcnt, (size_t)SEQ_T))) return rc;
-            HIPCHK(hipMemsetAsync(c->sq_fcnt, 0, sizeof(unsigned) * SEQ_T, c->stream));
-            { const char *f = getenv("RWKV_SEQ_FUSE"); c->seq_fuse = (f && f[0] == '0') ? 0 : 1; }
             {   // accumulator images: [slice][tile][2][4][64] floats, tiles = classes x 16-channel blocks
                 const size_t cbd = ((size_t)D + 15) / 16;
                 if ((rc = dalloc(c, &c->sq_pk3, (size_t)SEQ_O * 3 * cbd * 512))) return rc;
@@ -784,7 +776,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
     own.state = c->sq_state; own.y = c->sq_y; own.imgh = c->sq_imgh;
     for (int k = 0; k < 3; k++) own.img[k] = c->sq_img[k];
     own.qpart = c->sq_qpart; own.qparta = c->sq_qparta; own.qparth = c->sq_qparth; own.stat = c->sq_stat;
-    own.pk3 = c->sq_pk3; own.pk5 = c->sq_pk5; own.pk1 = c->sq_pk1; own.fcnt = c->sq_fcnt; own.fepoch = &c->sq_fepoch;
+    own.pk3 = c->sq_pk3; own.pk5 = c->sq_pk5; own.pk1 = c->sq_pk1;
     const SeqScratch &S = part ? *part->S : own;
     double *x = c->sq_x[buf];
     if (first) {
@@ -831,13 +823,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         else if (mode == 1) k_seq_resid<1><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(r);
         else k_seq_resid<2><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(r);
     };
-    auto resid_args = [&](const SeqPart *qpart) {
-        SeqResidArgs r{};
-        r.x = x; r.pk = S.pk1; r.qpart = qpart; r.pk_gate = S.pk5; r.qpart_gate = S.qpart + (size_t)1 * SEQ_T * SEQ_O;
-        r.stat = S.stat; r.D = D; r.T = n;
-        return r;
-    };
-    auto site_args = [&](int nv, const double *lnw, const double *lnb, const double *const *mix, const float *const *r, const float *const *o, double *state) {
+    auto site = [&](int nv, const double *lnw, const double *lnb, const double *const *mix, const float *const *r, const float *const *o, double *state) {
         SeqSiteArgs s{};
         s.x = x; s.stat = S.stat; s.lnw = lnw; s.lnb = lnb;
         for (int q = 0; q < nv; q++) { s.mix[q] = mix ? mix[q] : nullptr; s.r[q] = r[q]; s.o[q] = o[q]; }
@@ -845,71 +831,45 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         s.par = par && state; s.state_par = state; s.slot_stride = LD; s.slot0 = (int)row0;
         for (int q = 0; q < 3; q++) s.img[q] = S.img[q];
         s.part = S.qpart; s.D = D; s.T = n;
-        return s;
-    };
-    auto site = [&](int nv, const double *lnw, const double *lnb, const double *const *mix, const float *const *r, const float *const *o, double *state) {
-        const SeqSiteArgs s = site_args(nv, lnw, lnb, mix, r, o, state);
         if (nv == 3) k_seq_site<3><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(s);
         else if (nv == 2) k_seq_site<2><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(s);
         else k_seq_site<1><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(s);
     };
-    // resid(mode) and the site behind it: ONE launch (k_seq_resid_site: the workgroups meet on a per-row arrival counter), or two
-    const bool fuse = c->seq_fuse && S.fcnt && S.fepoch;
-    auto resid_site = [&](int mode, const SeqPart *qpart, int nv, const double *lnw, const double *lnb, const double *const *mix, const float *const *r,
-                          const float *const *o, double *state) {
-        if (!fuse) { resid(mode, qpart); site(nv, lnw, lnb, mix, r, o, state); return; }
-        const SeqResidArgs ra = resid_args(qpart);
-        const SeqSiteArgs sa = site_args(nv, lnw, lnb, mix, r, o, state);
-        const SeqFuse fz{S.fcnt, (unsigned)SEQ_O * ++(*S.fepoch), c->d_herr};
-        if (mode == 1) k_seq_resid_site<1, 2><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(ra, sa, fz);
-        else if (nv == 3) k_seq_resid_site<2, 3><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(ra, sa, fz);
-        else k_seq_resid_site<2, 1><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(ra, sa, fz);
-    };
     unsigned *imgh3[3] = {S.imgh, S.imgh, S.imgh};
     const int n_wkv = (D + WKV_CH - 1) / WKV_CH;
     const uint64_t CBd = ((uint64_t)D + 15) / 16;
-    // per layer: site(ln1) | K/V/R GEMM | WKV | stage | att_out GEMM | resid + site(ln2) | ffn k/r GEMM | stage | ffn_v GEMM | resid
-    // + the NEXT site (ln1 of layer l + 1, or ln_out in front of the head): 9 launches (11 with RWKV_SEQ_FUSE=0)
-    auto att_site = [&](uint64_t l, bool fused_behind_resid2, const SeqPart *qp) {
-        const size_t lo = (size_t)l * D;
-        const double *mix[3] = {c->mixk + lo, c->mixv + lo, c->mixr + lo};
-        const float *r[3] = {c->kr + lo, c->vr + lo, c->rr + lo}, *o[3] = {c->o1 + lo, c->o2 + lo, c->o3 + lo};
-        if (fused_behind_resid2) resid_site(2, qp, 3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D, mix, r, o, c->state[0] + lo);
-        else site(3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D, mix, r, o, c->state[0] + lo);
-    };
-    auto head_site = [&](bool fused_behind_resid2, const SeqPart *qp) {
-        const float *r[3] = {c->headr, nullptr, nullptr}, *o[3] = {c->heado, nullptr, nullptr};
-        if (fused_behind_resid2) resid_site(2, qp, 1, c->ln + (4 * L + 2) * D, c->ln + (4 * L + 3) * D, nullptr, r, o, nullptr);
-        else site(1, c->ln + (4 * L + 2) * D, c->ln + (4 * L + 3) * D, nullptr, r, o, nullptr);
-    };
     resid(0, nullptr);     // LayerNorm statistics of the incoming residual stream (embedding rows, or the previous stage's output)
-    if (la < lb) att_site(la, false, nullptr);
-    else if (last) head_site(false, nullptr);
     for (uint64_t l = la; l < lb; l++) {
         const size_t lo = (size_t)l * D, wl = (size_t)(l - c->l0);   // vectors are indexed by the model's layer, matrices by the stage's
-        {   // time mix (its site was opened behind the previous layer's ffn_v)
+        {   // time mix
+            const double *mix[3] = {c->mixk + lo, c->mixv + lo, c->mixr + lo};
+            const float *r[3] = {c->kr + lo, c->vr + lo, c->rr + lo}, *o[3] = {c->o1 + lo, c->o2 + lo, c->o3 + lo};
+            site(3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D, mix, r, o, c->state[0] + lo);
             gemm(0, c->b_kvr + wl * 3 * CBd * 16 * D, c->r8_kvr + wl * SEQ_O * 3 * (size_t)D, 3 * D, D, 3, v012, S.img, S.qpart, S.pk3, c->state[0] + lo);
             SeqWkvArgs wa{S.pk3, S.qpart, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, S.y, D, n, par ? 1 : 0, LD, (int)row0};
             k_seq_wkv<<<dim3(n_wkv), dim3(SEQ_T * WKV_CH), 0, st>>>(wa);
             SeqStageArgs sa{S.y, nullptr, nullptr, c->attr + lo, c->atto + lo, S.img[0], S.qparta, D, n};
             k_seq_stage<0><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(sa);
             gemm(1, c->b_att + wl * CBd * 16 * D, c->r8_att + wl * SEQ_O * (size_t)D, D, D, 1, v0, S.img, S.qparta, S.pk1, nullptr);
+            // x = f32(x) + att_out; statistics for ln2.  (Round 3 tried this launch and the site behind it as ONE launch whose (row, octant)
+            // workgroups meet on a per-row arrival counter: +3.6 us per fused launch, profiles/r03/prefill_fuse.txt -- the in-launch
+            // all-to-all costs more than the kernel boundary it replaces.)
+            resid(1, S.qparta);
         }
-        {   // channel mix: x = f32(x) + att_out, statistics, ln2 site
+        {   // channel mix
             const double *mix[3] = {c->fmixk + lo, c->fmixr + lo, nullptr};
             const float *r[3] = {c->fkr + lo, c->frr + lo, nullptr}, *o[3] = {c->fko + lo, c->fro + lo, nullptr};
-            resid_site(1, S.qparta, 2, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D, mix, r, o, c->state[4] + lo);
+            site(2, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D, mix, r, o, c->state[4] + lo);
             gemm(2, c->b_frk + wl * 5 * CBd * 16 * D, c->r8_frk + wl * SEQ_O * 5 * (size_t)D, 5 * D, D, 5, v00001, S.img, S.qpart, S.pk5, c->state[4] + lo);
             SeqStageArgs sh{nullptr, S.pk5, S.qpart, c->fvr + 4 * lo, c->fvo + 4 * lo, S.imgh, S.qparth, 4 * D, n};
             k_seq_stage<1><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(sh);
             gemm(3, c->b_fv + wl * CBd * 16 * 4 * D, c->r8_fv + wl * SEQ_O * (size_t)D, D, 4 * D, 1, v0, imgh3, S.qparth, S.pk1, nullptr);
+            resid(2, S.qparth);     // x += ffn_v * sigmoid(r); statistics for the next site
         }
-        // x += ffn_v * sigmoid(r), statistics, and the site that reads them: ln1 of the next layer of this part, ln_out at the model's end
-        if (l + 1 < lb) att_site(l + 1, true, S.qparth);
-        else if (last) head_site(true, S.qparth);
-        else resid(2, S.qparth);      // a later pipeline stage opens its own site from x
     }
-    if (last) {   // the head
+    if (last) {   // ln_out and the head
+        const float *r[3] = {c->headr, nullptr, nullptr}, *o[3] = {c->heado, nullptr, nullptr};
+        site(1, c->ln + (4 * L + 2) * D, c->ln + (4 * L + 3) * D, nullptr, r, o, nullptr);
         SeqGemmArgs g{};
         g.bimg = reinterpret_cast<const u32x4 *>(c->b_head); g.rs8 = c->r8_head; g.N = (int)V; g.K = D; g.Q = 1;
         for (int k = 0; k < 3; k++) g.img[k] = reinterpret_cast<const u32x4 *>(S.img[k]);
@@ -964,9 +924,6 @@ int split_setup(rwkv_ctx *c)
         if (!rc) rc = dalloc(c, &S->pk3, (size_t)SEQ_O * 3 * cbd * 512);
         if (!rc) rc = dalloc(c, &S->pk5, (size_t)SEQ_O * 5 * cbd * 512);
         if (!rc) rc = dalloc(c, &S->pk1, (size_t)SEQ_O * cbd * 512);
-        if (!rc) rc = dalloc(c, &S->fcnt, (size_t)SEQ_T);
-        if (!rc) HIPCHK(hipMemsetAsync(S->fcnt, 0, sizeof(unsigned) * SEQ_T, c->stream));
-        S->fepoch = &S->fepoch_own;
     }
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1095,7 +1052,7 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
             own.state = c->sq_state; own.y = c->sq_y; own.imgh = c->sq_imgh;
             for (int k = 0; k < 3; k++) own.img[k] = c->sq_img[k];
             own.qpart = c->sq_qpart; own.qparta = c->sq_qparta; own.qparth = c->sq_qparth; own.stat = c->sq_stat;
-            own.pk3 = c->sq_pk3; own.pk5 = c->sq_pk5; own.pk1 = c->sq_pk1; own.fcnt = c->sq_fcnt; own.fepoch = &c->sq_fepoch;
+            own.pk3 = c->sq_pk3; own.pk5 = c->sq_pk5; own.pk1 = c->sq_pk1;
             HIPCHK(hipEventRecord(c->sp_end, c->stream));                 // the other stages start behind whatever the context's stream holds
             for (int k = 1; k < ns; k++) HIPCHK(hipStreamWaitEvent(c->sp_stream[k], c->sp_end, 0));
             uint64_t i = 0;

@@ -830,20 +830,26 @@ template <> __device__ __forceinline__ void dma_unit<5>(const uint8_t *src, unsi
 #undef RWKV_DMA_UNIT
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 constexpr int GLDS_SPIN = 1 << 18;    // bound of every wait loop (a lost hand-off must end the kernel, not hang the GPU)
-// A wait that ran into its bound is RECORDED in the ring's LDS control block (GldsCtl::err) -- the waiting loops hold no global
-// pointer: the loader wave's registers and instruction count are the stream's ceiling, and an error word passed through them cost
-// 3.5 % of the decode rate -- and REPORTED once, behind the kernel's closing barrier (ring_report), to the context's error word
-// (mapped host memory; engine.hip device_check reads it after the stream synchronisation and fails the call with RWKV_E_DEVICE).
+// A wait that ran into its bound is RECORDED in a wave-uniform REGISTER (`fail`: no memory operation on any path that rejoins the
+// streaming loops -- an error word stored from inside them, global or LDS, cost 3.5 % of the decode rate: hipcc's waitcnt insertion
+// is path-insensitive, and the loader wave's instruction count is the stream's ceiling) and REPORTED once per wave, behind the
+// kernel's closing barrier (ring_report), to the context's error word (mapped host memory; engine.hip device_check reads it after
+// the stream synchronisation and fails the call with RWKV_E_DEVICE): the kernel still ends, but nobody is handed its results.
 // codes: 1 loader found no room, 2 a group never landed, 3 the prologue never staged, 4 the loader's own DMA never completed
-struct GldsCtl;
-__device__ __forceinline__ void ring_fail(GldsCtl *gc, unsigned code);
-__device__ __forceinline__ void wait_count(const unsigned *p, unsigned least, GldsCtl *gc)
+__device__ __forceinline__ void wait_count(const unsigned *p, unsigned least, unsigned &fail)
 {
+    bool ok = false;
     for (int it = 0; it < GLDS_SPIN; it++) {
-        if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= least) return;
+        if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= least) { ok = true; break; }
         __builtin_amdgcn_s_sleep(1);
     }
-    ring_fail(gc, 3u);
+    fail = ok ? fail : 3u;
+}
+__device__ __forceinline__ void ring_report(unsigned fail, unsigned *herr)
+{
+#ifndef RWKV_NO_HERR      // (A/B knob: what recording the failures costs; without the report the compiler drops every `fail` update)
+    if (fail != 0u && herr != nullptr && (threadIdx.x & 63) == 0) __hip_atomic_store(herr, fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
 }
 constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
 // DMA pieces (1 KiB) the loader keeps in flight.  By Little's law the queueing delay of EVERY access of the CU is in-flight bytes /
@@ -868,25 +874,12 @@ constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
 struct GldsCtl {            // LDS control block of the ring (80 dwords)
     unsigned staged;        // prologue waves that have staged their part of the vector
     unsigned landed;        // ring units (rows of S KiB) whose DMA has completed: loader -> consumers, monotonic
-    unsigned err;           // a bounded wait of this workgroup gave up (ring_fail); reported by ring_report
-    unsigned pad;
+    unsigned pad[2];
     unsigned freeq[GLDS_FQ];   // freeq[k % FQ] = k + 1: group k has been copied out of the ring
     unsigned gend[GLDS_FQ];    // the loader's own: end unit of group k
     unsigned pad2[12];
 };
 constexpr int NC = NW - 1;              // consumer waves of a ring kernel
-__device__ __forceinline__ void ring_fail(GldsCtl *gc, unsigned code)
-{
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(&gc->err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// behind the kernel's closing barrier: hand a recorded failure to the host
-__device__ __forceinline__ void ring_report(GldsCtl *gc, unsigned *herr)
-{
-    if (threadIdx.x == 0) {
-        const unsigned e = __hip_atomic_load(&gc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (e && herr) __hip_atomic_store(herr, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
 
 // The loader wave.  The ring is made of `nu` UNITS of one row (S KiB) each; a group of R rows takes the next R units (wrapping),
 // so slots of every group size share one ring and the LDS is used to the last 4 KiB.  Round 2's first loader handed out whole
@@ -910,6 +903,7 @@ template <int S> struct RingLoader {
     unsigned pos = 0;                   // ring position of the next unit
     int lane;
     bool dead = false;
+    unsigned fail = 0;                  // see wait_count
 
     __device__ __forceinline__ RingLoader(GldsCtl *mc_, unsigned ring_, int nu_, int chunks, int lane_)
         : mc(mc_), ring((unsigned)__builtin_amdgcn_readfirstlane((int)ring_)), nu((unsigned)nu_), lane(lane_)
@@ -960,7 +954,7 @@ template <int S> struct RingLoader {
             advance_tail();
             if (room<R>()) break;
             poll_landed();
-            if (it >= GLDS_SPIN) { dead = true; ring_fail(mc, 1u); }      // a lost hand-off must end the kernel, not hang the GPU -- and must be reported
+            if (it >= GLDS_SPIN) { dead = true; fail = 1u; }      // a lost hand-off must end the kernel, not hang the GPU -- and must be reported
             __builtin_amdgcn_s_sleep(1);
         }
         if (lane == 0) mc->gend[k % GLDS_FQ] = issued + R;
@@ -984,14 +978,14 @@ template <int S> struct RingLoader {
     {
         int it = 0;
         for (; it < GLDS_SPIN && in_flight() != 0u; it++) { poll_landed(); __builtin_amdgcn_s_sleep(1); }
-        if (it >= GLDS_SPIN) ring_fail(mc, 4u);
+        fail = it >= GLDS_SPIN ? 4u : fail;
         wait_vm<0>();
         publish(issued);
     }
 };
 // the loader wave of a launch kernel: groups [g0, g1) of the workgroup in order; base(g) = address of group g's first row
 template <int R, int S, class Base>
-__device__ __forceinline__ void glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int nu, unsigned ring, GldsCtl *ctl, int lane)
+__device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int nu, unsigned ring, GldsCtl *ctl, int lane)
 {
 #if RWKV_LOADER_PRIO
     __builtin_amdgcn_s_setprio(RWKV_LOADER_PRIO);     // the loader's instruction issue IS the stream's ceiling: let it win the SIMD's arbitration
@@ -1005,18 +999,19 @@ __device__ __forceinline__ void glds_loader(Base base, int g0, int g1, size_t st
     __syncthreads();   // order: the control block is zero, the prologue's requests are in the pipe
     for (; g < g1; g++) ld.template group<R>(base(g) + ld.off[0], stride);
     ld.finish();
+    return ld.fail;
 }
 // consumer side of one group (kl = its index in the workgroup): wait, copy its R units into registers, hand them back
 template <int R, int S>
-__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, const unsigned char *ring, GldsCtl *ctl, int lane)
+__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, const unsigned char *ring, GldsCtl *ctl, int lane, unsigned &fail)
 {
     const unsigned uend = (unsigned)(kl + 1) * R;
-    int it = 0;
-    for (; it < GLDS_SPIN; it++) {
-        if ((int)(__hip_atomic_load(&ctl->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - uend) >= 0) break;
+    bool ok = false;
+    for (int it = 0; it < GLDS_SPIN; it++) {
+        if ((int)(__hip_atomic_load(&ctl->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - uend) >= 0) { ok = true; break; }
         __builtin_amdgcn_s_sleep(1);
     }
-    if (it >= GLDS_SPIN) ring_fail(ctl, 2u);
+    fail = ok ? fail : 2u;
     unsigned p0 = (uend - R) % (unsigned)nu;
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -1030,7 +1025,7 @@ __device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, cons
 // the consumer waves' streaming loop (wave < NC): same pre / epi contract as stream_groups
 template <int R, int S, int PAT, class Pre, class Epi>
 __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
-                                            int chunks, Pre pre, Epi epi, unsigned long long *g_tl_groups = nullptr)
+                                            int chunks, Pre pre, Epi epi, unsigned &fail, unsigned long long *g_tl_groups = nullptr)
 {
 #ifdef RWKV_TL_GROUPS
     // debug build (tools/timeline.py): where a consumer wave's time goes.  Stamps of the wave: 1 inputs of its first group requested,
@@ -1043,7 +1038,7 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
         if (rr == 0) tl_stamp(g_tl_groups, 1);
 #endif
         u32x4 w[R][S];
-        glds_take<R, S>(w, g - g0, nu, ring, ctl, lane);
+        glds_take<R, S>(w, g - g0, nu, ring, ctl, lane, fail);
 #ifdef RWKV_TL_GROUPS
         asm volatile("" : "+v"(w[R - 1][S - 1]));
         if (rr < 1) tl_stamp(g_tl_groups, 2);
@@ -1077,7 +1072,7 @@ __device__ __forceinline__ void ring_init(GldsCtl *gc)
 // publish the scalars, the others wait; contains the workgroup's order barrier, which the loader executes once as well
 template <int NV, int S>
 __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &dy, const double *x, int D, double *red, unsigned *xq,
-                                          SiteRed<NV> &sr, bool publish_stats, GldsCtl *gc, unsigned long long *tl)
+                                          SiteRed<NV> &sr, bool publish_stats, GldsCtl *gc, unsigned long long *tl, unsigned &fail)
 {
     constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
     const int nqd = D >> 2;
@@ -1118,7 +1113,7 @@ __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &d
     } else {
         __syncthreads();   // order
     }
-    wait_count(&gc->staged, NWP, gc);
+    wait_count(&gc->staged, NWP, fail);
 #pragma unroll
     for (int m = 0; m < NV; m++) { sr.S[m] = (double)bc[m]; sr.amax[m] = bc[4 + m]; }
     sr.mean = sr.rstd = 0.0;
@@ -1127,7 +1122,7 @@ __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &d
 // plain-vector prologue of a ring kernel (k_attout, k_ffnv), same roles
 template <int NVEC, int S>
 __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, const float *partM, int n_part, int D, double *red, unsigned *xq,
-                                         float &Sf, float &amax, GldsCtl *gc, unsigned long long *tl)
+                                         float &Sf, float &amax, GldsCtl *gc, unsigned long long *tl, unsigned &fail)
 {
     constexpr int XVD = xvd<S>();
     constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
@@ -1156,7 +1151,7 @@ __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, 
         if (lane == 0) { red[RED_OFFS + wave] = ws; redf[wave] = wm; }
         tl_stamp(tl, 3);
         if (lane == 0) __hip_atomic_fetch_add(spin, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        wait_count(spin, NWP, gc);
+        wait_count(spin, NWP, fail);
         double ts = 0.0; float tm = 0.f;
 #pragma unroll
         for (int i = 0; i < NWP; i++) { ts += red[RED_OFFS + i]; tm = fmaxf(tm, redf[i]); }
@@ -1173,7 +1168,7 @@ __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, 
     } else {
         __syncthreads();   // order
     }
-    wait_count(&gc->staged, NWP, gc);
+    wait_count(&gc->staged, NWP, fail);
     Sf = bc[0]; amax = bc[4];
     tl_stamp(tl, 5);
 }
@@ -1298,17 +1293,18 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
             pmax = fmaxf(pmax, fabsf(ys));
         }
     };
+    unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
     if constexpr (RING) {
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 3 * S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            glds_loader<3, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            fail = glds_loader<3, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
             SiteRed<3> sr;
-            ring_site<3, S>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl);
+            ring_site<3, S>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl, fail);
             scalars(sr);
-            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, a.tl);
+            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl);
         }
     } else {
         u32x4 wA[3][S], wB[3][S];
@@ -1324,7 +1320,7 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     __syncthreads();   // every wave is past its last read of the reduction scratch
     block_sum_max(part, pmax, red + RED_PART);
     if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
-    if constexpr (RING) ring_report(reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 3 * S * 3072), a.herr);
+    if constexpr (RING) ring_report(fail, a.herr);
     tl_stamp(a.tl, 7);
 }
 
@@ -1401,16 +1397,17 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
             }
         }
     };
+    unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
     if constexpr (RING) {
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            fail = glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
-            ring_vec<1, S>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl);
+            ring_vec<1, S>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl, fail);
             sc = scale_of(amax);
-            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi);
+            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail);
         }
     } else {
         u32x4 wA[R][S], wB[R][S];
@@ -1424,7 +1421,7 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
     __syncthreads();   // every wave is past its last read of the reduction scratch (and of the staged vector / the ring)
     tl_stamp(a.tl, 6);
     site_publish<2, R>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
-    if constexpr (RING) ring_report(reinterpret_cast<GldsCtl *>(smem + RED_BYTES + S * 3072), a.herr);
+    if constexpr (RING) ring_report(fail, a.herr);
     tl_stamp(a.tl, 7);
 }
 
@@ -1494,17 +1491,18 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
             a.rgate[g] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
         }
     };
+    unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
     if constexpr (RING) {
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 2 * S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            glds_loader<5, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            fail = glds_loader<5, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
             SiteRed<2> sr;
-            ring_site<2, S>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl);
+            ring_site<2, S>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl, fail);
             scalars(sr);
-            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, a.tl);
+            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl);
         }
     } else {
         u32x4 wA[5][S], wB[5][S];
@@ -1520,7 +1518,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     __syncthreads();   // every wave is past its last read of the reduction scratch
     block_sum_max(part, pmax, red + RED_PART);
     if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
-    if constexpr (RING) ring_report(reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 2 * S * 3072), a.herr);
+    if constexpr (RING) ring_report(fail, a.herr);
     tl_stamp(a.tl, 7);
 }
 
@@ -1587,16 +1585,17 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
             site_emit<NVN>(in.pre, a.dy, D, g, xnew, in.prevn, acc);
         }
     };
+    unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
     if constexpr (RING) {
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 4 * S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            glds_loader<4, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            fail = glds_loader<4, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
-            ring_vec<4, S>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl);
+            ring_vec<4, S>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl, fail);
             sc = scale_of(amax);
-            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, a.tl);
+            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl);
         }
     } else {
         u32x4 wA[4][S], wB[4][S];
@@ -1610,7 +1609,7 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
     __syncthreads();   // every wave is past its last read of the reduction scratch
     tl_stamp(a.tl, 6);
     site_publish<NVN, 1>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
-    if constexpr (RING) ring_report(reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 4 * S * 3072), a.herr);
+    if constexpr (RING) ring_report(fail, a.herr);
     tl_stamp(a.tl, 7);
 }
 
@@ -1676,16 +1675,17 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
             if (i != 0 && (val > best || (val == best && (unsigned)i < besti))) { best = val; besti = (unsigned)i; }
         }
     };
+    unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
     if constexpr (RING) {
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + S * 3072 + 64);   // behind bval / bidx
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            fail = glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
         } else {
             SiteRed<1> sr;
-            ring_site<1, S>(a.st, a.dy, a.x, D, red, xq, sr, false, gc, nullptr);
+            ring_site<1, S>(a.st, a.dy, a.x, D, red, xq, sr, false, gc, nullptr, fail);
             Sf = (float)sr.S[0]; sc = scale_of(sr.amax[0]);
-            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi);
+            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail);
         }
     } else {
         u32x4 wA[R][S], wB[R][S];
@@ -1705,7 +1705,7 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
         a.blk_val[blockIdx.x] = best;
         a.blk_idx[blockIdx.x] = besti;
     }
-    if constexpr (RING) ring_report(reinterpret_cast<GldsCtl *>(smem + RED_BYTES + S * 3072 + 64), a.herr);
+    if constexpr (RING) ring_report(fail, a.herr);
 }
 
 // finish the greedy pick: argmax over workgroup partials (ties -> lowest id), feed it back as the

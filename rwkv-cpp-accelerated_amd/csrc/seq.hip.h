@@ -324,141 +324,6 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_site(SeqSiteArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// k_seq_resid<1|2> and the k_seq_site behind it as ONE launch (three launch boundaries less per layer; an element-wise launch of
-// this path costs ~5 us whatever it moves).  The seam between the two is an all-to-all per ROW only: the site of (row t, octant o)
-// needs the LayerNorm statistics of all 8 octants of row t and, for the token shift in GPT mode, those of row t - 1 plus the
-// previous row's new x of its own octant.  So the workgroups (256 threads, one per (row, octant), all co-resident: at most 256 of
-// them) meet on one arrival counter per row instead of a kernel boundary:
-//   producer side (cdna_hip_programming.md Guideline 16, R1): x and the partial statistics are stored write-through (agent-scope
-//   8-byte stores), every wave drains its stores, the workgroup meets, ONE lane adds 1 to cnt[row];
-//   consumer side: one lane polls cnt[t] (and cnt[t - 1]) relaxed until all 8 octants of this launch have arrived, the statistics
-//   and the previous row's x are read with agent-scope loads (the producer stored write-through: no cache invalidate needed).
-// The counters are monotonic: every launch adds 8 to EVERY row (workgroup (0, o) also ticks the rows past a ragged chunk's end),
-// so `expect` = 8 x (launches so far on this scratch set), kept by the host next to the counters.  A wait that runs into its
-// bound raises the context's error word.  Arithmetic and summation order are those of the two separate kernels with the site's
-// thread mapping (one quad per thread): results agree with the unfused path to rounding of the f64 statistics' summation order.
-struct SeqFuse { unsigned *cnt; unsigned expect; unsigned *herr; };
-template <int MODE, int NV>
-__global__ __launch_bounds__(SEQ_ENT) void k_seq_resid_site(SeqResidArgs ra, SeqSiteArgs a, SeqFuse fz)
-{
-    __shared__ double red[SEQ_ENW * 4];
-    __shared__ double st_l[2][SEQ_O][2];       // statistics of row t and row t - 1, per octant
-    const int D = a.D, t = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;
-    int c0, c1;
-    octant_range(D, o, c0, c1);
-    const bool shift = a.mix[0] != nullptr;
-    const bool lnprev = shift && t > 0 && !a.par;
-    const int qd = (c0 >> 2) + threadIdx.x;
-    const bool live = qd < (c1 >> 2);
-    // ---- the residual update of this (row, octant): k_seq_resid ----
-    const float so = seq_so(ra.qpart, 0, t);
-    const float sog = MODE == 2 ? seq_so(ra.qpart_gate, 0, t) : 0.f;
-    double xt[4] = {0.0, 0.0, 0.0, 0.0};
-    double s[2] = {0.0, 0.0};
-    if (live) {
-        load_quad_f64(ra.x + (size_t)t * D, qd, xt);
-        const int CB = (D + 15) >> 4;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int j = qd * 4 + e;
-            const float v = seq_val(ra.pk, CB, j >> 4, t, j & 15, so);
-            if (MODE == 1) xt[e] = (double)((float)xt[e] + v);
-            else {
-                const float r = seq_val(ra.pk_gate, 5 * CB, 4 * CB + (j >> 4), t, j & 15, sog);
-                const float gt = (float)(1.0 / (1.0 + exp(-(double)r)));
-                xt[e] = xt[e] + (double)(v * gt);
-            }
-            __hip_atomic_store(ra.x + (size_t)t * D + j, xt[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s[0] += xt[e]; s[1] += xt[e] * xt[e];
-        }
-    }
-    eblock_sum<2>(s, red);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&ra.stat[t * SEQ_O + o].sx, s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ra.stat[t * SEQ_O + o].sxx, s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains before the workgroup's arrival is counted
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&fz.cnt[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == 0)
-            for (int r = a.T; r < SEQ_T; r++) __hip_atomic_fetch_add(&fz.cnt[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool ok = false;
-        for (int it = 0; it < (1 << 22); it++) {
-            const unsigned a0 = __hip_atomic_load(&fz.cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned a1 = lnprev ? __hip_atomic_load(&fz.cnt[t - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a0;
-            if ((int)(a0 - fz.expect) >= 0 && (int)(a1 - fz.expect) >= 0) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (!ok && fz.herr) __hip_atomic_store(fz.herr, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __syncthreads();
-    // ---- the site of this (row, octant): k_seq_site, with x of the own row in registers ----
-    if (threadIdx.x < 2 * SEQ_O) {
-        const int which = threadIdx.x / SEQ_O, oo = threadIdx.x % SEQ_O, tr = which == 0 ? t : (t > 0 ? t - 1 : 0);
-        st_l[which][oo][0] = __hip_atomic_load(&a.stat[tr * SEQ_O + oo].sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        st_l[which][oo][1] = __hip_atomic_load(&a.stat[tr * SEQ_O + oo].sxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    auto row_stats = [&](int which, double &mean, double &rstd) {
-        double sx = 0.0, sxx = 0.0;
-#pragma unroll
-        for (int oo = 0; oo < SEQ_O; oo++) { sx += st_l[which][oo][0]; sxx += st_l[which][oo][1]; }
-        mean = sx / (double)D;
-        rstd = 1.0 / sqrt((sxx - sx * mean) / (double)(D - 1));
-    };
-    double mean, rstd, meanp = 0.0, rstdp = 1.0;
-    row_stats(0, mean, rstd);
-    if (lnprev) row_stats(1, meanp, rstdp);
-    const double *xprow = !shift ? a.x : a.par ? a.state_par + (size_t)(a.slot0 + t) * a.slot_stride : (t > 0 ? a.x + (size_t)(t - 1) * D : a.state);
-    float v[NV][4];
-    double So[NV];
-    float amax[NV];
-#pragma unroll
-    for (int m = 0; m < NV; m++) { So[m] = 0.0; amax[m] = 0.f; v[m][0] = v[m][1] = v[m][2] = v[m][3] = 0.f; }
-    if (live) {
-        double xp[4], lw[4], lb[4];
-        if (lnprev) {       // written in THIS launch by workgroup (t - 1, o)
-#pragma unroll
-            for (int e = 0; e < 4; e++) xp[e] = __hip_atomic_load(xprow + qd * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (shift) load_quad_f64(xprow, qd, xp);
-        else { xp[0] = xp[1] = xp[2] = xp[3] = 0.0; }
-        load_quad_f64(a.lnw, qd, lw);
-        load_quad_f64(a.lnb, qd, lb);
-        double xx[4], xprev[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            xx[e] = lw[e] * ((xt[e] - mean) * rstd) + lb[e];
-            xprev[e] = lnprev ? lw[e] * ((xp[e] - meanp) * rstdp) + lb[e] : xp[e];
-            const int j = qd * 4 + e;
-            if (a.par) a.state_par[(size_t)(a.slot0 + t) * a.slot_stride + j] = xx[e];
-            else if (a.state_new && t == a.T - 1) a.state_new[j] = xx[e];
-        }
-#pragma unroll
-        for (int m = 0; m < NV; m++) {
-            const f32x4 rr = reinterpret_cast<const f32x4 *>(a.r[m])[qd], oo = reinterpret_cast<const f32x4 *>(a.o[m])[qd];
-            double mk[4] = {1.0, 1.0, 1.0, 1.0};
-            if (shift) load_quad_f64(a.mix[m], qd, mk);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float f = (float)xx[e];
-                if (shift) f = (float)(xx[e] * mk[e] + xprev[e] * (1.0 - mk[e]));
-                v[m][e] = f * rr[e];
-                So[m] += (double)(f * oo[e]);
-                amax[m] = fmaxf(amax[m], fabsf(v[m][e]));
-            }
-        }
-    }
-    eblock_max<NV>(amax, red);
-#pragma unroll
-    for (int m = 0; m < NV; m++) {
-        unsigned ls[3] = {0u, 0u, 0u};
-        if (live) seq_store_quad(a.img[m], qd, t, v[m], inv_scale(amax[m]), ls);
-        seq_finish(ls, So[m], c1 - c0, amax[m], a.part + ((size_t)m * SEQ_T + t) * SEQ_O + o, red);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 struct SeqStageArgs {
     const float *src;            // KIND 0: gated wkv y [T][D]
     const float *pk;             // KIND 1: partials of the ffn k/r GEMM (5 classes): k of hidden unit 4 i + q = class q, channel i

@@ -196,28 +196,3 @@ def test_seq_stages_1_to_4_are_bit_identical_and_match_the_oracle(eng_mod, oracl
         assert np.abs(g[:n] - r[:n]).max() <= 1e-4 * max(1.0, np.abs(r).max()), name
     om.close()
 
-
-@pytest.mark.parametrize("mode,L,D,T", [("gpt", 3, 1024, 45), ("par", 2, 768, 40), ("gpt", 2, 5120, 19)])
-def test_fused_resid_site_launch_matches_the_separate_launches(eng_mod, mode, L, D, T, monkeypatch):
-    """RWKV_SEQ_FUSE=1 (default): the residual update and the LayerNorm site behind it are ONE launch whose (row, octant)
-    workgroups meet on a per-row arrival counter (seq.hip.h k_seq_resid_site); RWKV_SEQ_FUSE=0: two launches.  Same arithmetic,
-    a different summation order of the f64 row statistics only: logits and state agree to ~1e-7 of the logit range, twice in a
-    row (the counters are monotonic across launches), and with ragged chunks."""
-    t = mf.synthetic_tensors(L, D, seed=1234 + D)
-    toks = _toks(T, 7 * T)
-    md = eng_mod.MODE_GPT if mode == "gpt" else eng_mod.MODE_PARRALEL
-    outs = {}
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("RWKV_SEQ_FUSE", fuse)
-        m = eng_mod.RWKV(resident=True)
-        m.loadTensors(L, D, t, maxGPT=T)
-        a = m.forward(toks, md)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
-        b = m.forward(toks[: T - 3], md)[: (T - 3) * mf.VOCAB].reshape(T - 3, mf.VOCAB).copy()
-        m.pull_state(T if mode == "par" else 1)
-        outs[fuse] = (a, b, [x.copy() for x in m.state.arrays()])
-        m.close()
-    for k in (0, 1):
-        d = np.abs(outs["0"][k].astype(np.float64) - outs["1"][k]).max()
-        assert d <= 2e-6 * np.abs(outs["0"][k]).max(), (k, d)
-    for x, y in zip(outs["0"][2], outs["1"][2]):
-        assert np.abs(x - y).max() <= 1e-9 * max(1.0, np.abs(x).max())
