@@ -1326,10 +1326,15 @@ int rwkv_profile_batched(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint
     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
     for (int cls = 0; cls < RWKV_N_KCLASS; cls++) {
         const bool per_layer = cls >= 1 && cls <= 4;
+        // a class with ONE launch per token gets 8 x as many repetitions (4 launches in a bracket measured +10 % on k_head) and a
+        // warm-up launch; every launch of a class is preceded by the others of its batch only, so k_head's 206 MB are re-read from
+        // HBM each time (nt loads; the rocprofv3 duration of the same kernel inside the real token is the cross-check)
+        const int nrep = per_layer ? reps : reps * 8;
+        launch_class(c, cls, per_layer ? c->l0 : 0);
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipEventRecord(a, c->stream));
         uint32_t cnt = 0;
-        for (int r = 0; r < reps; r++)
+        for (int r = 0; r < nrep; r++)
             for (uint64_t l = (per_layer ? c->l0 : 0); l < (per_layer ? c->l1 : 1); l++) { launch_class(c, cls, l); cnt++; }
         HIPCHK(hipEventRecord(b, c->stream));
         HIPCHK(hipEventSynchronize(b));

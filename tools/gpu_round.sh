@@ -7,7 +7,7 @@ R=$PWD; TAG=${1:-r03}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 export PYTHONUNBUFFERED=1
 if [ -z "$SKIP_TESTS" ]; then
-  timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -rs 2>&1 | grep -v "^loading\|^n_layers\|^n_embed" | tail -8 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
+  timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rs 2>&1 | grep -v "^loading\|^n_layers\|^n_embed" | tail -8 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
 fi
 timeout 900 python bench.py 2>$O/bench7b_full.err | tail -1 > $O/bench7b_full.json; cut -c1-300 $O/bench7b_full.json
 bash tools/seq_trace.sh $O 2>&1 | tail -16
@@ -16,7 +16,7 @@ import json, subprocess, sys, os
 O = sys.argv[1]
 out = {}
 for m in ("169M", "1B5", "3B", "14B"):
-    r = subprocess.run([sys.executable, "bench.py", "--model", m, "--steps", "256", "--warmup", "16", "--no-cpu-baseline", "--ref-steps", "0"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "bench.py", "--model", m, "--steps", "256", "--warmup", "16", "--no-cpu-baseline", "--ref-steps", "0", "--config2-steps", "0"], capture_output=True, text=True, timeout=600)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])
         out[m] = dict(tokens_per_s=d["value"], ms_per_step=d["ms_per_step"], end_to_end=d["end_to_end"], kernels=d["kernels"], roofline=d["roofline"], prefill=d.get("prefill"))
@@ -27,8 +27,8 @@ json.dump(out, open(os.path.join(O, "bench_sizes.json"), "w"), indent=1)
 PY
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/kt $O/pmc
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 128 --warmup 8 --no-cpu-baseline --ref-steps 0 --prefill-chunks 0 2>/dev/null | tail -1 > $O/bench7b_under_rocprof.json
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --ref-steps 0 --profile-reps 4 --prefill-chunks 0 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 128 --warmup 8 --no-cpu-baseline --ref-steps 0 --prefill-chunks 0 --config2-steps 0 2>/dev/null | tail -1 > $O/bench7b_under_rocprof.json
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --ref-steps 0 --profile-reps 4 --prefill-chunks 0 --config2-steps 0 > /dev/null 2>&1
 cd $R
 python - "$O" <<'PY'
 import csv, glob, json, sys, collections, shutil, os
