@@ -302,9 +302,13 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     (rwkv_pipe_decode).  N independent greedy streams are in flight, one per stage, so every GPU is busy: a "step" = one
     token of every stream.  value = N*K tokens / max-over-ranks time.  torch.distributed only carries the 128-byte RCCL id,
     the barriers and the timing reduction.  (RWKV_BENCH_BACKEND=gloo: the Python schedule over torch P2P ops instead.)"""
+    import faulthandler
     import numpy as np
     import torch
     from rwkv_cpp_accelerated_amd import modelfile as mf, pipeline
+    # the engine-side RCCL schedule has run with several ranks only over the shared-memory stand-in (tests/fake_rccl.cpp): a transport
+    # that hangs on real xGMI must fail visibly (stack dump + exit) instead of stalling the whole run
+    faulthandler.dump_traceback_later(int(os.environ.get("RWKV_BENCH_WATCHDOG_S", "600")), exit=True)
     tensors = mf.synthetic_tensors_torch(L, D, seed=args.seed, device=dev)     # same seed on every rank: one model
     l0, l1 = pipeline.partition_layers(L, world, D)[rank]
     native = dist.get_backend() == "nccl" and os.environ.get("RWKV_BENCH_NATIVE", "1") == "1"
@@ -388,6 +392,7 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
                                  "the slowest stage is quoted"),
             end_to_end=dict(achieved_GBps=round(B_tok * tok_s / 1e9, 1), frac_of_aggregate_peak=round(B_tok * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)),
             per_stream_tokens_per_s=round(args.steps / dt, 2), prefill=prefill, transport_fallback=native_note)), flush=True)
+    faulthandler.cancel_dump_traceback_later()
     dist.barrier()
     dist.destroy_process_group()
 
