@@ -179,10 +179,6 @@ void *rwkv_stream(rwkv_ctx *ctx);
  * max_ctx > 1 on a whole-model context, the SECOND resident copy of the matrices in the MFMA B-operand image of the chunk
  * path (+7.2 GB at 7B, +13.9 GB at 14B). */
 uint64_t rwkv_resident_bytes(const rwkv_ctx *ctx);
-/* Bit mask of the decode kernel pairs this context runs as ONE launch with an in-kernel hand-off (csrc/fused.hip.h; env RWKV_FUSE
- * at load time): bit 0 = att_out + ffn r/k.  In rwkv_profile_* the pair is reported under the first kernel's class (2), class 3
- * then has no launch. */
-int rwkv_fused_pairs(const rwkv_ctx *ctx);
 /* Algorithmic HBM bytes of one token (13*L*D^2 + V*D uint8 weight bytes
  * + 168*L*D + 40*D bytes of vectors/state). */
 uint64_t rwkv_bytes_per_token(const rwkv_ctx *ctx);

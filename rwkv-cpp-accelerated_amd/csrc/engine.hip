@@ -5,7 +5,6 @@
 // engine: weights are re-tiled once at load, state and the embedding table stay resident on the
 // device, and one token is a replay of a captured hipGraph (4 launches per layer + 2).
 #include "kernels.hip.h"
-#include "fused.hip.h"
 #include "seq.hip.h"
 #include "sampler.hip.h"
 #include "../../include/rwkv_mi355x.h"
@@ -196,10 +195,6 @@ struct rwkv_ctx {
     // device error word: a mapped pinned word that a kernel raises when one of its bounded waits gave up (LDS ring hand-offs);
     // checked after every stream synchronisation (device_check)
     unsigned *herr = nullptr, *d_herr = nullptr;
-    // decode kernel pairs that run as ONE launch with an in-kernel hand-off (fused.hip.h): bit 0 = att_out + ffn r/k.
-    // env RWKV_FUSE; -1 = by model width
-    int fuse = -1;
-    unsigned *edge_cnt = nullptr;       // [layers of this stage][8 shards][16] arrival counters of the fused launches
     unsigned long long *tl = nullptr;   // phase-timeline buffer (debug), [grid][NW][8]
     bool tl_on = false;
     int tl_cls = 3;                     // kernel class the timeline instruments (env RWKV_TL_CLASS, 1..4)
@@ -263,9 +258,6 @@ int ring_slots(size_t fixed, int, int S)
 }
 size_t smem_ring(size_t fixed, int R, int S) { return fixed + sizeof(GldsCtl) + (size_t)ring_slots(fixed, R, S) * S * 1024; }
 
-#ifndef RWKV_FUSE_DEFAULT
-#define RWKV_FUSE_DEFAULT 0
-#endif
 #ifndef RWKV_ATTOUT_R
 #define RWKV_ATTOUT_R 2
 #endif
@@ -398,21 +390,10 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
     } break;
     case 2: {
         AttOutArgs ao = mk.attout(l);
-        if (c->fuse & 1) {      // att_out + ffn r/k as the two phases of one launch
-            FfnRKArgs fa = mk.frk(l);
-            const uint64_t nl = c->l1 - c->l0, li = l - c->l0;
-            const EdgeSync es{c->edge_cnt + li * 128, c->edge_cnt + ((li + nl - 1) % nl) * 128};
-            size_t fixed = 0;
-            DISPATCH_S(S, fixed = fuse_fixed<S_>());
-            ao.ns = fa.ns = ring_slots(fixed, 5, S);
-            DISPATCH_S(S, k_attout_ffn_rk<S_, ATTOUT_R><<<dim3(grid), dim3(NT), smem_ring(fixed, 5, S), c->stream>>>(ao, fa, es));
-            break;
-        }
         if (c->ring & 2) { ao.ns = ring_slots(smem_attout(S), ATTOUT_R, S); DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_attout(S), ATTOUT_R, S), c->stream>>>(ao)); }
         else DISPATCH_S(S, k_attout<S_, ATTOUT_R, nb_attout(S_)><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
     } break;
     case 3: {
-        if (c->fuse & 1) break;     // ran as the second phase of class 2's launch
         FfnRKArgs fa = mk.frk(l);
         if (c->ring & 4) { fa.ns = ring_slots(smem_frk(S), 5, S); DISPATCH_S(S, k_ffn_rk<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_frk(S), 5, S), c->stream>>>(fa)); }
         else DISPATCH_S(S, k_ffn_rk<S_, nb_frk(S_)><<<dim3(grid), dim3(NT), smem_frk(S), c->stream>>>(fa));
@@ -445,9 +426,8 @@ int device_check(rwkv_ctx *c)
     if (!c->herr || *c->herr == 0u) return 0;
     const unsigned code = *c->herr;
     *c->herr = 0u;
-    if (c->edge_cnt) { (void)hipMemsetAsync(c->edge_cnt, 0, sizeof(unsigned) * (c->l1 - c->l0) * 128, c->stream); (void)hipStreamSynchronize(c->stream); }
     return fail(RWKV_E_DEVICE, "a device-side wait gave up (code %u: LDS ring hand-off timed out; is the GPU shared or preempted?) -- "
-                               "the results of this call are invalid; RWKV_RING=0 RWKV_FUSE=0 select the register kernels, one launch each", code);
+                               "the results of this call are invalid; RWKV_RING=0 selects the register kernels", code);
 }
 
 // enqueue the kernels of one token on the context's stream.  ev: optional array of
@@ -548,7 +528,6 @@ int set_smem_limits(rwkv_ctx *c)
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, 1, true>, smem_ring(smem_fv(S), 4, S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, true>, smem_ring(smem_fv(S), 4, S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_head<S_, 1, true>, smem_ring(smem_head(S), RWKV_HEAD_RR, S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_attout_ffn_rk<S_, ATTOUT_R>, smem_ring(fuse_fixed<S_>(), 5, S))); if (rc) return rc;
     return 0;
 }
 
@@ -564,7 +543,6 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     HIPCHK(hipSetDevice(c->device));
     c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
     if (c->ring < 0) c->ring = (c->S == 3 || c->S == 4) ? 13 : (c->S == 5 ? 5 : 0);
-    if (c->fuse < 0) c->fuse = RWKV_FUSE_DEFAULT;
     if (c->l1 == UINT64_MAX) c->l1 = L;
     if (c->l0 >= c->l1 || c->l1 > L) return fail(RWKV_E_ARG, "layer range [%llu, %llu) does not fit a %llu-layer model", (unsigned long long)c->l0, (unsigned long long)c->l1, (unsigned long long)L);
     const uint64_t l0 = c->l0, l1 = c->l1, nl = l1 - l0;
@@ -689,9 +667,6 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if ((rc = dalloc(c, &c->ybuf, D))) return rc;
     if ((rc = dalloc(c, &c->hbuf, 4 * D))) return rc;
     if ((rc = dalloc(c, &c->rgate, D))) return rc;
-    if ((rc = dalloc(c, &c->edge_cnt, (size_t)nl * 128))) return rc;
-    HIPCHK(hipMemsetAsync(c->edge_cnt, 0, sizeof(unsigned) * nl * 128, c->stream));
-    if (nl < 2 || c->grid < 8) c->fuse = 0;      // a fused launch zeroes the PREVIOUS layer's counters; 8 shards
     if ((rc = dalloc(c, &c->partA, (size_t)c->grid))) return rc;
     if ((rc = dalloc(c, &c->partF, (size_t)c->grid))) return rc;
     if ((rc = dalloc(c, &c->partMA, (size_t)c->grid))) return rc;
@@ -996,7 +971,6 @@ int rwkv_create(rwkv_ctx **out, int device)
     const char *g = getenv("RWKV_GRID");
     if (g && atoi(g) > 0) c->grid = atoi(g);
     { const char *e = getenv("RWKV_RING"); if (e) c->ring = atoi(e); }
-    { const char *e = getenv("RWKV_FUSE"); if (e) c->fuse = atoi(e); }
     if (c->grid > NT / 2) c->grid = NT / 2;   // consumers sum one partial per thread of the prologue waves (half the workgroup)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(RWKV_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -1285,7 +1259,6 @@ float *rwkv_logits_device(rwkv_ctx *c) { return c ? c->logits : nullptr; }
 double *rwkv_state_device(rwkv_ctx *c, int which) { return (c && which >= 0 && which < 5) ? c->state[which] : nullptr; }
 void *rwkv_stream(rwkv_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int rwkv_abi_version(void) { return RWKV_MI355X_ABI_VERSION; }
-int rwkv_fused_pairs(const rwkv_ctx *c) { return c ? c->fuse : 0; }
 uint64_t rwkv_resident_bytes(const rwkv_ctx *c) { return c ? (uint64_t)c->alloc_bytes : 0; }
 
 uint64_t rwkv_bytes_per_token(const rwkv_ctx *c)
@@ -1332,10 +1305,6 @@ int rwkv_profile_token(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint64
     }
     if (launches) {
         launches[0] = 1; launches[1] = launches[2] = launches[3] = launches[4] = (uint32_t)(c->l1 - c->l0); launches[5] = 1; launches[6] = 1;
-    }
-    if (c->fuse & 1) {      // class 2 = att_out + ffn r/k in one launch, class 3 = nothing
-        if (bytes) { bytes[2] = 6 * D * D; bytes[3] = 0; }
-        if (launches) launches[3] = 0;
     }
     return rc;
 }

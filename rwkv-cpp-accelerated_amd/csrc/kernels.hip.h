@@ -375,8 +375,7 @@ __device__ __forceinline__ void site_prefetch(const SiteStatic &st, int j, SiteP
     for (int k = 0; k < PW / 4; k++) pre.p[k] = reinterpret_cast<const f32x4 *>(st.P + (size_t)j * PW)[k];
 }
 // row owner: emit B_m[j] and accumulate this thread's share of the workgroup tuple
-// SC: B goes out write-through (agent scope): its readers run in the SAME launch (fused.hip.h)
-template <int NV, bool SC = false>
+template <int NV>
 __device__ __forceinline__ void site_emit(const SitePre<NV> &pre, const SiteDyn &dy, int D, int j, double x, double prev, SiteAcc<NV> &acc)
 {
     acc.d[0] += x;
@@ -388,8 +387,7 @@ __device__ __forceinline__ void site_emit(const SitePre<NV> &pre, const SiteDyn 
         const float co = pre.p[(m * 5 + 2) >> 2][(m * 5 + 2) & 3];
         const float bol = pre.p[(m * 5 + 3) >> 2][(m * 5 + 3) & 3], bop = pre.p[(m * 5 + 4) >> 2][(m * 5 + 4) & 3];
         const float b = (float)((double)bl + (double)bp * prev);
-        if (SC) __hip_atomic_store(&dy.B[(size_t)m * D + j], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else dy.B[(size_t)m * D + j] = b;
+        dy.B[(size_t)m * D + j] = b;
         acc.d[2 + m] += (double)co * x;
         acc.d[5 + m] += (double)bol + (double)bop * prev;
         acc.f[1 + m] = fmaxf(acc.f[1 + m], fabsf(b));
@@ -879,10 +877,7 @@ struct GldsCtl {            // LDS control block of the ring (80 dwords)
     unsigned pad[2];
     unsigned freeq[GLDS_FQ];   // freeq[k % FQ] = k + 1: group k has been copied out of the ring
     unsigned gend[GLDS_FQ];    // the loader's own: end unit of group k
-    // two-phase kernels (fused.hip.h): consumer waves that have published their phase-1 outputs; the chip-wide hand-off has been
-    // seen by this workgroup's polling wave; prologue waves that have staged the phase-2 vectors; their reduction's meeting counter
-    unsigned pub, go, staged2, spin2;
-    unsigned pad2[8];
+    unsigned pad2[12];
 };
 constexpr int NC = NW - 1;              // consumer waves of a ring kernel
 
@@ -1007,12 +1002,10 @@ __device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_
     return ld.fail;
 }
 // consumer side of one group (kl = its index in the workgroup): wait, copy its R units into registers, hand them back
-// ubase / kbase: units and groups of the workgroup that precede this kernel phase's first group (two-phase kernels: 0 otherwise)
 template <int R, int S>
-__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, const unsigned char *ring, GldsCtl *ctl, int lane, unsigned &fail,
-                                          unsigned ubase = 0u, unsigned kbase = 0u)
+__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, const unsigned char *ring, GldsCtl *ctl, int lane, unsigned &fail)
 {
-    const unsigned uend = ubase + (unsigned)(kl + 1) * R;
+    const unsigned uend = (unsigned)(kl + 1) * R;
     bool ok = false;
     for (int it = 0; it < GLDS_SPIN; it++) {
         if ((int)(__hip_atomic_load(&ctl->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - uend) >= 0) { ok = true; break; }
@@ -1027,18 +1020,13 @@ __device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, cons
         for (int s = 0; s < S; s++) w[r][s] = p[s * 64];
         p0 = p0 + 1 == (unsigned)nu ? 0u : p0 + 1;
     }
-    if (lane == 0) __hip_atomic_store(&ctl->freeq[((unsigned)kl + kbase) % GLDS_FQ], (unsigned)kl + kbase + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(&ctl->freeq[kl % GLDS_FQ], (unsigned)kl + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // the consumer waves' streaming loop (wave < NC): same pre / epi contract as stream_groups
-struct NoGate { __device__ __forceinline__ void operator()() const {} };
-// gate(): called once, after the wave's FIRST group has been copied out of the ring and before its dot products (a two-phase
-// kernel's consumers take a group of phase 2 while the phase-2 vectors are still being staged: the ring turns over meanwhile)
-template <int R, int S, int PAT, class Pre, class Epi, class Gate = NoGate>
+template <int R, int S, int PAT, class Pre, class Epi>
 __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
-                                            int chunks, Pre pre, Epi epi, unsigned &fail, unsigned long long *g_tl_groups = nullptr,
-                                            unsigned ubase = 0u, unsigned kbase = 0u, Gate gate = Gate())
+                                            int chunks, Pre pre, Epi epi, unsigned &fail, unsigned long long *g_tl_groups = nullptr)
 {
-    bool first = true;
 #ifdef RWKV_TL_GROUPS
     // debug build (tools/timeline.py): where a consumer wave's time goes.  Stamps of the wave: 1 inputs of its first group requested,
     // 2 first group taken, 4 its dot products and reductions done, 3 its epilogue done (5 stays "staged", 6 / 7 the kernel's end)
@@ -1050,8 +1038,7 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
         if (rr == 0) tl_stamp(g_tl_groups, 1);
 #endif
         u32x4 w[R][S];
-        glds_take<R, S>(w, g - g0, nu, ring, ctl, lane, fail, ubase, kbase);
-        if (first) { gate(); first = false; }
+        glds_take<R, S>(w, g - g0, nu, ring, ctl, lane, fail);
 #ifdef RWKV_TL_GROUPS
         asm volatile("" : "+v"(w[R - 1][S - 1]));
         if (rr < 1) tl_stamp(g_tl_groups, 2);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "rwkv_create", "rwkv_load_file", "rwkv_load_tensors", "rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx",
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
-    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_fused_pairs", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
+    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
     "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode",
     "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device",
 ]
@@ -73,7 +73,6 @@ def lib():
     L.rwkv_debug_timeline.argtypes = [vp, u64, vp, u64]; L.rwkv_debug_timeline.restype = i32
     L.rwkv_abi_version.argtypes = []; L.rwkv_abi_version.restype = i32
     L.rwkv_resident_bytes.argtypes = [vp]; L.rwkv_resident_bytes.restype = u64
-    L.rwkv_fused_pairs.argtypes = [vp]; L.rwkv_fused_pairs.restype = i32
     if L.rwkv_abi_version() != ABI_VERSION:
         raise RWKVError(f"{LIB_PATH} has C-ABI version {L.rwkv_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
     L.rwkv_sample_typical.argtypes = [vp, u64, C.c_float, C.c_float, C.c_double, i32, C.POINTER(u64)]; L.rwkv_sample_typical.restype = i32
@@ -346,9 +345,6 @@ class RWKV:
         buf = np.zeros(512 * 8 * 8, dtype=np.uint64)
         _chk(lib().rwkv_debug_timeline(self._h, token, _ptr(buf), buf.size))
         return buf
-
-    def fused_pairs(self) -> int:
-        return int(lib().rwkv_fused_pairs(self._h))
 
     def resident_bytes(self) -> int:
         return int(lib().rwkv_resident_bytes(self._h))
