@@ -593,11 +593,21 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     }
     auto kclamp = [&](int c, int k) { const int n = min(NKB, nkb - c * NKB); return kb0 + c * NKB + (k < n ? k : (n > 0 ? n - 1 : 0)); };
     u32x4 bw[DB ? 2 : 1][NTW][NKB];
+    // MTS kernels (ffn k/r: two passes over the row tiles with the weights resident) work through their tiles in TWO BATCHES,
+    // [0, TB0) and [TB0, NTW): the loads are requested batch-major, so batch 0's second pass, epilogue and partial-value stores run
+    // under batch 1's weight stream instead of behind the whole stream (RWKV_SEQ_BATCH=0: one batch, as in round 2)
+#ifndef RWKV_SEQ_BATCH
+#define RWKV_SEQ_BATCH 1
+#endif
+    constexpr int TB0 = (RWKV_SEQ_BATCH && NTW >= 3) ? (NTW + 1) / 2 : NTW;        // (K/V/R, three tiles per wave and both row tiles at once: 2 + 1)
     auto load_b = [&](int set, int c) {
 #pragma unroll
-        for (int k = 0; k < NKB; k++)
+        for (int bt = 0; bt < 2; bt++)
 #pragma unroll
-            for (int i = 0; i < NTW; i++) bw[set][i][k] = __builtin_nontemporal_load(wt[i] + (size_t)min(kclamp(c, k), KB - 1) * 64);
+            for (int k = 0; k < NKB; k++)
+#pragma unroll
+                for (int i = 0; i < NTW; i++)
+                    if ((i < TB0) == (bt == 0)) bw[set][i][k] = __builtin_nontemporal_load(wt[i] + (size_t)min(kclamp(c, k), KB - 1) * 64);
     };
     // activation image of chunk c, vectors vlo .. vhi: units [(kb0 + c NKB) * 384, + n * 384) of each image are contiguous --
     // a straight copy, done by the DMA path (global_load_lds_dwordx4: 1 KiB per wave instruction, no registers, nothing to wait
@@ -640,9 +650,10 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
                 for (int b = 0; b < 3; b++) acc[i][mt][b] = i32x4{0, 0, 0, 0};
     };
     // per-slice value of tile i, row tile mt (accumulator set ms) -> pk, one coalesced 256-byte store per register
-    auto emit = [&](int mt, int ms) {
+    auto emit = [&](int mt, int ms, int i0 = 0, int i1 = NTW) {
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
+            if (i < i0 || i >= i1) continue;
             if (!tv[i]) continue;
             const int id = id0 + i;
             const double *rl = recl + 2 * ((size_t)vi[i] * SEQ_T + mt * 16 + 4 * (lane >> 4));
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     // the MFMAs of chunk c (weights in register set `set`, activation image in LDS buffer `buf`) for row tile(s) mt0 ..
     // The A fragments of a k-block are read from LDS once and kept while consecutive tiles use the same activation vector
     // (a wave's tiles are class-ordered; the re-read at a class change is a wave-uniform branch).
-    auto mult = [&](int set, int buf, int c, int mt0) {
+    auto mult = [&](int set, int buf, int c, int mt0, int i0 = 0, int i1 = NTW) {
         const int n = min(NKB, nkb - c * NKB);
         const u32x4 *ab = abuf + (size_t)buf * CHU + lane;
 #pragma unroll
@@ -670,10 +681,11 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
 #pragma unroll
                     for (int b = 0; b < 3; b++) av[ms][b] = ab[(((size_t)vv * NKB + k) * 2 + (MTS ? mt0 : ms)) * 3 * 64 + b * 64];
             };
-            read_a(vi[0]);
+            read_a(vi[i0]);
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                if (NVS > 1 && i > 0 && vi[i] != vi[i - 1]) read_a(vi[i]);
+                if (i < i0 || i >= i1) continue;
+                if (NVS > 1 && i > i0 && vi[i] != vi[i - 1]) read_a(vi[i]);
                 const u32x4 w = bw[set][i][k];
                 const i32x4 bf = i32x4{kv ? (int)w[0] : 0, kv ? (int)w[1] : 0, kv ? (int)w[2] : 0, kv ? (int)w[3] : 0};   // past the slice: zero weights
 #pragma unroll
@@ -688,11 +700,22 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
         }
     };
     if (MTS) {                        // single chunk: weights stay in registers for both row tiles
-        for (int mt = 0; mt < 2; mt++) {
-            zero_acc();
-            if (nchunk > 0) mult(0, 0, 0, mt);
-            emit(mt, 0);
+        if (TB0 < NTW) {
+            for (int mt = 0; mt < 2; mt++) { zero_acc(); if (nchunk > 0) mult(0, 0, 0, mt, 0, TB0); emit(mt, 0, 0, TB0); }
+            for (int mt = 0; mt < 2; mt++) { zero_acc(); if (nchunk > 0) mult(0, 0, 0, mt, TB0, NTW); emit(mt, 0, TB0, NTW); }
+        } else {
+            for (int mt = 0; mt < 2; mt++) {
+                zero_acc();
+                if (nchunk > 0) mult(0, 0, 0, mt);
+                emit(mt, 0);
+            }
         }
+    } else if (!DB && TB0 < NTW && nchunk == 1) {          // one chunk, weights in registers: batch 0's epilogue under batch 1's stream
+        zero_acc();
+        mult(0, 0, 0, 0, 0, TB0);
+        emit(0, 0, 0, TB0); emit(1, 1, 0, TB0);
+        mult(0, 0, 0, 0, TB0, NTW);
+        emit(0, 0, TB0, NTW); emit(1, 1, TB0, NTW);
     } else {
         zero_acc();
         for (int c = 0; c < nchunk; c++) {
