@@ -1327,20 +1327,30 @@ int rwkv_profile_batched(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint
     for (int cls = 0; cls < RWKV_N_KCLASS; cls++) {
         const bool per_layer = cls >= 1 && cls <= 4;
         // a class with ONE launch per token gets 8 x as many repetitions (4 launches in a bracket measured +10 % on k_head) and a
-        // warm-up launch; every launch of a class is preceded by the others of its batch only, so k_head's 206 MB are re-read from
-        // HBM each time (nt loads; the rocprofv3 duration of the same kernel inside the real token is the cross-check)
+        // warm-up launch.  k_head's 206 MB would stay in the 256 MiB Infinity Cache between back-to-back launches (33.6 us against
+        // 35.7 us inside the real token, rocprofv3): every head launch is preceded by ffn_v launches of four rotating layers (what a
+        // token puts in front of it) and the same sequence WITHOUT the head is timed as well; the difference is the head.
         const int nrep = per_layer ? reps : reps * 8;
-        launch_class(c, cls, per_layer ? c->l0 : 0);
-        HIPCHK(hipStreamSynchronize(c->stream));
-        HIPCHK(hipEventRecord(a, c->stream));
+        const uint64_t nl = c->l1 - c->l0;
+        const bool flush = cls == 5 && nl >= 4;
+        float t = 0.f, t0 = 0.f;
         uint32_t cnt = 0;
-        for (int r = 0; r < nrep; r++)
-            for (uint64_t l = (per_layer ? c->l0 : 0); l < (per_layer ? c->l1 : 1); l++) { launch_class(c, cls, l); cnt++; }
-        HIPCHK(hipEventRecord(b, c->stream));
-        HIPCHK(hipEventSynchronize(b));
-        float t = 0.f;
-        HIPCHK(hipEventElapsedTime(&t, a, b));
-        ms[cls] = (double)t; n[cls] = cnt;
+        for (int pass = flush ? 0 : 1; pass < 2; pass++) {      // pass 0: the flushing launches alone
+            launch_class(c, cls, per_layer ? c->l0 : 0);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipEventRecord(a, c->stream));
+            cnt = 0;
+            for (int r = 0; r < nrep; r++)
+                for (uint64_t l = (per_layer ? c->l0 : 0); l < (per_layer ? c->l1 : 1); l++) {
+                    if (flush) for (int q = 0; q < 4; q++) launch_class(c, 4, c->l0 + (uint64_t)(4 * r + q) % nl);
+                    if (pass == 1) launch_class(c, cls, l);
+                    cnt++;
+                }
+            HIPCHK(hipEventRecord(b, c->stream));
+            HIPCHK(hipEventSynchronize(b));
+            HIPCHK(hipEventElapsedTime(pass == 0 ? &t0 : &t, a, b));
+        }
+        ms[cls] = (double)(t - t0); n[cls] = cnt;
     }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     HIPCHK(hipGetLastError());
