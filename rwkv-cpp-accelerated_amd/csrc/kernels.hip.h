@@ -865,6 +865,11 @@ constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
 #ifndef RWKV_RING_PRE
 #define RWKV_RING_PRE 8
 #endif
+// TEST build only (tests/test_engine_gpu.py builds a variant with -DRWKV_TEST_DROP_GROUP=1): the loader "loses" every workgroup's last
+// group, so the consumers' bounded wait must give up and the call must fail with RWKV_E_DEVICE instead of returning garbage
+#ifndef RWKV_TEST_DROP_GROUP
+#define RWKV_TEST_DROP_GROUP 0
+#endif
 #ifndef RWKV_LOADER_PRIO
 #define RWKV_LOADER_PRIO 0        // s_setprio of the loader wave (0..3)
 #endif
@@ -997,7 +1002,7 @@ __device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_
     const int pre = RWKV_RING_PRE < nu - R ? RWKV_RING_PRE : nu - R;      // never wait for room before the barrier: the consumers are behind it
     for (; g < g1 && (int)ld.issued < pre; g++) ld.template group<R>(base(g) + ld.off[0], stride, true);
     __syncthreads();   // order: the control block is zero, the prologue's requests are in the pipe
-    for (; g < g1; g++) ld.template group<R>(base(g) + ld.off[0], stride);
+    for (; g < g1 - (RWKV_TEST_DROP_GROUP ? 1 : 0); g++) ld.template group<R>(base(g) + ld.off[0], stride);
     ld.finish();
     return ld.fail;
 }

@@ -83,3 +83,33 @@ def test_pybind_module_forward(built, tmp_path):
     rwkv.initState(h); rwkv.modelForward(h, 9)          # initState really resets the state forward() uses
     m.reset_state(); assert np.array_equal(rwkv.getOutput(h), m.forward(9)[: mf.VOCAB])
     rwkv.freeRwkv(h); m.close()
+
+
+@pytest.mark.gpu
+def test_pybind_module_two_models_side_by_side(built, tmp_path):
+    """reference bindings/pybind/c_binding.cpp:28-33: every initRwkv() hands out its own RWKV -- two different models alive in
+    one Python process through the module, forwards interleaved, one freed while the other goes on"""
+    sys.path.insert(0, CSRC)
+    import rwkv
+    from rwkv_cpp_accelerated_amd import engine
+    hs, ms = [], []
+    for (L, D, seed) in ((2, 768, 81), (3, 1024, 82)):
+        t = mf.synthetic_tensors(L, D, seed=seed)
+        p = str(tmp_path / f"m{seed}.bin")
+        mf.write_bin(p, L, D, t)
+        h = rwkv.initRwkv()
+        assert rwkv.loadModel(h, p) == (L, D)
+        rwkv.initOutput(h); rwkv.initState(h)
+        hs.append(h)
+        m = engine.RWKV(resident=True); m.loadFile(p)
+        ms.append(m)
+    for tk in (5, 50000, 17):
+        for h, m in zip(hs, ms):
+            rwkv.modelForward(h, tk)
+            assert np.array_equal(rwkv.getOutput(h), m.forward(tk)[: mf.VOCAB])
+    rwkv.freeRwkv(hs[0])
+    rwkv.modelForward(hs[1], 9)
+    assert np.array_equal(rwkv.getOutput(hs[1]), ms[1].forward(9)[: mf.VOCAB])
+    rwkv.freeRwkv(hs[1])
+    for m in ms:
+        m.close()

@@ -11,6 +11,7 @@ from rwkv_cpp_accelerated_amd import modelfile as mf
 import parity
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -387,3 +388,33 @@ def test_load_file_streams_through_pinned_staging(eng_mod, tmp_path):
         la = np.array(a.forward(tk)[: mf.VOCAB]); lb = np.array(b.forward(tk)[: mf.VOCAB])
         assert np.array_equal(la, lb)
     a.close(); b.close()
+
+
+def test_a_lost_ring_hand_off_fails_the_call_instead_of_returning_garbage(built, tmp_path):
+    """every wait of the LDS-ring kernels is bounded; one that gives up is recorded and reported (kernels.hip.h ring_report,
+    engine.hip device_check): a variant of the engine whose loader wave never issues a workgroup's last group
+    (-DRWKV_TEST_DROP_GROUP=1, built here with hipcc) must fail the forward with RWKV_E_DEVICE, and the context must be usable
+    for error reporting afterwards -- no hang, no silently wrong logits.  Runs in a subprocess (RWKV_LIB selects the variant)."""
+    import subprocess
+    import sys
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", "engine.hip")
+    lib = str(tmp_path / "lib_drop.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+                           "-DRWKV_TEST_DROP_GROUP=1", src, "-o", lib], timeout=600)
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch\n"
+        "from rwkv_cpp_accelerated_amd import engine, modelfile as mf\n"
+        "L, D = 2, 4096\n"
+        "m = engine.RWKV(resident=True); m.loadTensors(L, D, mf.synthetic_tensors(L, D, seed=5))\n"
+        "try:\n"
+        "    m.forward(7)\n"
+        "    print('NOERROR')\n"
+        "except engine.RWKVError as e:\n"
+        "    print('RWKVERROR', str(e)[-120:], '|', str(e)[:120])\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RWKV_LIB=lib, RWKV_RING="13"), capture_output=True, text=True, timeout=600)
+    assert "RWKVERROR" in out.stdout and "device-side wait gave up" in out.stdout and "status -3" in out.stdout, out.stdout[-400:] + out.stderr[-400:]
