@@ -156,7 +156,10 @@ def main():
                 method="algorithmic uint8 weight bytes of one launch / average launch duration; duration = one hipEvent pair "
                        "around a batch of back-to-back launches of the kernel (all layers x reps) on the engine stream, "
                        "right after the timed region; `traffic` is NOT a counter of this run: it is the committed figure of the "
-                       "separate rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), see traffic_source")
+                       "separate rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), see traffic_source.  With the carry on "
+                       "(7B default, DESIGN.md 4.5) a launch's first 32-40 KiB per workgroup were streamed by its predecessor's loader "
+                       "and it streams as much for its successor: the batch chains launches of one class the same way, so a launch "
+                       "still moves its algorithmic bytes")
     # `traffic`: HBM read bytes per launch of the dominant kernel from the round's own rocprofv3 --pmc FETCH_SIZE pass
     # (tools/gpu_round.sh writes profiles/<round>/hbm_traffic.json together with the sha256 of the kernel source it profiled);
     # a figure collected for ANOTHER kernels.hip.h is not quoted
@@ -186,6 +189,9 @@ def main():
         kernels={k: dict(us=round(v["us"], 3), GBps=round(v["gbps"], 1), us_event_pair=round(v["us_event_pair"], 3))
                  for k, v in per_launch.items()},
         load_s=round(load_s, 2),
+        carry=dict(RWKV_CARRY=os.environ.get("RWKV_CARRY", "default: 32 KiB per workgroup where rows are 4 KiB (7B), else off"),
+                   note="ring kernels leave the first rows of the next ring kernel in the CU's LDS across the kernel boundary; "
+                        "checked against their row sums before use (DESIGN.md 4.5; 7B: 565 -> 572 tokens/s, profiles/r03/carry.txt)"),
         hbm_resident_bytes=dict(total=m.resident_bytes(),
                                 note="device bytes of this context: decode-layout weights + embedding + state + scratch"
                                      + (", plus the SECOND copy of the matrices in the MFMA B-operand image of the chunk path "

@@ -179,6 +179,10 @@ void *rwkv_stream(rwkv_ctx *ctx);
  * max_ctx > 1 on a whole-model context, the SECOND resident copy of the matrices in the MFMA B-operand image of the chunk
  * path (+7.2 GB at 7B, +13.9 GB at 14B). */
 uint64_t rwkv_resident_bytes(const rwkv_ctx *ctx);
+/* debug: with RWKV_CARRY_COUNT=1 in the environment at load time, out2[0] / out2[1] = workgroup launches of the decode kernels that
+ * found / did not find, in their CU's LDS, the first weight rows their predecessor was asked to leave there;
+ * counted since the previous call. */
+int rwkv_debug_carry_hits(rwkv_ctx *ctx, uint64_t *out2);
 /* Algorithmic HBM bytes of one token (13*L*D^2 + V*D uint8 weight bytes
  * + 168*L*D + 40*D bytes of vectors/state). */
 uint64_t rwkv_bytes_per_token(const rwkv_ctx *ctx);

@@ -12,6 +12,9 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <unistd.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -158,6 +161,11 @@ struct rwkv_ctx {
     uint64_t L = 0, D = 0, maxT = 1;
     uint64_t l0 = 0, l1 = UINT64_MAX;   // pipeline stage: this context owns layers [l0, l1) (whole model by default)
     int S = 0;               // ceil(D / 1024): 1 KiB row pieces per lane
+    int carry_kib = -1;      // ring kernels: KiB of the NEXT ring kernel's rows a workgroup's loader leaves in LDS (kernels.hip.h "CARRY"; env RWKV_CARRY, 0 = off;
+                             // default: 32 where it pays -- 4 KiB rows (7B: +1.3 %; 3B -1.3 %, 14B -2.6 %: profiles/r03/carry.txt) -- else 0)
+    int carry_edges = 7;     //   which boundaries: bit 0 k_att -> (k_attout) -> k_ffn_rk, 1 k_ffn_rk -> k_ffnv, 2 k_ffnv -> k_att of the next layer (env RWKV_CARRY_EDGES)
+    unsigned nonce[2] = {0u, 0u};   //   stamp of this context's carried rows
+    unsigned *carry_hits = nullptr; //   debug counters (env RWKV_CARRY_COUNT=1; rwkv_debug_carry_hits)
     int ring = RWKV_RING;    // decode kernels that stream their weights through the LDS ring (bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv, 4 k_head; env RWKV_RING)
 
     // weights (device)
@@ -257,6 +265,11 @@ int ring_slots(size_t fixed, int, int S)
     return (int)((LDS_BYTES - fixed - sizeof(GldsCtl)) / ((size_t)S * 1024));
 }
 size_t smem_ring(size_t fixed, int R, int S) { return fixed + sizeof(GldsCtl) + (size_t)ring_slots(fixed, R, S) * S * 1024; }
+// k_att / k_ffn_rk / k_ffnv in ring form: [scratch][control block][ring][nv staged vectors]; `common`: the geometry all three share
+// when rows are carried across their boundaries (sized for k_ffnv's four vectors)
+int ring_units(int nv, int S, bool common) { return (int)((LDS_BYTES - RED_BYTES - sizeof(GldsCtl) - (size_t)(common ? 4 : nv) * S * 3072) / ((size_t)S * 1024)); }
+int ring_xq_bytes(int nv, int S, bool common) { return (common ? 4 : nv) * S * 3072; }
+size_t smem_ring3(int nv, int S, bool common) { return RED_BYTES + (size_t)ring_xq_bytes(nv, S, common) + sizeof(GldsCtl) + (size_t)ring_units(nv, S, common) * S * 1024; }
 
 #ifndef RWKV_ATTOUT_R
 #define RWKV_ATTOUT_R 2
@@ -288,9 +301,78 @@ struct ArgMaker {
     rwkv_ctx *c;
     int D, grid, n_first;
     size_t LD;
-    explicit ArgMaker(rwkv_ctx *c_) : c(c_), D((int)c_->D), grid(c_->grid), LD((size_t)c_->L * c_->D)
+    bool chain;      // profiling batches: launches of ONE class, layer after layer (each carries rows for the same class of the next layer)
+    bool common;     // the ring kernels share one ring geometry: rows are carried across their boundaries (kernels.hip.h "CARRY")
+    explicit ArgMaker(rwkv_ctx *c_, bool chain_ = false) : c(c_), D((int)c_->D), grid(c_->grid), LD((size_t)c_->L * c_->D), chain(chain_)
     {
         n_first = grid < 32 ? grid : 32;
+        common = c->carry_kib > 0 && c->carry_edges != 0 && D % grid == 0 && D / grid >= 2 && (c->ring & 13) != 0;
+    }
+    // ---- the carry plan: who streams the first rows of whom ----
+    static int rows_of(int cls) { return cls == 1 ? 3 : cls == 3 ? 5 : 4; }
+    static int nv_of(int cls) { return cls == 1 ? 3 : cls == 3 ? 2 : 4; }
+    bool ring_cls(int cls) const { return cls == 1 ? (c->ring & 1) != 0 : cls == 3 ? (c->ring & 4) != 0 : cls == 4 ? (c->ring & 8) != 0 : false; }
+    int units() const { return ring_units(0, c->S, true); }
+    // the ring kernel that runs behind (cls, l) and takes rows from it
+    bool next_of(int cls, uint64_t l, bool as_chain, int &cls2, uint64_t &l2) const
+    {
+        if (!common || !ring_cls(cls)) return false;
+        const int e = c->carry_edges;
+        if (as_chain) {
+            const int bit = cls == 3 ? 1 : cls == 4 ? 2 : 4;      // the class's in-edge in token order
+            cls2 = cls; l2 = l + 1;
+            return (e & bit) && l2 < c->l1 && (cls != 3 || !(c->ring & 2));
+        }
+        if (cls == 1) { cls2 = 3; l2 = l; return (e & 1) && !(c->ring & 2) && ring_cls(3); }      // across k_attout in register form: its one staged vector
+                                                                                                  // sits where the ring kernels stage theirs, below the ring
+        if (cls == 3) { cls2 = 4; l2 = l; return (e & 2) && ring_cls(4); }
+        cls2 = 1; l2 = l + 1;
+        return (e & 4) && l2 < c->l1 && ring_cls(1);
+    }
+    bool prev_of(int cls, uint64_t l, bool as_chain, int &cls0, uint64_t &l0_) const
+    {
+        if (!common || !ring_cls(cls)) return false;
+        if (as_chain) { cls0 = cls; l0_ = l - 1; }
+        else if (cls == 1) { cls0 = 4; l0_ = l - 1; }
+        else if (cls == 3) { cls0 = 1; l0_ = l; }
+        else { cls0 = 3; l0_ = l; }
+        if ((cls0 == 4 || as_chain) && l == c->l0) return false;
+        int cb; uint64_t lb;
+        return next_of(cls0, l0_, as_chain, cb, lb) && cb == cls && lb == l;
+    }
+    int carry_groups(int cls) const      // groups of class `cls` that travel: ~carry_kib, at least one, at most half a workgroup's share and half the ring
+    {
+        const int per = rows_of(cls) * c->S, G = D / grid;
+        int n = (c->carry_kib + per / 2) / per;
+        n = std::max(n, 1);
+        n = std::min(n, std::min(G / 2, units() / (2 * rows_of(cls))));
+        return std::max(n, 0);
+    }
+    const uint8_t *weights_of(int cls, uint64_t l) const
+    {
+        const size_t lr = (size_t)(l - c->l0);
+        return cls == 1 ? c->w_kvr + lr * 3 * D * D : cls == 3 ? c->w_frk + lr * 5 * D * D : c->w_fv + lr * 4 * D * D;
+    }
+    RingCarry carry(int cls, uint64_t l) const
+    {
+        RingCarry cy{};
+        cy.xq_bytes = ring_xq_bytes(nv_of(cls), c->S, common);
+        cy.hits = c->carry_hits;
+        if (!common) return cy;
+        const int G = D / grid, nu = units();
+        const uint64_t lr = l - c->l0;
+        const uint64_t before = chain ? lr * (uint64_t)G * rows_of(cls) : lr * 12u * G + (cls == 1 ? 0 : cls == 3 ? 3 * G : 8 * G);
+        cy.pos0 = (int)(before % (uint64_t)nu);
+        int c2; uint64_t l2;
+        if (next_of(cls, l, chain, c2, l2) && carry_groups(c2) > 0) {
+            cy.w_next = weights_of(c2, l2); cy.rows_next = rows_of(c2); cy.n_out = carry_groups(c2);
+            cy.tag_out[0] = c->nonce[0]; cy.tag_out[1] = c->nonce[1] ^ (unsigned)(l2 * 8 + (uint64_t)c2);
+        }
+        if (prev_of(cls, l, chain, c2, l2) && carry_groups(cls) > 0) {
+            cy.n_in = carry_groups(cls);
+            cy.tag_in[0] = c->nonce[0]; cy.tag_in[1] = c->nonce[1] ^ (unsigned)(l * 8 + (uint64_t)cls);
+        }
+        return cy;
     }
     unsigned long long *tl_of(int k, uint64_t l) const { return (c->tl_on && k == c->tl_cls && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr; }
     SiteStatic site_static(int k, uint64_t ll) const
@@ -325,7 +407,7 @@ struct ArgMaker {
         aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
         aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
         aa.slot_stride = LD; aa.ybuf = c->ybuf; aa.partS = c->partA; aa.partM = c->partMA;
-        aa.ctl = c->ctl; aa.D = D; aa.ns = 0; aa.tl = tl_of(1, l); aa.herr = c->d_herr;
+        aa.ctl = c->ctl; aa.D = D; aa.ns = 0; aa.tl = tl_of(1, l); aa.herr = c->d_herr; aa.cy = carry(1, l);
         return aa;
     }
     AttOutArgs attout(uint64_t l) const
@@ -346,7 +428,7 @@ struct ArgMaker {
         fa.w = c->w_frk + (size_t)(l - c->l0) * 5 * D * D; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5;
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.partM = c->partMF; fa.ctl = c->ctl; fa.D = D;
-        fa.ns = 0; fa.tl = tl_of(3, l); fa.herr = c->d_herr;
+        fa.ns = 0; fa.tl = tl_of(3, l); fa.herr = c->d_herr; fa.cy = carry(3, l);
         return fa;
     }
     // the site ffn_v opens: ln1 of layer l + 1 (3 vectors), or ln_out -> head after the stage's last layer (on a non-final
@@ -359,7 +441,7 @@ struct ArgMaker {
         fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
         fv.rgate = c->rgate; fv.x = c->x; fv.lnw = c->ln + (4 * l + 4) * D; fv.lnb = c->ln + (4 * l + 5) * D; fv.lnstat = c->lnstat + 2;
         fv.sdd = c->state[4] + lo; fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D; fv.tl = tl_of(4, l);
-        fv.ns = 0; fv.herr = c->d_herr;
+        fv.ns = 0; fv.herr = c->d_herr; fv.cy = carry(4, l);
         if (fv_next_att(l)) { fv.st = site_static(0, l + 1); fv.dy = site_dyn(0, grid); fv.sprev = c->state[0] + lo + D; }
         else { fv.st = site_static(2, 0); fv.dy = site_dyn(2, grid); fv.sprev = nullptr; }
         return fv;
@@ -374,10 +456,10 @@ struct ArgMaker {
 };
 
 // ---- one launch helper per kernel class (0 embed, 1 att, 2 att_out, 3 ffn_rk, 4 ffn_v, 5 head, 6 argmax) ----
-void launch_class(rwkv_ctx *c, int cls, uint64_t l)
+void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
 {
     const int S = c->S, grid = c->grid;
-    const ArgMaker mk(c);
+    const ArgMaker mk(c, chain);
     switch (cls) {
     case 0: {
         FirstArgs fa = mk.first();
@@ -385,33 +467,47 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l)
     } break;
     case 1: {
         AttArgs aa = mk.att(l);
-        if (c->ring & 1) { aa.ns = ring_slots(smem_att(S), 3, S); DISPATCH_S(S, k_att<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_att(S), 3, S), c->stream>>>(aa)); }
+        if (c->ring & 1) {
+            aa.ns = ring_units(3, S, mk.common);
+            if (mk.common) DISPATCH_S(S, k_att<S_, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(3, S, true), c->stream>>>(aa))
+            else DISPATCH_S(S, k_att<S_, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(3, S, false), c->stream>>>(aa));
+        }
         else DISPATCH_S(S, k_att<S_, nb_att(S_)><<<dim3(grid), dim3(NT), smem_att(S), c->stream>>>(aa));
     } break;
     case 2: {
         AttOutArgs ao = mk.attout(l);
-        if (c->ring & 2) { ao.ns = ring_slots(smem_attout(S), ATTOUT_R, S); DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_attout(S), ATTOUT_R, S), c->stream>>>(ao)); }
+        if (c->ring & 2) { ao.ns = ring_slots(smem_attout(S), ATTOUT_R, S); DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, 1><<<dim3(grid), dim3(NT), smem_ring(smem_attout(S), ATTOUT_R, S), c->stream>>>(ao)); }
         else DISPATCH_S(S, k_attout<S_, ATTOUT_R, nb_attout(S_)><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
     } break;
     case 3: {
         FfnRKArgs fa = mk.frk(l);
-        if (c->ring & 4) { fa.ns = ring_slots(smem_frk(S), 5, S); DISPATCH_S(S, k_ffn_rk<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_frk(S), 5, S), c->stream>>>(fa)); }
+        if (c->ring & 4) {
+            fa.ns = ring_units(2, S, mk.common);
+            if (mk.common) DISPATCH_S(S, k_ffn_rk<S_, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(2, S, true), c->stream>>>(fa))
+            else DISPATCH_S(S, k_ffn_rk<S_, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(2, S, false), c->stream>>>(fa));
+        }
         else DISPATCH_S(S, k_ffn_rk<S_, nb_frk(S_)><<<dim3(grid), dim3(NT), smem_frk(S), c->stream>>>(fa));
     } break;
     case 4: {
         FfnVArgs fv = mk.fv(l);
-        fv.ns = ring_slots(smem_fv(S), 4, S);
+        fv.ns = ring_units(4, S, mk.common);
         if (mk.fv_next_att(l)) {
-            if (c->ring & 8) { DISPATCH_S(S, k_ffnv<S_, 3, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_fv(S), 4, S), c->stream>>>(fv)); }
+            if (c->ring & 8) {
+                if (mk.common) DISPATCH_S(S, k_ffnv<S_, 3, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(4, S, true), c->stream>>>(fv))
+                else DISPATCH_S(S, k_ffnv<S_, 3, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(4, S, false), c->stream>>>(fv));
+            }
             else DISPATCH_S(S, k_ffnv<S_, 3, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
         } else {
-            if (c->ring & 8) { DISPATCH_S(S, k_ffnv<S_, 1, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_fv(S), 4, S), c->stream>>>(fv)); }
+            if (c->ring & 8) {
+                if (mk.common) DISPATCH_S(S, k_ffnv<S_, 1, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(4, S, true), c->stream>>>(fv))
+                else DISPATCH_S(S, k_ffnv<S_, 1, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(4, S, false), c->stream>>>(fv));
+            }
             else DISPATCH_S(S, k_ffnv<S_, 1, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
         }
     } break;
     case 5: {
         HeadArgs ha = mk.head();
-        if (c->ring & 16) { ha.ns = ring_slots(smem_head(S), RWKV_HEAD_RR, S); DISPATCH_S(S, k_head<S_, 1, true><<<dim3(grid), dim3(NT), smem_ring(smem_head(S), RWKV_HEAD_RR, S), c->stream>>>(ha)); }
+        if (c->ring & 16) { ha.ns = ring_slots(smem_head(S), RWKV_HEAD_RR, S); DISPATCH_S(S, k_head<S_, 1, 1><<<dim3(grid), dim3(NT), smem_ring(smem_head(S), RWKV_HEAD_RR, S), c->stream>>>(ha)); }
         else DISPATCH_S(S, k_head<S_, nb_head(S_)><<<dim3(grid), dim3(NT), smem_head(S), c->stream>>>(ha));
     } break;
     default:
@@ -426,6 +522,9 @@ int device_check(rwkv_ctx *c)
     if (!c->herr || *c->herr == 0u) return 0;
     const unsigned code = *c->herr;
     *c->herr = 0u;
+    if (code == 5u)
+        return fail(RWKV_E_DEVICE, "weight rows carried across a kernel boundary in LDS arrived damaged (code 5: another process's kernel had the CU in between?) -- "
+                                   "the results of this call are invalid; RWKV_CARRY=0 turns the carry off");
     return fail(RWKV_E_DEVICE, "a device-side wait gave up (code %u: LDS ring hand-off timed out; is the GPU shared or preempted?) -- "
                                "the results of this call are invalid; RWKV_RING=0 selects the register kernels", code);
 }
@@ -522,12 +621,16 @@ int set_smem_limits(rwkv_ctx *c)
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, nb_fv(S_)>, smem_fv(S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, nb_fv(S_)>, smem_fv(S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_head<S_, nb_head(S_)>, smem_head(S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_att<S_, 1, true>, smem_ring(smem_att(S), 3, S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R, 1, true>, smem_ring(smem_attout(S), ATTOUT_R, S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_, 1, true>, smem_ring(smem_frk(S), 5, S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, 1, true>, smem_ring(smem_fv(S), 4, S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, true>, smem_ring(smem_fv(S), 4, S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_head<S_, 1, true>, smem_ring(smem_head(S), RWKV_HEAD_RR, S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_att<S_, 1, 1>, smem_ring3(3, S, false))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_att<S_, 1, 2>, smem_ring3(3, S, true))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R, 1, 1>, smem_ring(smem_attout(S), ATTOUT_R, S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_, 1, 1>, smem_ring3(2, S, false))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_, 1, 2>, smem_ring3(2, S, true))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, 1, 1>, smem_ring3(4, S, false))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, 1, 2>, smem_ring3(4, S, true))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, 1>, smem_ring3(4, S, false))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, 2>, smem_ring3(4, S, true))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_head<S_, 1, 1>, smem_ring(smem_head(S), RWKV_HEAD_RR, S))); if (rc) return rc;
     return 0;
 }
 
@@ -543,7 +646,13 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     HIPCHK(hipSetDevice(c->device));
     c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
     if (c->ring < 0) c->ring = (c->S == 3 || c->S == 4) ? 13 : (c->S == 5 ? 5 : 0);
+    if (c->carry_kib < 0) c->carry_kib = c->S == 4 ? 32 : 0;
     if (c->l1 == UINT64_MAX) c->l1 = L;
+    if (getenv("RWKV_CARRY_COUNT") && !c->carry_hits) {
+        int rcc = dalloc(c, &c->carry_hits, 4);
+        if (rcc) return rcc;
+        HIPCHK(hipMemset(c->carry_hits, 0, 16));
+    }
     if (c->l0 >= c->l1 || c->l1 > L) return fail(RWKV_E_ARG, "layer range [%llu, %llu) does not fit a %llu-layer model", (unsigned long long)c->l0, (unsigned long long)c->l1, (unsigned long long)L);
     const uint64_t l0 = c->l0, l1 = c->l1, nl = l1 - l0;
     const bool first = l0 == 0, last = l1 == L;
@@ -971,6 +1080,14 @@ int rwkv_create(rwkv_ctx **out, int device)
     const char *g = getenv("RWKV_GRID");
     if (g && atoi(g) > 0) c->grid = atoi(g);
     { const char *e = getenv("RWKV_RING"); if (e) c->ring = atoi(e); }
+    { const char *e = getenv("RWKV_CARRY"); if (e) c->carry_kib = atoi(e); }
+    { const char *e = getenv("RWKV_CARRY_EDGES"); if (e) c->carry_edges = atoi(e); }
+    {
+        static std::atomic<unsigned> serial{0u};
+        const unsigned long long t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((unsigned long long)(uintptr_t)c << 17);
+        c->nonce[0] = 0x52574b56u ^ (unsigned)(t * 0x9e3779b97f4a7c15ull >> 32) ^ (++serial << 24);
+        c->nonce[1] = (unsigned)((t ^ (unsigned long long)getpid()) * 0xbf58476d1ce4e5b9ull >> 29);
+    }
     if (c->grid > NT / 2) c->grid = NT / 2;   // consumers sum one partial per thread of the prologue waves (half the workgroup)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(RWKV_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -1261,6 +1378,22 @@ void *rwkv_stream(rwkv_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int rwkv_abi_version(void) { return RWKV_MI355X_ABI_VERSION; }
 uint64_t rwkv_resident_bytes(const rwkv_ctx *c) { return c ? (uint64_t)c->alloc_bytes : 0; }
 
+// debug (RWKV_CARRY_COUNT=1 at load): workgroup launches that found / did not find the rows their predecessor was asked to leave
+// in LDS since the last call
+int rwkv_debug_carry_hits(rwkv_ctx *c, uint64_t *out2)
+{
+    if (!c || !out2) return fail(RWKV_E_ARG, "NULL argument");
+    out2[0] = out2[1] = 0;
+    if (!c->carry_hits) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned h[2] = {0u, 0u};
+    HIPCHK(hipMemcpy(h, c->carry_hits, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(c->carry_hits, 0, 8));
+    out2[0] = h[0]; out2[1] = h[1];
+    return 0;
+}
+
 uint64_t rwkv_bytes_per_token(const rwkv_ctx *c)
 {
     if (!c) return 0;
@@ -1336,14 +1469,14 @@ int rwkv_profile_batched(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint
         float t = 0.f, t0 = 0.f;
         uint32_t cnt = 0;
         for (int pass = flush ? 0 : 1; pass < 2; pass++) {      // pass 0: the flushing launches alone
-            launch_class(c, cls, per_layer ? c->l0 : 0);
+            launch_class(c, cls, per_layer ? c->l0 : 0, per_layer);
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipEventRecord(a, c->stream));
             cnt = 0;
             for (int r = 0; r < nrep; r++)
                 for (uint64_t l = (per_layer ? c->l0 : 0); l < (per_layer ? c->l1 : 1); l++) {
                     if (flush) for (int q = 0; q < 4; q++) launch_class(c, 4, c->l0 + (uint64_t)(4 * r + q) % nl);
-                    if (pass == 1) launch_class(c, cls, l);
+                    if (pass == 1) launch_class(c, cls, l, per_layer);
                     cnt++;
                 }
             HIPCHK(hipEventRecord(b, c->stream));

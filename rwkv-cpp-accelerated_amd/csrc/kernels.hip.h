@@ -835,7 +835,8 @@ constexpr int GLDS_SPIN = 1 << 18;    // bound of every wait loop (a lost hand-o
 // is path-insensitive, and the loader wave's instruction count is the stream's ceiling) and REPORTED once per wave, behind the
 // kernel's closing barrier (ring_report), to the context's error word (mapped host memory; engine.hip device_check reads it after
 // the stream synchronisation and fails the call with RWKV_E_DEVICE): the kernel still ends, but nobody is handed its results.
-// codes: 1 loader found no room, 2 a group never landed, 3 the prologue never staged, 4 the loader's own DMA never completed
+// codes: 1 loader found no room, 2 a group never landed, 3 the prologue never staged, 4 the loader's own DMA never completed,
+// 5 rows carried over from the previous kernel do not add up to their row sums (ring_groups)
 __device__ __forceinline__ void wait_count(const unsigned *p, unsigned least, unsigned &fail)
 {
     bool ok = false;
@@ -870,6 +871,14 @@ constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
 #ifndef RWKV_TEST_DROP_GROUP
 #define RWKV_TEST_DROP_GROUP 0
 #endif
+// TEST build only (-DRWKV_TEST_CORRUPT_CARRY=1): the loader flips one bit of the rows it carries for the next kernel, whose consumers
+// must notice (code 5) and fail the call
+#ifndef RWKV_CARRY_VERIFY
+#define RWKV_CARRY_VERIFY 1      // A/B knob: check carried rows against their row sums
+#endif
+#ifndef RWKV_TEST_CORRUPT_CARRY
+#define RWKV_TEST_CORRUPT_CARRY 0
+#endif
 #ifndef RWKV_LOADER_PRIO
 #define RWKV_LOADER_PRIO 0        // s_setprio of the loader wave (0..3)
 #endif
@@ -879,12 +888,37 @@ constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
 struct GldsCtl {            // LDS control block of the ring (80 dwords)
     unsigned staged;        // prologue waves that have staged their part of the vector
     unsigned landed;        // ring units (rows of S KiB) whose DMA has completed: loader -> consumers, monotonic
-    unsigned pad[2];
+    unsigned carried;       // groups at the head of the workgroup's share that the PREVIOUS kernel's loader left in the ring (carry)
+    unsigned pad[1];
     unsigned freeq[GLDS_FQ];   // freeq[k % FQ] = k + 1: group k has been copied out of the ring
     unsigned gend[GLDS_FQ];    // the loader's own: end unit of group k
-    unsigned pad2[12];
+    unsigned stamp[4];         // carry (below): what the previous ring kernel left in the ring for this workgroup
+    unsigned pad2[8];
+};
+// CARRY: the weight stream does not stop at the kernel boundary.  Weights do not depend on activations, a CU's LDS keeps its content
+// from one kernel to the next, and with one whole-LDS workgroup per CU block b of launch N + 1 lands on the CU block b of launch N
+// ran on (tools/ldskeep.hip, profiles/r03/ldskeep.txt: 256 / 256 blocks, every word intact, launch after launch and inside a
+// hipGraph; a kernel with a small allocation in between overwrites exactly its own allocation at the bottom of the LDS).  So the
+// loader of ring kernel N, behind its own last row, goes on with the first `n_out` groups of the NEXT ring kernel's share of this
+// workgroup -- the rows land in the ring while this workgroup's consumers finish their last groups and the slower workgroups
+// their streams, i.e. in the microseconds in which HBM used to idle -- and, when they have landed, leaves a stamp in the control
+// block: {context nonce, launch id of the consumer, block, groups}.  The loader of kernel N + 1 reads the stamp before it clears
+// the control block: if it is the one it expects, the ring already holds its first groups (all ring kernels of a model share ONE
+// ring geometry: same control block address -- behind room for the LARGEST set of staged vectors --, same unit size and count; the ring position simply carries on), it announces
+// them as landed and starts its stream behind them; if not -- another kernel ran on the CU in between, the block landed elsewhere
+// -- it loads everything as before.  Every ring kernel clears the stamp on entry, so one is only ever alive between two adjacent
+// kernels of one graph replay; the weights behind it are immutable for the life of the context.
+struct RingCarry {
+    const uint8_t *w_next;      // the next ring kernel's weights: its group g = rows_next rows of D bytes from w_next + g * rows_next * D
+    int rows_next, n_out;       // prefetch n_out groups of rows_next rows for it (0: none)
+    int n_in;                   // groups the previous ring kernel was asked to leave for this one
+    unsigned tag_in[2], tag_out[2];
+    int pos0;                   // ring position of this kernel's first unit
+    unsigned *hits;             // debug (RWKV_CARRY_COUNT=1): [0] workgroups that found their rows, [1] that did not
+    int xq_bytes;               // LDS reserved for the staged vectors in front of the control block (the same for all kernels that carry)
 };
 constexpr int NC = NW - 1;              // consumer waves of a ring kernel
+// LDS of k_att / k_ffn_rk / k_ffnv in ring form: [reduction scratch RED_BYTES][staged vectors: cy.xq_bytes][GldsCtl][ring: ns units of S KiB]
 
 // The loader wave.  The ring is made of `nu` UNITS of one row (S KiB) each; a group of R rows takes the next R units (wrapping),
 // so slots of every group size share one ring and the LDS is used to the last 4 KiB.  Round 2's first loader handed out whole
@@ -905,13 +939,13 @@ template <int S> struct RingLoader {
     unsigned issued = 0, pub = 0;       // units issued / announced as landed
     unsigned k = 0, tail = 0;           // groups issued / groups known to be copied out
     unsigned tailu = 0;                 // first unit still in use
-    unsigned pos = 0;                   // ring position of the next unit
+    unsigned pos;                       // ring position of the next unit
     int lane;
     bool dead = false;
     unsigned fail = 0;                  // see wait_count
 
-    __device__ __forceinline__ RingLoader(GldsCtl *mc_, unsigned ring_, int nu_, int chunks, int lane_)
-        : mc(mc_), ring((unsigned)__builtin_amdgcn_readfirstlane((int)ring_)), nu((unsigned)nu_), lane(lane_)
+    __device__ __forceinline__ RingLoader(GldsCtl *mc_, unsigned ring_, int nu_, int chunks, int lane_, int pos0 = 0)
+        : mc(mc_), ring((unsigned)__builtin_amdgcn_readfirstlane((int)ring_)), nu((unsigned)nu_), pos((unsigned)pos0), lane(lane_)
     {
         asm volatile("" : "+s"(ring));      // an opaque SGPR value (else the generic -> LDS address conversion is redone at every use)
         whole = chunks == 64 * S;
@@ -979,6 +1013,35 @@ template <int S> struct RingLoader {
         k++;
         poll_landed();
     }
+    // the first n groups of R rows are in the ring already (carry): book them as issued and landed.  Before the order barrier.
+    template <int R> __device__ __forceinline__ void adopt(unsigned n)
+    {
+        if ((unsigned)lane < n) mc->gend[lane] = ((unsigned)lane + 1u) * R;
+        issued = n * R; pub = issued; k = n;
+        pos = (pos + issued) % nu;
+        if (lane == 0) { mc->landed = issued; mc->carried = n; }
+    }
+    // one more row behind the workgroup's own groups (carry): a unit that no consumer of THIS kernel takes
+    __device__ __forceinline__ void row(const uint8_t *src)
+    {
+        for (int it = 0; !room<1>() && !dead; it++) {
+            advance_tail();
+            if (room<1>()) break;
+            poll_landed();
+            if (it >= GLDS_SPIN) { dead = true; fail = 1u; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        wait_vm<(RWKV_RING_DEPTH < 63 ? RWKV_RING_DEPTH : 63) - S>();
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring + pos * (unsigned)(S * 1024)));
+        if (whole) dma_unit<S>(src, dst);
+        else {
+#pragma unroll
+            for (int s = 0; s < S; s++) dma_piece(src + (off[s] - off[0]), dst + s * 1024);
+        }
+        pos = pos + 1 == nu ? 0u : pos + 1;
+        issued += 1;
+        poll_landed();
+    }
     __device__ __forceinline__ void finish()
     {
         int it = 0;
@@ -989,26 +1052,51 @@ template <int S> struct RingLoader {
     }
 };
 // the loader wave of a launch kernel: groups [g0, g1) of the workgroup in order; base(g) = address of group g's first row
-template <int R, int S, class Base>
-__device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int nu, unsigned ring, GldsCtl *ctl, int lane)
+// CARRY: compiled with the stream across the kernel boundary (the kernels' RING == 2 instances); without it `cy` is not looked at
+template <int R, int S, bool CARRY = false, class Base>
+__device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int nu, unsigned ring, GldsCtl *ctl, int lane,
+                                                const RingCarry &cy = RingCarry{})
 {
 #if RWKV_LOADER_PRIO
     __builtin_amdgcn_s_setprio(RWKV_LOADER_PRIO);     // the loader's instruction issue IS the stream's ceiling: let it win the SIMD's arbitration
 #endif
+    // carry: did the previous ring kernel leave this workgroup's first groups in the ring?  (read before the block is cleared)
+    unsigned have = 0u;
+    if (CARRY && cy.n_in > 0) {
+        const unsigned got = ctl->stamp[lane & 3];
+        const unsigned want = (lane & 3) == 0 ? cy.tag_in[0] : (lane & 3) == 1 ? cy.tag_in[1] : (lane & 3) == 2 ? (unsigned)blockIdx.x : (unsigned)cy.n_in;
+        have = __builtin_amdgcn_ballot_w64(got != want) == 0ull ? (unsigned)cy.n_in : 0u;
+        have = (int)have <= g1 - g0 ? have : 0u;
+        if (cy.hits != nullptr && lane == 0) __hip_atomic_fetch_add(cy.hits + (have ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // the control block is this wave's to zero: nobody else touches it before the order barrier
     for (int i = lane; i < (int)(sizeof(GldsCtl) / 4); i += 64) reinterpret_cast<unsigned *>(ctl)[i] = 0u;
-    RingLoader<S> ld(ctl, ring, nu, chunks, lane);
-    int g = g0;
+    RingLoader<S> ld(ctl, ring, nu, chunks, lane, CARRY ? cy.pos0 : 0);
+    if (CARRY && have) ld.template adopt<R>(have);
+    int g = g0 + (int)have;
     const int pre = RWKV_RING_PRE < nu - R ? RWKV_RING_PRE : nu - R;      // never wait for room before the barrier: the consumers are behind it
     for (; g < g1 && (int)ld.issued < pre; g++) ld.template group<R>(base(g) + ld.off[0], stride, true);
     __syncthreads();   // order: the control block is zero, the prologue's requests are in the pipe
     for (; g < g1 - (RWKV_TEST_DROP_GROUP ? 1 : 0); g++) ld.template group<R>(base(g) + ld.off[0], stride);
+    const unsigned cpos = ld.pos;
+    if (CARRY && cy.n_out > 0 && !RWKV_TEST_DROP_GROUP) {
+        const uint8_t *src = cy.w_next + (size_t)g0 * cy.rows_next * stride + ld.off[0];
+        const int rows = cy.n_out * cy.rows_next;
+        for (int r = 0; r < rows; r++) ld.row(src + (size_t)r * stride);
+    }
     ld.finish();
+#if RWKV_TEST_CORRUPT_CARRY
+    if (CARRY && cy.n_out > 0 && lane == 0) *reinterpret_cast<__attribute__((address_space(3))) unsigned *>(ring + cpos * (unsigned)(S * 1024) + 64u) ^= 0x00010000u;
+#else
+    (void)cpos;
+#endif
+    if (CARRY && cy.n_out > 0 && !RWKV_TEST_DROP_GROUP && ld.fail == 0u && lane < 4)
+        ctl->stamp[lane] = lane == 0 ? cy.tag_out[0] : lane == 1 ? cy.tag_out[1] : lane == 2 ? (unsigned)blockIdx.x : (unsigned)cy.n_out;
     return ld.fail;
 }
 // consumer side of one group (kl = its index in the workgroup): wait, copy its R units into registers, hand them back
 template <int R, int S>
-__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, const unsigned char *ring, GldsCtl *ctl, int lane, unsigned &fail)
+__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, const unsigned char *ring, GldsCtl *ctl, int lane, unsigned &fail, int pos0 = 0)
 {
     const unsigned uend = (unsigned)(kl + 1) * R;
     bool ok = false;
@@ -1017,7 +1105,7 @@ __device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, cons
         __builtin_amdgcn_s_sleep(1);
     }
     fail = ok ? fail : 2u;
-    unsigned p0 = (uend - R) % (unsigned)nu;
+    unsigned p0 = ((unsigned)pos0 + uend - R) % (unsigned)nu;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const u32x4 *p = reinterpret_cast<const u32x4 *>(ring + (size_t)p0 * (S * 1024)) + lane;
@@ -1027,10 +1115,41 @@ __device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, cons
     }
     if (lane == 0) __hip_atomic_store(&ctl->freeq[kl % GLDS_FQ], (unsigned)kl + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// Rows that were CARRIED into this kernel (the first ctl->carried groups of the workgroup: they have been sitting in LDS since the
+// previous kernel, across a boundary at which another process's kernel may have had the CU) are checked before anybody is handed
+// the token: their bytes must add up to the row sums the engine keeps for the 2^22 offset anyway (`rs`: nrs sums per group, the
+// group's first at rs[g * nrs]).  Run by the consumer waves that have nothing to do while waves 0..3 stage the vector (widx of
+// nw), straight from the ring, off the streaming loop; a mismatch is recorded like a lost hand-off (code 5) and fails the call.
+template <int R, int S>
+__device__ __forceinline__ void carry_verify(const unsigned char *ring, int nu, int pos0, const GldsCtl *ctl, int chunks, const unsigned *rs, int nrs,
+                                             int g0, int lane, int widx, int nw, unsigned &fail)
+{
+    const int ncar = (int)ctl->carried;
+    for (int k = widx; k < ncar; k += nw) {
+        unsigned want = 0u;
+        if (lane < nrs) want = rs[(size_t)(g0 + k) * nrs + lane];
+        unsigned t = 0u;
+        unsigned p0 = ((unsigned)pos0 + (unsigned)k * R) % (unsigned)nu;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const u32x4 *p = reinterpret_cast<const u32x4 *>(ring + (size_t)p0 * (S * 1024)) + lane;
+#pragma unroll
+            for (int s = 0; s < S; s++)
+                if (lane + 64 * s < chunks) {
+                    const u32x4 w = p[s * 64];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t = __builtin_amdgcn_udot4(w[q], 0x01010101u, t, false);
+                }
+            p0 = p0 + 1 == (unsigned)nu ? 0u : p0 + 1;
+        }
+        fail = wave_sum_dpp(t) == wave_sum_dpp(want) ? fail : 5u;          // R * S KiB * 255 < 2^32
+    }
+}
+struct CarryCheck { const unsigned char *ring; int nu, pos0, chunks, g0; const unsigned *rs; int nrs; };
 // the consumer waves' streaming loop (wave < NC): same pre / epi contract as stream_groups
 template <int R, int S, int PAT, class Pre, class Epi>
 __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
-                                            int chunks, Pre pre, Epi epi, unsigned &fail, unsigned long long *g_tl_groups = nullptr)
+                                            int chunks, Pre pre, Epi epi, unsigned &fail, unsigned long long *g_tl_groups = nullptr, int pos0 = 0)
 {
 #ifdef RWKV_TL_GROUPS
     // debug build (tools/timeline.py): where a consumer wave's time goes.  Stamps of the wave: 1 inputs of its first group requested,
@@ -1043,7 +1162,7 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
         if (rr == 0) tl_stamp(g_tl_groups, 1);
 #endif
         u32x4 w[R][S];
-        glds_take<R, S>(w, g - g0, nu, ring, ctl, lane, fail);
+        glds_take<R, S>(w, g - g0, nu, ring, ctl, lane, fail, pos0);
 #ifdef RWKV_TL_GROUPS
         asm volatile("" : "+v"(w[R - 1][S - 1]));
         if (rr < 1) tl_stamp(g_tl_groups, 2);
@@ -1075,9 +1194,10 @@ __device__ __forceinline__ void ring_init(GldsCtl *gc)
 }
 // LayerNorm-site prologue of a ring kernel, called by the consumer waves (wave < NC): waves 0..3 stage the NV vectors and
 // publish the scalars, the others wait; contains the workgroup's order barrier, which the loader executes once as well
-template <int NV, int S>
+template <int NV, int S, int RC = 0>
 __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &dy, const double *x, int D, double *red, unsigned *xq,
-                                          SiteRed<NV> &sr, bool publish_stats, GldsCtl *gc, unsigned long long *tl, unsigned &fail)
+                                          SiteRed<NV> &sr, bool publish_stats, GldsCtl *gc, unsigned long long *tl, unsigned &fail,
+                                          const CarryCheck &ck = CarryCheck{})
 {
     constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
     const int nqd = D >> 2;
@@ -1117,6 +1237,8 @@ __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &d
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&gc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         __syncthreads();   // order
+        if constexpr (RC > 0)
+            carry_verify<RC, S>(ck.ring, ck.nu, ck.pos0, gc, ck.chunks, ck.rs, ck.nrs, ck.g0, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6) - NWP, NC - NWP, fail);
     }
     wait_count(&gc->staged, NWP, fail);
 #pragma unroll
@@ -1125,9 +1247,9 @@ __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &d
     tl_stamp(tl, 5);
 }
 // plain-vector prologue of a ring kernel (k_attout, k_ffnv), same roles
-template <int NVEC, int S>
+template <int NVEC, int S, int RC = 0>
 __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, const float *partM, int n_part, int D, double *red, unsigned *xq,
-                                         float &Sf, float &amax, GldsCtl *gc, unsigned long long *tl, unsigned &fail)
+                                         float &Sf, float &amax, GldsCtl *gc, unsigned long long *tl, unsigned &fail, const CarryCheck &ck = CarryCheck{})
 {
     constexpr int XVD = xvd<S>();
     constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
@@ -1172,6 +1294,7 @@ __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, 
         if (lane == 0) __hip_atomic_fetch_add(&gc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         __syncthreads();   // order
+        if constexpr (RC > 0) carry_verify<RC, S>(ck.ring, ck.nu, ck.pos0, gc, ck.chunks, ck.rs, ck.nrs, ck.g0, lane, wave - NWP, NC - NWP, fail);
     }
     wait_count(&gc->staged, NWP, fail);
     Sf = bc[0]; amax = bc[4];
@@ -1242,11 +1365,12 @@ struct AttArgs {
     int ns;                               // ring kernels: LDS slots
     unsigned long long *tl;               // optional phase timeline (see tl_stamp)
     unsigned *herr;                       // ring kernels: the context's error word (raise_error)
+    RingCarry cy;                         // ring kernels: the stream across the kernel boundary
 };
 
 // ln1 site -> K,V,R dequant-GEMV -> WKV (rwkv.cu:535-545; kernels :351-392, :58-100, :221-259)
 struct AttIn { unsigned rs[3]; double aa, bb, uw, ew; float ra, oa; };
-template <int S, int NB, bool RING = false>
+template <int S, int NB, int RING = 0>
 __global__ __launch_bounds__(NT) void k_att(AttArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1300,16 +1424,17 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
     if constexpr (RING) {
-        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 3 * S * 3072);
+        constexpr bool CARRY = RING == 2;      // the stream crosses the kernel boundaries (kernels.hip.h "CARRY"): common ring geometry
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : 3 * S * 3072));
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            fail = glds_loader<3, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            fail = glds_loader<3, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
             tl_stamp(a.tl, 2);
         } else {
             SiteRed<3> sr;
-            ring_site<3, S>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl, fail);
+            ring_site<3, S, CARRY && RWKV_CARRY_VERIFY ? 3 : 0>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rs, 3});
             scalars(sr);
-            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl);
+            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[3][S], wB[3][S];
@@ -1355,7 +1480,7 @@ struct AttOutArgs {
 // att_out dequant-GEMV + residual through f32 (rwkv.cu:548-553), R rows per group; commits state xy;
 // opens the ln2 site for the rows it owns
 template <int R> struct AttOutIn { unsigned rsum; double xold, lw, lb, prev2; SitePre<2> pre; int mi, shift; };
-template <int S, int R, int NB, bool RING = false>
+template <int S, int R, int NB, int RING = 0>
 __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1447,11 +1572,12 @@ struct FfnRKArgs {
     int ns;                           // ring kernels: LDS slots
     unsigned long long *tl;           // optional phase timeline (see tl_stamp)
     unsigned *herr;
+    RingCarry cy;
 };
 
 // ln2 site -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573)
 struct FfnRKIn { unsigned rsum; float rq, oq; };
-template <int S, int NB, bool RING = false>
+template <int S, int NB, int RING = 0>
 __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1498,16 +1624,17 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
     if constexpr (RING) {
-        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 2 * S * 3072);
+        constexpr bool CARRY = RING == 2;      // the stream crosses the kernel boundaries (kernels.hip.h "CARRY"): common ring geometry
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : 2 * S * 3072));
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            fail = glds_loader<5, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            fail = glds_loader<5, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
             tl_stamp(a.tl, 2);
         } else {
             SiteRed<2> sr;
-            ring_site<2, S>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl, fail);
+            ring_site<2, S, CARRY && RWKV_CARRY_VERIFY ? 5 : 0>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rs, 5});
             scalars(sr);
-            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl);
+            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[5][S], wB[5][S];
@@ -1549,11 +1676,12 @@ struct FfnVArgs {
     int ns;                // ring kernels: LDS slots
     unsigned long long *tl;
     unsigned *herr;
+    RingCarry cy;
 };
 
 // ffn_v dequant-GEMV, x += v * sigmoid(r) (rwkv.cu:574-577); commits state dd; opens the next site
 template <int NVN> struct FfnVIn { unsigned rsum; double xold, lw, lb, prevn; float rg; SitePre<NVN> pre; };
-template <int S, int NVN, int NB, bool RING = false>
+template <int S, int NVN, int NB, int RING = 0>
 __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1592,15 +1720,16 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
     if constexpr (RING) {
-        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 4 * S * 3072);
+        constexpr bool CARRY = RING == 2;      // the stream crosses the kernel boundaries (kernels.hip.h "CARRY"): common ring geometry
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : 4 * S * 3072));
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            fail = glds_loader<4, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            fail = glds_loader<4, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
             tl_stamp(a.tl, 2);
         } else {
-            ring_vec<4, S>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl, fail);
+            ring_vec<4, S, CARRY && RWKV_CARRY_VERIFY ? 4 : 0>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rs, 1});
             sc = scale_of(amax);
-            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl);
+            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[4][S], wB[4][S];
@@ -1636,7 +1765,7 @@ struct HeadArgs {
 
 // ln_out site -> head dequant-GEMV -> logits (rwkv.cu:585-589); also per-workgroup argmax partials
 template <int R> struct HeadIn { unsigned rsr[R]; int row0, shift; };
-template <int S, int NB, bool RING = false, int R = RING ? RWKV_HEAD_RR : RWKV_HEAD_R>
+template <int S, int NB, int RING = 0, int R = RING ? RWKV_HEAD_RR : RWKV_HEAD_R>
 __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

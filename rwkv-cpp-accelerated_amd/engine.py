@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "rwkv_create", "rwkv_load_file", "rwkv_load_tensors", "rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx",
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
-    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
+    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_debug_carry_hits", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
     "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode",
     "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device",
 ]
@@ -73,6 +73,8 @@ def lib():
     L.rwkv_debug_timeline.argtypes = [vp, u64, vp, u64]; L.rwkv_debug_timeline.restype = i32
     L.rwkv_abi_version.argtypes = []; L.rwkv_abi_version.restype = i32
     L.rwkv_resident_bytes.argtypes = [vp]; L.rwkv_resident_bytes.restype = u64
+    if hasattr(L, "rwkv_debug_carry_hits"):      # debug counters: absent from tuning variants built from older sources
+        L.rwkv_debug_carry_hits.argtypes = [vp, C.POINTER(u64)]; L.rwkv_debug_carry_hits.restype = i32
     if L.rwkv_abi_version() != ABI_VERSION:
         raise RWKVError(f"{LIB_PATH} has C-ABI version {L.rwkv_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
     L.rwkv_sample_typical.argtypes = [vp, u64, C.c_float, C.c_float, C.c_double, i32, C.POINTER(u64)]; L.rwkv_sample_typical.restype = i32
@@ -348,6 +350,12 @@ class RWKV:
 
     def resident_bytes(self) -> int:
         return int(lib().rwkv_resident_bytes(self._h))
+
+    def carry_hits(self):
+        """(found, not found): workgroup launches whose first weight rows were / were not waiting in LDS (needs RWKV_CARRY_COUNT=1 at load)"""
+        out = (C.c_uint64 * 2)()
+        _chk(lib().rwkv_debug_carry_hits(self._h, out))
+        return int(out[0]), int(out[1])
 
     def stream(self) -> int:
         return int(lib().rwkv_stream(self._h) or 0)

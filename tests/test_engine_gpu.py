@@ -418,3 +418,63 @@ def test_a_lost_ring_hand_off_fails_the_call_instead_of_returning_garbage(built,
     )
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RWKV_LIB=lib, RWKV_RING="13"), capture_output=True, text=True, timeout=600)
     assert "RWKVERROR" in out.stdout and "device-side wait gave up" in out.stdout and "status -3" in out.stdout, out.stdout[-400:] + out.stderr[-400:]
+
+
+def _run_py(code, **env):
+    import subprocess
+    import sys
+    return subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+
+
+_CARRY_PROBE = (
+    "import sys, numpy as np, hashlib\n"
+    "sys.path.insert(0, {root!r})\n"
+    "import torch\n"
+    "from rwkv_cpp_accelerated_amd import engine, modelfile as mf\n"
+    "L, D = {L}, {D}\n"
+    "m = engine.RWKV(resident=True); m.loadTensors(L, D, mf.synthetic_tensors(L, D, seed=11))\n"
+    "try:\n"
+    "    ids = m.decode_greedy(7, 24)\n"
+    "    lg = np.array(m.forward(int(ids[-1])), dtype=np.float32)\n"
+    "    print('IDS', ' '.join(str(int(i)) for i in ids))\n"
+    "    print('LOGITS', hashlib.sha256(lg.tobytes()).hexdigest())\n"
+    "    print('HITS', *m.carry_hits())\n"
+    "except engine.RWKVError as e:\n"
+    "    print('RWKVERROR', str(e)[-160:], '|', str(e)[:200])\n"
+)
+
+
+@pytest.mark.parametrize("L,D", [(3, 4096), (2, 2560)])
+def test_rows_carried_across_kernel_boundaries_are_found_and_change_nothing(built, L, D):
+    """kernels.hip.h "CARRY": the loader of a ring kernel leaves the first rows of the NEXT ring kernel in the CU's LDS.  With the
+    counters on, every workgroup of every consuming launch must report that it found its rows (25 tokens x (3 L - 1) consuming
+    launches x 256 workgroups, none missed), and tokens and logits must be bit-identical to a run with RWKV_CARRY=0: the carried
+    rows are the same bytes, multiplied by the same code."""
+    code = _CARRY_PROBE.format(root=ROOT, L=L, D=D)
+    on = _run_py(code, RWKV_CARRY="32", RWKV_CARRY_COUNT="1")
+    off = _run_py(code, RWKV_CARRY="0", RWKV_CARRY_COUNT="1")
+    get = lambda out, key: [ln for ln in out.stdout.splitlines() if ln.startswith(key)]
+    assert get(on, "IDS") and get(on, "IDS") == get(off, "IDS"), on.stdout[-600:] + on.stderr[-600:] + off.stdout[-300:]
+    assert get(on, "LOGITS") == get(off, "LOGITS")
+    import torch
+    hit, miss = (int(v) for v in get(on, "HITS")[0].split()[1:])
+    grid = torch.cuda.get_device_properties(0).multi_processor_count
+    assert miss == 0 and hit == 25 * (3 * L - 1) * grid, (hit, miss)
+    assert get(off, "HITS")[0].split()[1:] == ["0", "0"]
+
+
+def test_damaged_carried_rows_fail_the_call(built, tmp_path):
+    """rows that waited in LDS across a kernel boundary are checked against their row sums before they are used: an engine variant
+    whose loader flips one bit of what it carries (-DRWKV_TEST_CORRUPT_CARRY=1) must fail with RWKV_E_DEVICE and say what to do."""
+    import subprocess
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", "engine.hip")
+    lib = str(tmp_path / "lib_corrupt.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+                           "-DRWKV_TEST_CORRUPT_CARRY=1", src, "-o", lib], timeout=600)
+    out = _run_py(_CARRY_PROBE.format(root=ROOT, L=2, D=4096), RWKV_LIB=lib, RWKV_CARRY="32")
+    assert "RWKVERROR" in out.stdout and "arrived damaged" in out.stdout and "RWKV_CARRY=0" in out.stdout and "status -3" in out.stdout, \
+        out.stdout[-500:] + out.stderr[-400:]
+    ok = _run_py(_CARRY_PROBE.format(root=ROOT, L=2, D=4096), RWKV_LIB=lib, RWKV_CARRY="0")
+    assert "IDS" in ok.stdout and "RWKVERROR" not in ok.stdout, ok.stdout[-400:]
