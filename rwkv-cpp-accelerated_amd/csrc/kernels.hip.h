@@ -41,6 +41,11 @@ namespace rwkvk {
 constexpr int NT = 512;          // threads per workgroup
 constexpr int NW = NT / 64;      // wavefronts per workgroup
 constexpr int RED_BYTES = 1024;  // LDS scratch for workgroup reductions
+// rows [block_lo(n), block_hi(n)) of n belong to this workgroup: floor(b n / blocks) in 32-bit arithmetic (b n < 2^32 for every
+// use: blocks <= 512, n <= 65536).  As a 64-bit expression it compiled to two ~130-instruction scalar divisions at the head of
+// every wave, in front of the kernel-argument loads -- half a microsecond of every launch before the prologue's first request.
+__device__ __forceinline__ int block_lo(int n) { return (int)(((unsigned)blockIdx.x * (unsigned)n) / gridDim.x); }
+__device__ __forceinline__ int block_hi(int n) { return (int)((((unsigned)blockIdx.x + 1u) * (unsigned)n) / gridDim.x); }
 constexpr unsigned VOCAB = 50277u;
 constexpr float QLIM = 4194000.0f;       // |quantised activation| <= QLIM < 2^22
 constexpr double QOFF = 4194304.0;       // 2^22: limbs hold q + 2^22 as an unsigned 23-bit number
@@ -1321,7 +1326,7 @@ __global__ __launch_bounds__(NT) void k_first(FirstArgs a)
 {
     __shared__ double red[RED_BYTES / 8];
     const int D = a.D;
-    const int j0 = (int)(((long long)blockIdx.x * D) / gridDim.x), j1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
+    const int j0 = block_lo(D), j1 = block_hi(D);
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
     double mean = 0.0, rstd = 1.0;
     const float *row = a.from_token ? a.embed + (size_t)a.ctl->token * D : nullptr;
@@ -1378,8 +1383,8 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = D >> 4;
-    const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
-    const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
+    const int g0 = block_lo(D);
+    const int g1 = block_hi(D);
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
 
     tl_stamp(a.tl, 0);
@@ -1490,8 +1495,8 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
     const int chunks = D >> 4;
     tl_stamp(a.tl, 0);
     const int G = (D + R - 1) / R;
-    const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
-    const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
+    const int g0 = block_lo(G);
+    const int g1 = block_hi(G);
 
     const double mean1 = a.lnstat[0], rstd1 = a.lnstat[1];
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
@@ -1585,8 +1590,8 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = D >> 4;
-    const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
-    const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
+    const int g0 = block_lo(D);
+    const int g1 = block_hi(D);
     tl_stamp(a.tl, 0);
 
     auto base = [&](int g) { return a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 5 * D; };
@@ -1690,8 +1695,8 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = D >> 4;
     tl_stamp(a.tl, 0);
-    const int g0 = (int)(((long long)blockIdx.x * D) / gridDim.x);
-    const int g1 = (int)(((long long)(blockIdx.x + 1) * D) / gridDim.x);
+    const int g0 = block_lo(D);
+    const int g1 = block_hi(D);
 
     const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
@@ -1778,8 +1783,8 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
     const int chunks = D >> 4;
     const int V = (int)VOCAB;
     const int G = (V + R - 1) / R;
-    const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
-    const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
+    const int g0 = block_lo(G);
+    const int g1 = block_hi(G);
     float *lg = a.logits + (size_t)a.ctl->out_row * V;   // read at entry: behind the prologue's barriers it is a cold scalar load
 
     auto base = [&](int gg) {
@@ -1897,8 +1902,8 @@ __global__ __launch_bounds__(NT) void k_mm8(Mm8Args a)
     const int chunks = Dq >> 4, nqd = Dq >> 2;
     const int M = a.M;
     const int G = QUARTERS ? M : (M + R - 1) / R;
-    const int g0 = (int)(((long long)blockIdx.x * G) / gridDim.x);
-    const int g1 = (int)(((long long)(blockIdx.x + 1) * G) / gridDim.x);
+    const int g0 = block_lo(G);
+    const int g1 = block_hi(G);
 
     double Ssum[1] = {0.0};
     float amax[1] = {0.f};

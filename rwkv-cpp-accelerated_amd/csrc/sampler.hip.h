@@ -55,7 +55,7 @@ __global__ __launch_bounds__(TS_GT) void k_typical_stats(TypicalArgs a)
 {
     __shared__ double red[RED_BYTES / 8];
     const int V = (int)VOCAB;
-    const int i0 = (int)(((long long)blockIdx.x * V) / gridDim.x), i1 = (int)(((long long)(blockIdx.x + 1) * V) / gridDim.x);
+    const int i0 = block_lo(V), i1 = block_hi(V);
     const float *lg = ts_row(a);
     float mx[1] = {-INFINITY};
     for (int i = i0 + threadIdx.x; i < i1; i += TS_GT) mx[0] = fmaxf(mx[0], ts_logit(a, lg, i));
@@ -102,7 +102,7 @@ static_assert(TS_G <= 64, "one lane per partial");
 __global__ __launch_bounds__(TS_GT) void k_typical_keys(TypicalArgs a)
 {
     const int V = (int)VOCAB;
-    const int i0 = (int)(((long long)blockIdx.x * V) / gridDim.x), i1 = (int)(((long long)(blockIdx.x + 1) * V) / gridDim.x);
+    const int i0 = block_lo(V), i1 = block_hi(V);
     const float *lg = ts_row(a);
     double M, logZ, H;
     ts_combine(a, M, logZ, H);

@@ -807,7 +807,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_ks(SeqGemmArgs a)
     const int nch = (N + Q - 1) / Q;                    // channels per class
     const int CB = (nch + 15) >> 4;                     // 16-channel blocks per class
     const int ntiles = Q * CB;
-    const int tb0 = (int)(((long long)blockIdx.x * ntiles) / gridDim.x), tb1 = (int)(((long long)(blockIdx.x + 1) * ntiles) / gridDim.x);
+    const int tb0 = block_lo(ntiles), tb1 = block_hi(ntiles);
     const int kb0 = (int)(((long long)wave * KB) / SEQ_O), kb1 = (int)(((long long)(wave + 1) * KB) / SEQ_O);
     if (blockIdx.x == gridDim.x - 1)
         for (int j = threadIdx.x; j < a.cp_n; j += SEQ_NT) a.cp_dst[j] = a.cp_src[j];
