@@ -44,6 +44,20 @@ constexpr int RED_BYTES = 1024;  // LDS scratch for workgroup reductions
 // rows [block_lo(n), block_hi(n)) of n belong to this workgroup: floor(b n / blocks) in 32-bit arithmetic (b n < 2^32 for every
 // use: blocks <= 512, n <= 65536).  As a 64-bit expression it compiled to two ~130-instruction scalar divisions at the head of
 // every wave, in front of the kernel-argument loads -- half a microsecond of every launch before the prologue's first request.
+// Kernel arguments the prologue needs, fetched with the kernel's FIRST scalar loads: hipcc sinks an argument's s_load into the block
+// that uses it, so the prologue waves paid a second and a third scalar-cache round trip (the role branch, then the site's
+// pointers) before their first request to memory.
+#define RWKV_ARGS_NOW(...) asm volatile("" ::RWKV_ARGS_S(__VA_ARGS__))
+#define RWKV_ARGS_S(...) RWKV_ARGS_PICK(__VA_ARGS__, RWKV_A8, RWKV_A7, RWKV_A6, RWKV_A5, RWKV_A4, RWKV_A3, RWKV_A2, RWKV_A1)(__VA_ARGS__)
+#define RWKV_ARGS_PICK(a, b, c, d, e, f, g, h, N, ...) N
+#define RWKV_A1(a) "s"(a)
+#define RWKV_A2(a, ...) "s"(a), RWKV_A1(__VA_ARGS__)
+#define RWKV_A3(a, ...) "s"(a), RWKV_A2(__VA_ARGS__)
+#define RWKV_A4(a, ...) "s"(a), RWKV_A3(__VA_ARGS__)
+#define RWKV_A5(a, ...) "s"(a), RWKV_A4(__VA_ARGS__)
+#define RWKV_A6(a, ...) "s"(a), RWKV_A5(__VA_ARGS__)
+#define RWKV_A7(a, ...) "s"(a), RWKV_A6(__VA_ARGS__)
+#define RWKV_A8(a, ...) "s"(a), RWKV_A7(__VA_ARGS__)
 __device__ __forceinline__ int block_lo(int n) { return (int)(((unsigned)blockIdx.x * (unsigned)n) / gridDim.x); }
 __device__ __forceinline__ int block_hi(int n) { return (int)((((unsigned)blockIdx.x + 1u) * (unsigned)n) / gridDim.x); }
 constexpr unsigned VOCAB = 50277u;
@@ -1383,6 +1397,7 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = D >> 4;
+    if constexpr (RING) RWKV_ARGS_NOW(a.x, a.st.C, a.st.TC, a.st.maxC, a.dy.B, a.dy.pd, a.dy.pf, a.dy.n_part);
     const int g0 = block_lo(D);
     const int g1 = block_hi(D);
     const size_t so = (size_t)a.ctl->slot * a.slot_stride;
@@ -1590,6 +1605,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = D >> 4;
+    if constexpr (RING) RWKV_ARGS_NOW(a.x, a.st.C, a.st.TC, a.st.maxC, a.dy.B, a.dy.pd, a.dy.pf, a.dy.n_part);
     const int g0 = block_lo(D);
     const int g1 = block_hi(D);
     tl_stamp(a.tl, 0);
@@ -1694,6 +1710,7 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = D >> 4;
+    if constexpr (RING) RWKV_ARGS_NOW(a.hbuf, a.partS, a.partM, a.n_part);
     tl_stamp(a.tl, 0);
     const int g0 = block_lo(D);
     const int g1 = block_hi(D);
