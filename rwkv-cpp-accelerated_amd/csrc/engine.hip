@@ -163,7 +163,7 @@ struct rwkv_ctx {
     int S = 0;               // ceil(D / 1024): 1 KiB row pieces per lane
     int carry_kib = -1;      // ring kernels: KiB of the NEXT ring kernel's rows a workgroup's loader leaves in LDS (kernels.hip.h "CARRY"; env RWKV_CARRY, 0 = off;
                              // default: 32 where it pays -- 4 KiB rows (7B: +1.3 %; 3B -1.3 %, 14B -2.6 %: profiles/r03/carry.txt) -- else 0)
-    int carry_edges = 7;     //   which boundaries: bit 0 k_att -> (k_attout) -> k_ffn_rk, 1 k_ffn_rk -> k_ffnv, 2 k_ffnv -> k_att of the next layer (env RWKV_CARRY_EDGES)
+    int carry_edges = 15;    //   which boundaries, by CONSUMER: bit 0 into k_ffn_rk, 1 into k_ffnv, 2 into k_att (of the next layer), 3 into k_attout (env RWKV_CARRY_EDGES)
     unsigned nonce[2] = {0u, 0u};   //   stamp of this context's carried rows
     unsigned *carry_hits = nullptr; //   debug counters (env RWKV_CARRY_COUNT=1; rwkv_debug_carry_hits)
     int ring = RWKV_RING;    // decode kernels that stream their weights through the LDS ring (bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv, 4 k_head; env RWKV_RING)
@@ -308,33 +308,36 @@ struct ArgMaker {
         n_first = grid < 32 ? grid : 32;
         common = c->carry_kib > 0 && c->carry_edges != 0 && D % grid == 0 && D / grid >= 2 && (c->ring & 13) != 0;
     }
-    // ---- the carry plan: who streams the first rows of whom ----
-    static int rows_of(int cls) { return cls == 1 ? 3 : cls == 3 ? 5 : 4; }
-    static int nv_of(int cls) { return cls == 1 ? 3 : cls == 3 ? 2 : 4; }
-    bool ring_cls(int cls) const { return cls == 1 ? (c->ring & 1) != 0 : cls == 3 ? (c->ring & 4) != 0 : cls == 4 ? (c->ring & 8) != 0 : false; }
+    // ---- the carry plan: who streams the first rows of whom.  Ring kernels of a layer in launch order: 1 k_att, 2 k_attout (only when
+    // it is on the ring), 3 k_ffn_rk, 4 k_ffnv; a k_attout in register form is stepped over (it stays below the ring's LDS) ----
+    static int rows_of(int cls) { return cls == 1 ? 3 : cls == 2 ? ATTOUT_R : cls == 3 ? 5 : 4; }
+    static int nv_of(int cls) { return cls == 1 ? 3 : cls == 2 ? 1 : cls == 3 ? 2 : 4; }
+    int groups_of(int cls) const { return cls == 2 ? D / ATTOUT_R : D; }               // groups the class splits over the workgroups
+    bool ring_cls(int cls) const
+    {
+        if (cls == 2) return (c->ring & 2) != 0 && D % (ATTOUT_R * grid) == 0;
+        return cls == 1 ? (c->ring & 1) != 0 : cls == 3 ? (c->ring & 4) != 0 : cls == 4 ? (c->ring & 8) != 0 : false;
+    }
+    static int edge_bit(int to_cls) { return to_cls == 3 ? 1 : to_cls == 4 ? 2 : to_cls == 1 ? 4 : 8; }      // RWKV_CARRY_EDGES: by consumer
     int units() const { return ring_units(0, c->S, true); }
     // the ring kernel that runs behind (cls, l) and takes rows from it
     bool next_of(int cls, uint64_t l, bool as_chain, int &cls2, uint64_t &l2) const
     {
         if (!common || !ring_cls(cls)) return false;
-        const int e = c->carry_edges;
-        if (as_chain) {
-            const int bit = cls == 3 ? 1 : cls == 4 ? 2 : 4;      // the class's in-edge in token order
-            cls2 = cls; l2 = l + 1;
-            return (e & bit) && l2 < c->l1 && (cls != 3 || !(c->ring & 2));
-        }
-        if (cls == 1) { cls2 = 3; l2 = l; return (e & 1) && !(c->ring & 2) && ring_cls(3); }      // across k_attout in register form: its one staged vector
-                                                                                                  // sits where the ring kernels stage theirs, below the ring
-        if (cls == 3) { cls2 = 4; l2 = l; return (e & 2) && ring_cls(4); }
-        cls2 = 1; l2 = l + 1;
-        return (e & 4) && l2 < c->l1 && ring_cls(1);
+        if (as_chain) { cls2 = cls; l2 = l + 1; }
+        else if (cls == 1) { cls2 = (c->ring & 2) ? 2 : 3; l2 = l; }
+        else if (cls == 2) { cls2 = 3; l2 = l; }
+        else if (cls == 3) { cls2 = 4; l2 = l; }
+        else { cls2 = 1; l2 = l + 1; }
+        return (c->carry_edges & edge_bit(cls2)) && l2 < c->l1 && ring_cls(cls2);
     }
     bool prev_of(int cls, uint64_t l, bool as_chain, int &cls0, uint64_t &l0_) const
     {
         if (!common || !ring_cls(cls)) return false;
         if (as_chain) { cls0 = cls; l0_ = l - 1; }
         else if (cls == 1) { cls0 = 4; l0_ = l - 1; }
-        else if (cls == 3) { cls0 = 1; l0_ = l; }
+        else if (cls == 2) { cls0 = 1; l0_ = l; }
+        else if (cls == 3) { cls0 = (c->ring & 2) ? 2 : 1; l0_ = l; }
         else { cls0 = 3; l0_ = l; }
         if ((cls0 == 4 || as_chain) && l == c->l0) return false;
         int cb; uint64_t lb;
@@ -342,7 +345,7 @@ struct ArgMaker {
     }
     int carry_groups(int cls) const      // groups of class `cls` that travel: ~carry_kib, at least one, at most half a workgroup's share and half the ring
     {
-        const int per = rows_of(cls) * c->S, G = D / grid;
+        const int per = rows_of(cls) * c->S, G = groups_of(cls) / grid;
         int n = (c->carry_kib + per / 2) / per;
         n = std::max(n, 1);
         n = std::min(n, std::min(G / 2, units() / (2 * rows_of(cls))));
@@ -351,7 +354,7 @@ struct ArgMaker {
     const uint8_t *weights_of(int cls, uint64_t l) const
     {
         const size_t lr = (size_t)(l - c->l0);
-        return cls == 1 ? c->w_kvr + lr * 3 * D * D : cls == 3 ? c->w_frk + lr * 5 * D * D : c->w_fv + lr * 4 * D * D;
+        return cls == 1 ? c->w_kvr + lr * 3 * D * D : cls == 2 ? c->w_att + lr * D * D : cls == 3 ? c->w_frk + lr * 5 * D * D : c->w_fv + lr * 4 * D * D;
     }
     RingCarry carry(int cls, uint64_t l) const
     {
@@ -359,13 +362,15 @@ struct ArgMaker {
         cy.xq_bytes = ring_xq_bytes(nv_of(cls), c->S, common);
         cy.hits = c->carry_hits;
         if (!common) return cy;
-        const int G = D / grid, nu = units();
+        const int Gw = D / grid, nu = units();                        // rows per workgroup of a D-row matrix
         const uint64_t lr = l - c->l0;
-        const uint64_t before = chain ? lr * (uint64_t)G * rows_of(cls) : lr * 12u * G + (cls == 1 ? 0 : cls == 3 ? 3 * G : 8 * G);
+        const int ao = ring_cls(2) ? Gw : 0;                            // units per workgroup: k_att 3 Gw, k_attout Gw, k_ffn_rk 5 Gw, k_ffnv 4 Gw
+        const uint64_t own = (uint64_t)Gw * (cls == 1 ? 3 : cls == 2 ? 1 : cls == 3 ? 5 : 4);
+        const uint64_t before = chain ? lr * own : lr * (uint64_t)(12 * Gw + ao) + (cls == 1 ? 0 : cls == 2 ? 3 * Gw : cls == 3 ? 3 * Gw + ao : 8 * Gw + ao);
         cy.pos0 = (int)(before % (uint64_t)nu);
         int c2; uint64_t l2;
         if (next_of(cls, l, chain, c2, l2) && carry_groups(c2) > 0) {
-            cy.w_next = weights_of(c2, l2); cy.rows_next = rows_of(c2); cy.n_out = carry_groups(c2);
+            cy.w_next = weights_of(c2, l2); cy.rows_next = rows_of(c2); cy.n_out = carry_groups(c2); cy.groups_next = groups_of(c2);
             cy.tag_out[0] = c->nonce[0]; cy.tag_out[1] = c->nonce[1] ^ (unsigned)(l2 * 8 + (uint64_t)c2);
         }
         if (prev_of(cls, l, chain, c2, l2) && carry_groups(cls) > 0) {
@@ -417,7 +422,7 @@ struct ArgMaker {
         ao.w = c->w_att + (size_t)(l - c->l0) * D * D; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
         ao.x = c->x; ao.lnw = c->ln + (4 * l + 2) * D; ao.lnb = c->ln + (4 * l + 3) * D; ao.lnstat = c->lnstat + 0;
         ao.sxy = c->state[0] + lo; ao.st = site_static(1, l); ao.dy = site_dyn(1, grid); ao.sdd = c->state[4] + lo;
-        ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.ns = 0; ao.tl = tl_of(2, l); ao.herr = c->d_herr;
+        ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.ns = 0; ao.tl = tl_of(2, l); ao.herr = c->d_herr; ao.cy = carry(2, l);
         return ao;
     }
     FfnRKArgs frk(uint64_t l) const
@@ -476,7 +481,11 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
     } break;
     case 2: {
         AttOutArgs ao = mk.attout(l);
-        if (c->ring & 2) { ao.ns = ring_slots(smem_attout(S), ATTOUT_R, S); DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, 1><<<dim3(grid), dim3(NT), smem_ring(smem_attout(S), ATTOUT_R, S), c->stream>>>(ao)); }
+        if ((c->ring & 2) && mk.common && mk.ring_cls(2)) {
+            ao.ns = ring_units(1, S, true);
+            DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(1, S, true), c->stream>>>(ao));
+        }
+        else if (c->ring & 2) { ao.ns = ring_slots(smem_attout(S), ATTOUT_R, S); DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, 1><<<dim3(grid), dim3(NT), smem_ring(smem_attout(S), ATTOUT_R, S), c->stream>>>(ao)); }
         else DISPATCH_S(S, k_attout<S_, ATTOUT_R, nb_attout(S_)><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
     } break;
     case 3: {
@@ -624,6 +633,7 @@ int set_smem_limits(rwkv_ctx *c)
     DISPATCH_S(S, rc = allow_smem(k_att<S_, 1, 1>, smem_ring3(3, S, false))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_att<S_, 1, 2>, smem_ring3(3, S, true))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R, 1, 1>, smem_ring(smem_attout(S), ATTOUT_R, S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R, 1, 2>, smem_ring3(1, S, true))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_, 1, 1>, smem_ring3(2, S, false))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_, 1, 2>, smem_ring3(2, S, true))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, 1, 1>, smem_ring3(4, S, false))); if (rc) return rc;

@@ -930,6 +930,7 @@ struct GldsCtl {            // LDS control block of the ring (80 dwords)
 struct RingCarry {
     const uint8_t *w_next;      // the next ring kernel's weights: its group g = rows_next rows of D bytes from w_next + g * rows_next * D
     int rows_next, n_out;       // prefetch n_out groups of rows_next rows for it (0: none)
+    int groups_next;            // its rows are split over the workgroups in groups_next groups (block_lo / block_hi)
     int n_in;                   // groups the previous ring kernel was asked to leave for this one
     unsigned tag_in[2], tag_out[2];
     int pos0;                   // ring position of this kernel's first unit
@@ -1099,7 +1100,7 @@ __device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_
     for (; g < g1 - (RWKV_TEST_DROP_GROUP ? 1 : 0); g++) ld.template group<R>(base(g) + ld.off[0], stride);
     const unsigned cpos = ld.pos;
     if (CARRY && cy.n_out > 0 && !RWKV_TEST_DROP_GROUP) {
-        const uint8_t *src = cy.w_next + (size_t)g0 * cy.rows_next * stride + ld.off[0];
+        const uint8_t *src = cy.w_next + (size_t)block_lo(cy.groups_next) * cy.rows_next * stride + ld.off[0];
         const int rows = cy.n_out * cy.rows_next;
         for (int r = 0; r < rows; r++) ld.row(src + (size_t)r * stride);
     }
@@ -1495,6 +1496,7 @@ struct AttOutArgs {
     int ns;                // ring kernels: LDS slots
     unsigned long long *tl;
     unsigned *herr;
+    RingCarry cy;
 };
 
 // att_out dequant-GEMV + residual through f32 (rwkv.cu:548-553), R rows per group; commits state xy;
@@ -1509,6 +1511,7 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
     const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = D >> 4;
     tl_stamp(a.tl, 0);
+    if constexpr (RING) RWKV_ARGS_NOW(a.ybuf, a.partS, a.partM, a.n_part);
     const int G = (D + R - 1) / R;
     const int g0 = block_lo(G);
     const int g1 = block_hi(G);
@@ -1549,15 +1552,17 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
     if constexpr (RING) {
-        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + S * 3072);
+        constexpr bool CARRY = RING == 2;      // (needs D % R == 0: no overlapping last group)
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : S * 3072));
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            fail = glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
+            fail = glds_loader<R, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
             tl_stamp(a.tl, 2);
         } else {
-            ring_vec<1, S>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl, fail);
+            ring_vec<1, S, CARRY && RWKV_CARRY_VERIFY ? R : 0>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl, fail,
+                                                              CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rs, R});
             sc = scale_of(amax);
-            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail);
+            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, nullptr, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[R][S], wB[R][S];
