@@ -913,6 +913,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
     const int egrid = n * SEQ_O;
     const bool big = (D >> 6) > 8 * SEQ_O;       // octants of K = D longer than 8 k-blocks (D > 4096): the NKB = 10 instances
     static const int v012[5] = {0, 1, 2, 0, 0}, v0[5] = {0, 0, 0, 0, 0}, v00001[5] = {0, 0, 0, 0, 1};
+    bool tl_layer = false;     // debug timeline (rwkv_debug_timeline with RWKV_TL_CLASS = 10 + GEMM kind): the middle layer's GEMM stamps its phases
     // kind 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v: tile-per-wave GEMM over the 8 K-slices, partial values into pk
     auto gemm = [&](int kind, const uint8_t *bimg, const unsigned *rs8, int N, int K, int Q, const int *voq, unsigned *const *img, const SeqPart *qpart,
                     float *pk, double *state_dst) {
@@ -921,6 +922,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         for (int q = 0; q < 5; q++) g.vec_of_q[q] = q < Q ? voq[q] : voq[Q - 1];
         for (int k = 0; k < 3; k++) g.img[k] = reinterpret_cast<const u32x4 *>(img[k]);
         g.part = qpart; g.pk = pk; g.out = nullptr; g.T = n;
+        g.tl = (c->tl_on && c->tl_cls == 10 + kind && tl_layer) ? c->tl : nullptr;
         g.cp_src = S.state; g.cp_dst = state_dst; g.cp_n = (state_dst && !par) ? D : 0;   // GPT: commit the site's state behind it
         const int nch = (N + Q - 1) / Q, ntiles = Q * ((nch + 15) / 16);
         const int ntw_max = kind == 0 ? 3 : kind == 2 ? (big ? 4 : 5) : 1;
@@ -959,6 +961,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
     const uint64_t CBd = ((uint64_t)D + 15) / 16;
     resid(0, nullptr);     // LayerNorm statistics of the incoming residual stream (embedding rows, or the previous stage's output)
     for (uint64_t l = la; l < lb; l++) {
+        tl_layer = l == (c->l0 + c->l1) / 2;
         const size_t lo = (size_t)l * D, wl = (size_t)(l - c->l0);   // vectors are indexed by the model's layer, matrices by the stage's
         {   // time mix
             const double *mix[3] = {c->mixk + lo, c->mixv + lo, c->mixr + lo};
@@ -1519,7 +1522,13 @@ int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, ui
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     { const char *e = getenv("RWKV_TL_CLASS"); c->tl_cls = e ? atoi(e) : 3; }
     c->tl_on = true;
-    int rc = enqueue_token(c, false, nullptr);
+    int rc;
+    if (c->tl_cls >= 10) {          // a GEMM of the chunk path: one 32-row GPT chunk of this token
+        if (!c->seq_ok) { c->tl_on = false; return fail(RWKV_E_STATE, "the chunk path is not loaded (max_ctx 1)"); }
+        uint64_t toks[SEQ_T];
+        for (int t = 0; t < SEQ_T; t++) toks[t] = token;
+        rc = enqueue_chunk(c, toks, SEQ_T, 0, false);
+    } else rc = enqueue_token(c, false, nullptr);
     c->tl_on = false;
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, c->tl, n * 8, hipMemcpyDeviceToHost, c->stream));

@@ -522,6 +522,8 @@ struct SeqGemmArgs {
     const double *cp_src;        // piggy-back copy (stream-ordered behind the site kernel that produced it): the chunk's
     double *cp_dst;              // last LayerNorm output -> recurrent state; cp_n == 0: none
     int cp_n;
+    unsigned long long *tl;      // optional phase timeline (tl_stamp; tools/gemm_timeline.py): 0 entry, 1 requests issued, 2 activation image
+                                 // staged, 3 first batch / chunk multiplied and emitted, 4 last weights multiplied, 5 end
 };
 constexpr int SEQ_NT = 512;      // GEMM workgroup: 8 waves, two per SIMD
 constexpr int SEQ_NW = SEQ_NT / 64;
@@ -548,6 +550,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
     double *recl = reinterpret_cast<double *>(smem + (size_t)(DB ? 2 : 1) * CHU * 16);   // [NVS][SEQ_T]{scale, cA} of this slice
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    tl_stamp(a.tl, 0);
     // in flight per wave at the worst moment: record + row sums, the wave's share of the activation DMA, its weight loads
     // (x 2 register sets when double-buffered) -- the vmcnt counter has 6 bits
     static_assert(1 + NTW + (NVS * NKB * 6 + SEQ_NW - 1) / SEQ_NW + (DB ? 2 : 1) * NTW * NKB <= 63, "k_seq_gemm: more than 63 vector memory operations in flight");
@@ -636,9 +639,11 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     // unconditional (an empty slice copies nothing and loads clamped addresses): a branch here would make the compiler wait for
     // the weights where the record is used -- its count of what may be in flight is the minimum over the paths that join
     stage_a(0, 0); load_b(0, 0);
+    tl_stamp(a.tl, 1);
     wait_vm<NTW * NKB>();
     if (threadIdx.x < NVS * SEQ_T) { recl[2 * threadIdx.x] = scale_of(rc.amax); recl[2 * threadIdx.x + 1] = rc.cA; }
     __syncthreads();
+    tl_stamp(a.tl, 2);
 
     i32x4 acc[NTW][MTS ? 1 : 2][3];
     auto zero_acc = [&]() {
@@ -702,7 +707,8 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     if (MTS) {                        // single chunk: weights stay in registers for both row tiles
         if (TB0 < NTW) {
             for (int mt = 0; mt < 2; mt++) { zero_acc(); if (nchunk > 0) mult(0, 0, 0, mt, 0, TB0); emit(mt, 0, 0, TB0); }
-            for (int mt = 0; mt < 2; mt++) { zero_acc(); if (nchunk > 0) mult(0, 0, 0, mt, TB0, NTW); emit(mt, 0, TB0, NTW); }
+            tl_stamp(a.tl, 3);
+            for (int mt = 0; mt < 2; mt++) { zero_acc(); if (nchunk > 0) mult(0, 0, 0, mt, TB0, NTW); if (mt == 0) tl_stamp(a.tl, 4); emit(mt, 0, TB0, NTW); }
         } else {
             for (int mt = 0; mt < 2; mt++) {
                 zero_acc();
@@ -714,7 +720,9 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
         zero_acc();
         mult(0, 0, 0, 0, 0, TB0);
         emit(0, 0, 0, TB0); emit(1, 1, 0, TB0);
+        tl_stamp(a.tl, 3);
         mult(0, 0, 0, 0, TB0, NTW);
+        tl_stamp(a.tl, 4);
         emit(0, 0, TB0, NTW); emit(1, 1, TB0, NTW);
     } else {
         zero_acc();
@@ -734,10 +742,13 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
                     staged();
                 }
             }
+            if (c == 0) tl_stamp(a.tl, 3);
         }
+        tl_stamp(a.tl, 4);
         emit(0, 0);
         emit(1, 1);
     }
+    tl_stamp(a.tl, 5);
 }
 constexpr size_t seq_gemm_smem(int ntw, int nkb, bool mts, int nvs) { return (size_t)((!mts && ntw * nkb <= 16) ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
 
