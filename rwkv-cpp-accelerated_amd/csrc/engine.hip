@@ -161,6 +161,7 @@ struct rwkv_ctx {
     uint64_t L = 0, D = 0, maxT = 1;
     uint64_t l0 = 0, l1 = UINT64_MAX;   // pipeline stage: this context owns layers [l0, l1) (whole model by default)
     int S = 0;               // ceil(D / 1024): 1 KiB row pieces per lane
+    int seq_pipe = 15;       // chunk path: GEMM kinds (bit 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v) that run as k_seq_gemm_p (env RWKV_SEQ_PIPE)
     int carry_kib = -1;      // ring kernels: KiB of the NEXT ring kernel's rows a workgroup's loader leaves in LDS (kernels.hip.h "CARRY"; env RWKV_CARRY, 0 = off;
                              // default: 32 where it pays -- 4 KiB rows (7B: +1.3 %; 3B -1.3 %, 14B -2.6 %: profiles/r03/carry.txt) -- else 0)
     int carry_edges = 15;    //   which boundaries, by CONSUMER: bit 0 into k_ffn_rk, 1 into k_ffnv, 2 into k_att (of the next layer), 3 into k_attout (env RWKV_CARRY_EDGES)
@@ -616,6 +617,12 @@ int seq_smem_limits()
     SEQ_ALLOW(2, 5, 8, true, 2); SEQ_ALLOW(2, 4, 10, true, 2);
     SEQ_ALLOW(3, 1, 8, false, 1); SEQ_ALLOW(3, 1, 10, false, 1);
 #undef SEQ_ALLOW
+#define SEQ_ALLOW_P(TAG, NTW, NKB, NVS, DEPTH, MULTI) if (!rc) rc = allow_smem(k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI>, seq_gemm_p_smem(NKB, NVS, MULTI))
+    SEQ_ALLOW_P(0, 3, 8, 3, 2, false); SEQ_ALLOW_P(0, 3, 10, 2, 2, false);
+    SEQ_ALLOW_P(1, 1, 8, 1, 8, false); SEQ_ALLOW_P(1, 1, 10, 1, 10, false);
+    SEQ_ALLOW_P(2, 5, 8, 2, 2, false); SEQ_ALLOW_P(2, 4, 10, 2, 2, false);
+    SEQ_ALLOW_P(3, 1, 8, 1, 8, true); SEQ_ALLOW_P(3, 1, 10, 1, 10, true);
+#undef SEQ_ALLOW_P
     if (!rc) rc = allow_smem(k_seq_gemm_ks, SEQ_KS_SMEM);
     return rc;
 }
@@ -929,6 +936,15 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         const int RB = (ntiles + SEQ_NW * ntw_max - 1) / (SEQ_NW * ntw_max);
         g.ntw = (ntiles + SEQ_NW * RB - 1) / (SEQ_NW * RB);
         const dim3 grid(SEQ_O * RB), blk(SEQ_NT);
+#define SEQ_LAUNCH_P(TAG, NTW, NKB, NVS, DEPTH, MULTI) k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI><<<grid, blk, seq_gemm_p_smem(NKB, NVS, MULTI), st>>>(g)
+        if (c->seq_pipe & (1 << kind)) {       // the GEMM as a software pipeline over k-blocks (seq.hip.h k_seq_gemm_p; RWKV_SEQ_PIPE bit per kind)
+            if (kind == 0) { if (big) SEQ_LAUNCH_P(0, 3, 10, 2, 2, false); else SEQ_LAUNCH_P(0, 3, 8, 3, 2, false); }
+            else if (kind == 1) { if (big) SEQ_LAUNCH_P(1, 1, 10, 1, 10, false); else SEQ_LAUNCH_P(1, 1, 8, 1, 8, false); }
+            else if (kind == 2) { if (big) SEQ_LAUNCH_P(2, 4, 10, 2, 2, false); else SEQ_LAUNCH_P(2, 5, 8, 2, 2, false); }
+            else { if (big) SEQ_LAUNCH_P(3, 1, 10, 1, 10, true); else SEQ_LAUNCH_P(3, 1, 8, 1, 8, true); }
+            return;
+        }
+#undef SEQ_LAUNCH_P
 #define SEQ_LAUNCH(TAG, NTW, NKB, MTS, NVS) k_seq_gemm<TAG, NTW, NKB, MTS, NVS><<<grid, blk, seq_gemm_smem(NTW, NKB, MTS, NVS), st>>>(g)
         if (kind == 0) { if (big) SEQ_LAUNCH(0, 3, 10, false, 2); else SEQ_LAUNCH(0, 3, 8, false, 3); }
         else if (kind == 1) { if (big) SEQ_LAUNCH(1, 1, 10, false, 1); else SEQ_LAUNCH(1, 1, 8, false, 1); }
@@ -1094,6 +1110,7 @@ int rwkv_create(rwkv_ctx **out, int device)
     if (g && atoi(g) > 0) c->grid = atoi(g);
     { const char *e = getenv("RWKV_RING"); if (e) c->ring = atoi(e); }
     { const char *e = getenv("RWKV_CARRY"); if (e) c->carry_kib = atoi(e); }
+    { const char *e = getenv("RWKV_SEQ_PIPE"); if (e) c->seq_pipe = atoi(e); }
     { const char *e = getenv("RWKV_CARRY_EDGES"); if (e) c->carry_edges = atoi(e); }
     {
         static std::atomic<unsigned> serial{0u};

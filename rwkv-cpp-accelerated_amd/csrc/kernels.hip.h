@@ -825,6 +825,13 @@ __device__ __forceinline__ void dma_piece(const uint8_t *src, unsigned lds_dst)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
+// the same for data that OTHER workgroups of the XCD read as well (the chunk path's activation image): no "nt", it should stay in L2
+__device__ __forceinline__ void dma_piece_shared(const uint8_t *src, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
 // One row of S KiB as S DMA instructions that share ONE address register pair and one M0 value: the instruction offset advances
 // the global address AND the LDS address (tools/dmabench.hip, modes 2 / 6: every word verified).  A one-wave DMA stream is bounded
 // by the loader wave's instruction count -- at 7 instructions per piece it stood at 5.7 TB/s chip-wide, at 2 per piece 7.0 TB/s.

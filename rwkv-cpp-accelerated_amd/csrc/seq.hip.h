@@ -750,6 +750,181 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
     }
     tl_stamp(a.tl, 5);
 }
+// ------------------------------------------------------------------------------------------
+// k_seq_gemm_p: the same GEMM as a SOFTWARE PIPELINE over the slice's k-blocks (round 3).  The phase timeline of k_seq_gemm
+// (tools/gemm_timeline.py, profiles/r03/gemm_timeline.txt) showed why it ran at 3.3 TB/s: a wave that requests all its weights up
+// front BLOCKS AT ISSUE (a CU's memory path holds ~16 KB of requests), the workgroup barrier behind the requests is reached when
+// three quarters of the stream have arrived (12.5 of 17 us for ffn k/r), and the MFMAs, the epilogue and the partial-value stores
+// run BEHIND the stream instead of under it.  Here a wave keeps DEPTH k-blocks of its NTW tiles in flight in a rolling register
+// buffer: step f requests block f + DEPTH - 1, waits for block f, multiplies it against both row tiles of the chunk (no second
+// pass: without the resident weights the accumulators of both fit).  Slices longer than NKB k-blocks (ffn_v: K = 4 D) re-stage
+// the activation image per NKB blocks into the other LDS buffer, requested at the head of the previous group of blocks.
+// The weight loads are inline asm like the DMA: hipcc does not count asm in vmcnt, so its own waitcnt insertion would make every
+// wait for a weight block drain the DMA pieces requested behind it; all waits for them are explicit (in-order completion).
+__device__ __forceinline__ u32x4 load_b_asm(const u32x4 *p)
+{
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int TAG, int NTW, int NKB, int NVS, int DEPTH, bool MULTI>
+__global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(NKB % DEPTH == 0, "the rolling buffer's slot of a k-block must be a compile-time value");
+    constexpr int NBUF = MULTI ? 2 : 1;
+    constexpr int CHU = NVS * NKB * 384;                // units of one LDS buffer: [vector][k][row tile][limb][lane]
+    constexpr int PW = (NVS * NKB * 6 + SEQ_NW - 1) / SEQ_NW;      // DMA pieces (1 KiB) per wave and chunk; the last round is padded with duplicates
+    static_assert(PW + DEPTH * NTW + 2 + NTW <= 63, "k_seq_gemm_p: more than 63 vector memory operations in flight");
+    u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
+    double *recl = reinterpret_cast<double *>(smem + (size_t)NBUF * CHU * 16);   // [NVS][SEQ_T]{scale, cA} of this slice
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    tl_stamp(a.tl, 0);
+    const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
+    const int nch = (N + Q - 1) / Q, CB = (nch + 15) >> 4, ntiles = Q * CB;
+    const int j = blockIdx.x % SEQ_O, rb = blockIdx.x / SEQ_O;
+    const int kb0 = (int)(((long long)j * KB) / SEQ_O), kb1 = (int)(((long long)(j + 1) * KB) / SEQ_O);
+    const int nkb = kb1 - kb0, nchunk = (nkb + NKB - 1) / NKB;
+    if (blockIdx.x == gridDim.x - 1)
+        for (int q = threadIdx.x; q < a.cp_n; q += SEQ_NT) a.cp_dst[q] = a.cp_src[q];
+    const int ntw = a.ntw;
+    const int id0 = (rb * SEQ_NW + wave) * ntw;          // this wave's tiles: id0 .. id0 + ntw - 1
+    const int wg0 = rb * SEQ_NW * ntw, wg1 = min(wg0 + SEQ_NW * ntw, ntiles) - 1;
+    const int vlo = a.vec_of_q[min(wg0, ntiles - 1) / CB], vhi = a.vec_of_q[max(wg1, 0) / CB];
+    SeqPart rc;
+    {
+        const int tr = threadIdx.x < NVS * SEQ_T ? (int)threadIdx.x : 0;
+        const int v = min(vlo + tr / SEQ_T, vhi), t = tr % SEQ_T;
+        rc = a.part[((size_t)v * SEQ_T + t) * SEQ_O + j];
+    }
+    const u32x4 *wt[NTW];
+    int vi[NTW];
+    bool tv[NTW];
+    unsigned rsv[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; i++) {
+        const int id = id0 + i;
+        tv[i] = i < ntw && id < ntiles;
+        const int idc = tv[i] ? id : 0;
+        {
+            const int q = idc / CB, ch = 16 * (idc % CB) + (lane & 15), row = Q * ch + q;
+            rsv[i] = a.rs8[(size_t)j * N + ((ch < nch && row < N) ? row : 0)];
+        }
+        wt[i] = a.bimg + ((size_t)idc * KB) * 64 + lane;
+        vi[i] = a.vec_of_q[idc / CB] - vlo;
+        vi[i] = vi[i] < 0 ? 0 : (vi[i] >= NVS ? NVS - 1 : vi[i]);
+        vi[i] = __builtin_amdgcn_readfirstlane(vi[i]);
+    }
+    // activation image of chunk c (k-blocks kb0 + c NKB ...), vectors vlo .. vhi -> LDS buffer `buf`, flat piece index over
+    // [vector][1 KiB piece].  A kernel that re-stages (MULTI) must know how many pieces a wave has in flight: every wave issues
+    // exactly PW, an index past the end copies piece 0 of vector vlo again (same bytes, same place); the others issue what is needed.
+    // (What the image costs: a CU takes in ~25 KB/us whatever the source, and 32 rows x 3 limbs of the slice are 48 KiB per vector
+    // at D = 4096 -- 15 % on top of the weights for ffn k/r, 25 % for K/V/R, 75 % for att_out and ffn_v, whose workgroups own 128
+    // weight rows only.  The first version of this kernel padded EVERY kind to PW pieces: K/V/R got slower than the kernel it replaces.)
+    const unsigned abuf_lds = lds_addr(abuf);
+    const int nvec = min(vhi - vlo + 1, NVS);
+    auto piece = [&](int p, int kbs, int np, int buf) {
+        int v = p / (NKB * 6), pc = p % (NKB * 6);
+        if (v >= nvec || pc >= np) { v = 0; pc = 0; }
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(a.img[vlo + v] + (size_t)kbs * 384) + lane * 16 + (size_t)pc * 1024;
+        const unsigned dst = abuf_lds + (unsigned)(((size_t)buf * CHU + (size_t)v * NKB * 384) * 16) + (unsigned)pc * 1024u;
+        dma_piece_shared(np > 0 ? src : reinterpret_cast<const uint8_t *>(a.img[vlo]) + lane * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+    };
+    auto stage_a = [&](int c, int buf) {
+        const int kbs = kb0 + c * NKB, n = max(min(NKB, nkb - c * NKB), 0);
+        const int np = n * 6;
+        if (MULTI) {
+#pragma unroll
+            for (int r = 0; r < PW; r++) piece(wave + r * SEQ_NW, kbs, np, buf);
+        } else {
+            for (int v = 0; v < nvec; v++)
+                for (int pc = wave; pc < np; pc += SEQ_NW) piece(v * NKB * 6 + pc, kbs, np, buf);
+        }
+    };
+    u32x4 bwr[DEPTH][NTW];
+    // weights of the slice's k-block f (clamped past the end: the multiplication zeroes them) into slot f % DEPTH
+    auto load_k = [&](int f, int slot) {
+        const int kb = min(kb0 + min(f, max(nkb - 1, 0)), KB - 1);
+#pragma unroll
+        for (int i = 0; i < NTW; i++) bwr[slot][i] = load_b_asm(wt[i] + (size_t)kb * 64);
+    };
+    i32x4 acc[NTW][2][3];
+#pragma unroll
+    for (int i = 0; i < NTW; i++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) acc[i][mt][b] = i32x4{0, 0, 0, 0};
+
+    stage_a(0, 0);
+#pragma unroll
+    for (int f = 0; f < DEPTH - 1; f++) load_k(f, f);
+    tl_stamp(a.tl, 1);
+    wait_vm<(DEPTH - 1) * NTW>();            // this wave's share of the image is older than the weights
+    __syncthreads();
+    tl_stamp(a.tl, 2);
+    for (int c = 0; c < nchunk; c++) {
+        const bool more = MULTI && c + 1 < nchunk;
+        const int n = min(NKB, nkb - c * NKB);
+        const u32x4 *ab = abuf + (size_t)(MULTI ? (c & 1) : 0) * CHU + lane;
+#pragma unroll
+        for (int k = 0; k < NKB; k++) {
+            load_k(c * NKB + k + DEPTH - 1, (k + DEPTH - 1) % DEPTH);
+            if (k == 0 && more) stage_a(c + 1, (c + 1) & 1);
+            // block f = c NKB + k has landed when only what was requested behind it is outstanding: DEPTH - 1 blocks, and -- for the
+            // first DEPTH steps behind a re-staging -- the DMA pieces
+            if (more && k <= DEPTH - 1) wait_vm<(DEPTH - 1) * NTW + PW>(); else wait_vm<(DEPTH - 1) * NTW>();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool kv = k < n;
+            u32x4 av[2][3];
+            auto read_a = [&](int vv) {
+#pragma unroll
+                for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) av[ms][b] = ab[(((size_t)vv * NKB + k) * 2 + ms) * 3 * 64 + b * 64];
+            };
+            read_a(vi[0]);
+#pragma unroll
+            for (int i = 0; i < NTW; i++) {
+                if (NVS > 1 && i > 0 && vi[i] != vi[i - 1]) read_a(vi[i]);
+                const u32x4 w = bwr[k % DEPTH][i];
+                const i32x4 bf = i32x4{kv ? (int)w[0] : 0, kv ? (int)w[1] : 0, kv ? (int)w[2] : 0, kv ? (int)w[3] : 0};   // past the slice: zero weights
+#pragma unroll
+                for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        const i32x4 af = i32x4{(int)av[ms][b][0], (int)av[ms][b][1], (int)av[ms][b][2], (int)av[ms][b][3]};
+                        acc[i][ms][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[i][ms][b], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c == 0) tl_stamp(a.tl, 3);
+        if (more) __syncthreads();      // every wave's pieces of chunk c + 1 have landed (waited for above); everyone has left chunk c's buffer
+    }
+    wait_vm<0>();                       // the clamped requests past the end
+    tl_stamp(a.tl, 4);
+    // (the record and the row sums are first TOUCHED here: hipcc's own wait for them -- it cannot see the asm requests behind them --
+    // would otherwise drain the pipeline in front of the loop)
+    if (threadIdx.x < NVS * SEQ_T) { recl[2 * threadIdx.x] = scale_of(rc.amax); recl[2 * threadIdx.x + 1] = rc.cA; }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            if (!tv[i]) continue;
+            const int id = id0 + i;
+            const double *rl = recl + 2 * ((size_t)vi[i] * SEQ_T + mt * 16 + 4 * (lane >> 4));
+            float *dst = a.pk + ((((size_t)j * ntiles + id) * 2 + mt) * 4) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double M = (double)acc[i][mt][0][r] + 256.0 * (double)acc[i][mt][1][r] + 65536.0 * (double)acc[i][mt][2][r];
+                dst[r * 64] = (float)(rl[2 * r] * (M + rl[2 * r + 1] + SEQ_CU * (double)rsv[i]));   // scale_o (M + cA_o + CU rowsum_o)
+            }
+        }
+    tl_stamp(a.tl, 5);
+}
+constexpr size_t seq_gemm_p_smem(int nkb, int nvs, bool multi) { return (size_t)(multi ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
 constexpr size_t seq_gemm_smem(int ntw, int nkb, bool mts, int nvs) { return (size_t)((!mts && ntw * nkb <= 16) ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
 
 // ------------------------------------------------------------------------------------------
