@@ -196,3 +196,25 @@ def test_seq_stages_1_to_4_are_bit_identical_and_match_the_oracle(eng_mod, oracl
         assert np.abs(g[:n] - r[:n]).max() <= 1e-4 * max(1.0, np.abs(r).max()), name
     om.close()
 
+
+
+@pytest.mark.parametrize("L,D,T", [(2, 4096, 32), (2, 2560, 27), (2, 5120, 32), (3, 768, 70)])
+def test_pipelined_gemm_is_bit_identical_to_the_up_front_gemm(eng_mod, L, D, T, monkeypatch):
+    """RWKV_SEQ_PIPE: k_seq_gemm_p (a rolling register buffer of k-blocks, both row tiles at once, asm loads with explicit waits) and
+    k_seq_gemm (all weights requested up front) contract the same integers and fold them with the same f64 epilogue: logits rows
+    and state must be BIT-identical, kind by kind, for 4 KiB / 2.5 KiB / 5 KiB rows (the 10-block instances) and ragged chunks."""
+    t = mf.synthetic_tensors(L, D, seed=4242 + D)
+    toks = _toks(T, 5 * T + 1)
+    outs = {}
+    for pipe in ("0", "15", "1", "2", "4", "8"):
+        monkeypatch.setenv("RWKV_SEQ_PIPE", pipe)
+        m = eng_mod.RWKV(resident=True)
+        m.loadTensors(L, D, t, maxGPT=T)
+        lg = m.forward(toks, eng_mod.MODE_GPT)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+        m.pull_state(1)
+        outs[pipe] = (lg, [a.copy() for a in m.state.arrays()])
+        m.close()
+    for pipe in ("15", "1", "2", "4", "8"):
+        assert np.array_equal(outs["0"][0], outs[pipe][0]), pipe
+        for a, b in zip(outs["0"][1], outs[pipe][1]):
+            assert np.array_equal(a, b), pipe
