@@ -272,6 +272,13 @@ int ring_units(int nv, int S, bool common) { return (int)((LDS_BYTES - RED_BYTES
 int ring_xq_bytes(int nv, int S, bool common) { return (common ? 4 : nv) * S * 3072; }
 size_t smem_ring3(int nv, int S, bool common) { return RED_BYTES + (size_t)ring_xq_bytes(nv, S, common) + sizeof(GldsCtl) + (size_t)ring_units(nv, S, common) * S * 1024; }
 
+// k-blocks a wave of k_seq_gemm_p keeps in flight (K/V/R, ffn k/r at up to 4 KiB rows; a divisor of 8)
+#ifndef RWKV_SEQ_DEPTH0
+#define RWKV_SEQ_DEPTH0 2
+#endif
+#ifndef RWKV_SEQ_DEPTH2
+#define RWKV_SEQ_DEPTH2 2
+#endif
 #ifndef RWKV_ATTOUT_R
 #define RWKV_ATTOUT_R 2
 #endif
@@ -618,9 +625,9 @@ int seq_smem_limits()
     SEQ_ALLOW(3, 1, 8, false, 1); SEQ_ALLOW(3, 1, 10, false, 1);
 #undef SEQ_ALLOW
 #define SEQ_ALLOW_P(TAG, NTW, NKB, NVS, DEPTH, MULTI) if (!rc) rc = allow_smem(k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI>, seq_gemm_p_smem(NKB, NVS, MULTI))
-    SEQ_ALLOW_P(0, 3, 8, 3, 2, false); SEQ_ALLOW_P(0, 3, 10, 2, 2, false);
+    SEQ_ALLOW_P(0, 3, 8, 3, RWKV_SEQ_DEPTH0, false); SEQ_ALLOW_P(0, 3, 10, 2, 2, false);
     SEQ_ALLOW_P(1, 1, 8, 1, 8, false); SEQ_ALLOW_P(1, 1, 10, 1, 10, false);
-    SEQ_ALLOW_P(2, 5, 8, 2, 2, false); SEQ_ALLOW_P(2, 4, 10, 2, 2, false);
+    SEQ_ALLOW_P(2, 5, 8, 2, RWKV_SEQ_DEPTH2, false); SEQ_ALLOW_P(2, 4, 10, 2, 2, false);
     SEQ_ALLOW_P(3, 1, 8, 1, 8, true); SEQ_ALLOW_P(3, 1, 10, 1, 10, true);
 #undef SEQ_ALLOW_P
     if (!rc) rc = allow_smem(k_seq_gemm_ks, SEQ_KS_SMEM);
@@ -938,9 +945,9 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         const dim3 grid(SEQ_O * RB), blk(SEQ_NT);
 #define SEQ_LAUNCH_P(TAG, NTW, NKB, NVS, DEPTH, MULTI) k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI><<<grid, blk, seq_gemm_p_smem(NKB, NVS, MULTI), st>>>(g)
         if (c->seq_pipe & (1 << kind)) {       // the GEMM as a software pipeline over k-blocks (seq.hip.h k_seq_gemm_p; RWKV_SEQ_PIPE bit per kind)
-            if (kind == 0) { if (big) SEQ_LAUNCH_P(0, 3, 10, 2, 2, false); else SEQ_LAUNCH_P(0, 3, 8, 3, 2, false); }
+            if (kind == 0) { if (big) SEQ_LAUNCH_P(0, 3, 10, 2, 2, false); else SEQ_LAUNCH_P(0, 3, 8, 3, RWKV_SEQ_DEPTH0, false); }
             else if (kind == 1) { if (big) SEQ_LAUNCH_P(1, 1, 10, 1, 10, false); else SEQ_LAUNCH_P(1, 1, 8, 1, 8, false); }
-            else if (kind == 2) { if (big) SEQ_LAUNCH_P(2, 4, 10, 2, 2, false); else SEQ_LAUNCH_P(2, 5, 8, 2, 2, false); }
+            else if (kind == 2) { if (big) SEQ_LAUNCH_P(2, 4, 10, 2, 2, false); else SEQ_LAUNCH_P(2, 5, 8, 2, RWKV_SEQ_DEPTH2, false); }
             else { if (big) SEQ_LAUNCH_P(3, 1, 10, 1, 10, true); else SEQ_LAUNCH_P(3, 1, 8, 1, 8, true); }
             return;
         }

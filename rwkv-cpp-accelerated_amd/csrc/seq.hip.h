@@ -767,6 +767,17 @@ __device__ __forceinline__ u32x4 load_b_asm(const u32x4 *p)
     asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+// wait until only the `newer` k-blocks (NTW loads each) requested behind the wanted one -- and, with `dma`, PW DMA pieces -- are outstanding
+template <int NTW, int PW, int B> struct WaitBlocks {
+    static __device__ __forceinline__ void run(int newer, bool dma)
+    {
+        if (newer >= B) { if (dma) wait_vm<B * NTW + PW>(); else wait_vm<B * NTW>(); }
+        else WaitBlocks<NTW, PW, B - 1>::run(newer, dma);
+    }
+};
+template <int NTW, int PW> struct WaitBlocks<NTW, PW, 0> {
+    static __device__ __forceinline__ void run(int, bool dma) { if (dma) wait_vm<PW>(); else wait_vm<0>(); }
+};
 template <int TAG, int NTW, int NKB, int NVS, int DEPTH, bool MULTI>
 __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
 {
@@ -842,11 +853,14 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
         }
     };
     u32x4 bwr[DEPTH][NTW];
-    // weights of the slice's k-block f (clamped past the end: the multiplication zeroes them) into slot f % DEPTH
+    // weights of the slice's k-block f into slot f % DEPTH; nothing is requested past the slice's end (a request nobody uses would
+    // still have to land before the epilogue: 1-2 us), so the waits count the blocks that really are behind the wanted one
     auto load_k = [&](int f, int slot) {
-        const int kb = min(kb0 + min(f, max(nkb - 1, 0)), KB - 1);
+        if (f < nkb) {
+            const int kb = min(kb0 + f, KB - 1);
 #pragma unroll
-        for (int i = 0; i < NTW; i++) bwr[slot][i] = load_b_asm(wt[i] + (size_t)kb * 64);
+            for (int i = 0; i < NTW; i++) bwr[slot][i] = load_b_asm(wt[i] + (size_t)kb * 64);
+        }
     };
     i32x4 acc[NTW][2][3];
 #pragma unroll
@@ -860,7 +874,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
 #pragma unroll
     for (int f = 0; f < DEPTH - 1; f++) load_k(f, f);
     tl_stamp(a.tl, 1);
-    wait_vm<(DEPTH - 1) * NTW>();            // this wave's share of the image is older than the weights
+    WaitBlocks<NTW, PW, DEPTH - 1>::run(min(DEPTH - 1, nkb), false);     // this wave's share of the image is older than the weights
     __syncthreads();
     tl_stamp(a.tl, 2);
     for (int c = 0; c < nchunk; c++) {
@@ -869,13 +883,14 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
         const u32x4 *ab = abuf + (size_t)(MULTI ? (c & 1) : 0) * CHU + lane;
 #pragma unroll
         for (int k = 0; k < NKB; k++) {
-            load_k(c * NKB + k + DEPTH - 1, (k + DEPTH - 1) % DEPTH);
+            if (k >= n) continue;                   // (wave-uniform) past the slice's end
+            const int f = c * NKB + k;
+            load_k(f + DEPTH - 1, (k + DEPTH - 1) % DEPTH);
             if (k == 0 && more) stage_a(c + 1, (c + 1) & 1);
-            // block f = c NKB + k has landed when only what was requested behind it is outstanding: DEPTH - 1 blocks, and -- for the
-            // first DEPTH steps behind a re-staging -- the DMA pieces
-            if (more && k <= DEPTH - 1) wait_vm<(DEPTH - 1) * NTW + PW>(); else wait_vm<(DEPTH - 1) * NTW>();
+            // block f has landed when only what was requested behind it is outstanding: up to DEPTH - 1 blocks, and -- for the first
+            // DEPTH steps behind a re-staging -- the DMA pieces
+            WaitBlocks<NTW, PW, DEPTH - 1>::run(min(DEPTH - 1, nkb - 1 - f), more && k <= DEPTH - 1);
             __builtin_amdgcn_sched_barrier(0);
-            const bool kv = k < n;
             u32x4 av[2][3];
             auto read_a = [&](int vv) {
 #pragma unroll
@@ -888,7 +903,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
             for (int i = 0; i < NTW; i++) {
                 if (NVS > 1 && i > 0 && vi[i] != vi[i - 1]) read_a(vi[i]);
                 const u32x4 w = bwr[k % DEPTH][i];
-                const i32x4 bf = i32x4{kv ? (int)w[0] : 0, kv ? (int)w[1] : 0, kv ? (int)w[2] : 0, kv ? (int)w[3] : 0};   // past the slice: zero weights
+                const i32x4 bf = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
 #pragma unroll
                 for (int ms = 0; ms < 2; ms++)
 #pragma unroll
@@ -902,7 +917,6 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
         if (c == 0) tl_stamp(a.tl, 3);
         if (more) __syncthreads();      // every wave's pieces of chunk c + 1 have landed (waited for above); everyone has left chunk c's buffer
     }
-    wait_vm<0>();                       // the clamped requests past the end
     tl_stamp(a.tl, 4);
     // (the record and the row sums are first TOUCHED here: hipcc's own wait for them -- it cannot see the asm requests behind them --
     // would otherwise drain the pipeline in front of the loop)

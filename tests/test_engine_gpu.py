@@ -390,19 +390,31 @@ def test_load_file_streams_through_pinned_staging(eng_mod, tmp_path):
     a.close(); b.close()
 
 
-def test_a_lost_ring_hand_off_fails_the_call_instead_of_returning_garbage(built, tmp_path):
+@pytest.fixture(scope="module")
+def fault_libs(built, tmp_path_factory):
+    """two variants of the engine with a fault built in (the loader loses a group / damages what it carries), compiled side by side"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", "engine.hip")
+    d = tmp_path_factory.mktemp("fault_libs")
+    libs = {"drop": (str(d / "lib_drop.so"), "-DRWKV_TEST_DROP_GROUP=1"), "corrupt": (str(d / "lib_corrupt.so"), "-DRWKV_TEST_CORRUPT_CARRY=1")}
+    procs = [subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", flag, src, "-o", lib])
+             for lib, flag in libs.values()]
+    for pr in procs:
+        assert pr.wait(timeout=900) == 0
+    return {k: v[0] for k, v in libs.items()}
+
+
+
+def test_a_lost_ring_hand_off_fails_the_call_instead_of_returning_garbage(fault_libs):
     """every wait of the LDS-ring kernels is bounded; one that gives up is recorded and reported (kernels.hip.h ring_report,
     engine.hip device_check): a variant of the engine whose loader wave never issues a workgroup's last group
     (-DRWKV_TEST_DROP_GROUP=1, built here with hipcc) must fail the forward with RWKV_E_DEVICE, and the context must be usable
     for error reporting afterwards -- no hang, no silently wrong logits.  Runs in a subprocess (RWKV_LIB selects the variant)."""
     import subprocess
     import sys
-    import shutil
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    src = os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", "engine.hip")
-    lib = str(tmp_path / "lib_drop.so")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-                           "-DRWKV_TEST_DROP_GROUP=1", src, "-o", lib], timeout=600)
+    lib = fault_libs["drop"]
     code = (
         "import sys, numpy as np\n"
         f"sys.path.insert(0, {ROOT!r})\n"
@@ -463,16 +475,10 @@ def test_rows_carried_across_kernel_boundaries_are_found_and_change_nothing(buil
     assert get(off, "HITS")[0].split()[1:] == ["0", "0"]
 
 
-def test_damaged_carried_rows_fail_the_call(built, tmp_path):
+def test_damaged_carried_rows_fail_the_call(fault_libs):
     """rows that waited in LDS across a kernel boundary are checked against their row sums before they are used: an engine variant
     whose loader flips one bit of what it carries (-DRWKV_TEST_CORRUPT_CARRY=1) must fail with RWKV_E_DEVICE and say what to do."""
-    import subprocess
-    import shutil
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    src = os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", "engine.hip")
-    lib = str(tmp_path / "lib_corrupt.so")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-                           "-DRWKV_TEST_CORRUPT_CARRY=1", src, "-o", lib], timeout=600)
+    lib = fault_libs["corrupt"]
     out = _run_py(_CARRY_PROBE.format(root=ROOT, L=2, D=4096), RWKV_LIB=lib, RWKV_CARRY="32")
     assert "RWKVERROR" in out.stdout and "arrived damaged" in out.stdout and "RWKV_CARRY=0" in out.stdout and "status -3" in out.stdout, \
         out.stdout[-500:] + out.stderr[-400:]
