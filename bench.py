@@ -189,7 +189,7 @@ def main():
         kernels={k: dict(us=round(v["us"], 3), GBps=round(v["gbps"], 1), us_event_pair=round(v["us_event_pair"], 3))
                  for k, v in per_launch.items()},
         load_s=round(load_s, 2),
-        carry=dict(RWKV_CARRY=os.environ.get("RWKV_CARRY", "default: 32 KiB per workgroup where rows are 4 KiB (7B), else off"),
+        carry=dict(RWKV_CARRY=os.environ.get("RWKV_CARRY", "default: 32 KiB per workgroup where rows are 4 KiB (7B), 20 where they are 3 KiB (3B), else off"),
                    note="ring kernels leave the first rows of the next ring kernel in the CU's LDS across the kernel boundary; "
                         "checked against their row sums before use (DESIGN.md 4.5; 7B: 565 -> 572 tokens/s, profiles/r03/carry.txt)"),
         hbm_resident_bytes=dict(total=m.resident_bytes(),

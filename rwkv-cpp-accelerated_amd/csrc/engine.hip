@@ -163,7 +163,8 @@ struct rwkv_ctx {
     int S = 0;               // ceil(D / 1024): 1 KiB row pieces per lane
     int seq_pipe = 15;       // chunk path: GEMM kinds (bit 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v) that run as k_seq_gemm_p (env RWKV_SEQ_PIPE)
     int carry_kib = -1;      // ring kernels: KiB of the NEXT ring kernel's rows a workgroup's loader leaves in LDS (kernels.hip.h "CARRY"; env RWKV_CARRY, 0 = off;
-                             // default: 32 where it pays -- 4 KiB rows (7B: +1.3 %; 3B -1.3 %, 14B -2.6 %: profiles/r03/carry.txt) -- else 0)
+                             // default: where it pays -- 32 at 4 KiB rows (7B: +1.3 %), 20 at 3 KiB rows (3B: +3.3 %; 32: -0.7 %) -- else 0 (14B: -2.2 %;
+                             // profiles/r03/carry.txt))
     int carry_edges = 15;    //   which boundaries, by CONSUMER: bit 0 into k_ffn_rk, 1 into k_ffnv, 2 into k_att (of the next layer), 3 into k_attout (env RWKV_CARRY_EDGES)
     unsigned nonce[2] = {0u, 0u};   //   stamp of this context's carried rows
     unsigned *carry_hits = nullptr; //   debug counters (env RWKV_CARRY_COUNT=1; rwkv_debug_carry_hits)
@@ -670,7 +671,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     HIPCHK(hipSetDevice(c->device));
     c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
     if (c->ring < 0) c->ring = (c->S == 3 || c->S == 4) ? 13 : (c->S == 5 ? 5 : 0);
-    if (c->carry_kib < 0) c->carry_kib = c->S == 4 ? 32 : 0;
+    if (c->carry_kib < 0) c->carry_kib = c->S == 4 ? 32 : c->S == 3 ? 20 : 0;
     if (c->l1 == UINT64_MAX) c->l1 = L;
     if (getenv("RWKV_CARRY_COUNT") && !c->carry_hits) {
         int rcc = dalloc(c, &c->carry_hits, 4);
