@@ -167,6 +167,8 @@ struct rwkv_ctx {
                              // profiles/r03/carry.txt))
     int carry_edges = 15;    //   which boundaries, by CONSUMER: bit 0 into k_ffn_rk, 1 into k_ffnv, 2 into k_att (of the next layer), 3 into k_attout (env RWKV_CARRY_EDGES)
     unsigned nonce[2] = {0u, 0u};   //   stamp of this context's carried rows
+    bool carry_active = true;       //   this context is the only one of the process on its device (carry_policy)
+    unsigned carry_epoch = 0u;      //   g_ctx_epoch when that was last looked at
     unsigned *carry_hits = nullptr; //   debug counters (env RWKV_CARRY_COUNT=1; rwkv_debug_carry_hits)
     int ring = RWKV_RING;    // decode kernels that stream their weights through the LDS ring (bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv, 4 k_head; env RWKV_RING)
 
@@ -315,7 +317,7 @@ struct ArgMaker {
     explicit ArgMaker(rwkv_ctx *c_, bool chain_ = false) : c(c_), D((int)c_->D), grid(c_->grid), LD((size_t)c_->L * c_->D), chain(chain_)
     {
         n_first = grid < 32 ? grid : 32;
-        common = c->carry_kib > 0 && c->carry_edges != 0 && D % grid == 0 && D / grid >= 2 && (c->ring & 13) != 0;
+        common = c->carry_kib > 0 && c->carry_active && c->carry_edges != 0 && D % grid == 0 && D / grid >= 2 && (c->ring & 13) != 0;
     }
     // ---- the carry plan: who streams the first rows of whom.  Ring kernels of a layer in launch order: 1 k_att, 2 k_attout (only when
     // it is on the ring), 3 k_ffn_rk, 4 k_ffnv; a k_attout in register form is stepped over (it stays below the ring's LDS) ----
@@ -568,6 +570,7 @@ int enqueue_token(rwkv_ctx *c, bool with_argmax, hipEvent_t *ev)
     return 0;
 }
 
+int carry_policy(rwkv_ctx *c);
 int build_graph(rwkv_ctx *c, bool with_argmax, hipGraphExec_t *out)
 {
     hipGraph_t g = nullptr;
@@ -880,6 +883,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if (c->seq_ok && (rc = seq_smem_limits())) return rc;
     const char *nograph = getenv("RWKV_NO_GRAPH");
     if (!(nograph && nograph[0] == '1')) {
+        if ((rc = carry_policy(c))) return rc;      // (no graphs yet: only decides whether this context carries)
         if ((rc = build_graph(c, false, &c->g_fwd))) return rc;
         if ((rc = build_graph(c, true, &c->g_greedy))) return rc;
     }
@@ -1088,6 +1092,27 @@ uint64_t split_point(const rwkv_ctx *c, int k, int n)
     return l;
 }
 
+// Rows carried in LDS across kernel boundaries pay only while THIS context's kernels follow each other on the CUs: with two contexts
+// decoding at once (two models, two streams of one model) nearly every workgroup finds that the other context's kernel has had its
+// CU (hits 1.2 %, profiles/r03/carry.txt) and the rows left for it were streamed for nothing -- 678 -> 656 tokens/s aggregate.  So
+// the carry is on only while a context is alone on its device in this process (RWKV_CARRY_SHARED=1: always); the token graphs are
+// re-captured at the next call after that changed.
+std::atomic<int> g_ctx_live[64];
+std::atomic<unsigned> g_ctx_epoch{1u};
+int carry_policy(rwkv_ctx *c)
+{
+    const unsigned e = g_ctx_epoch.load(std::memory_order_acquire);
+    if (e == c->carry_epoch) return 0;
+    c->carry_epoch = e;
+    const bool shared = getenv("RWKV_CARRY_SHARED") != nullptr;
+    const bool want = shared || g_ctx_live[c->device & 63].load(std::memory_order_acquire) <= 1;
+    if (want == c->carry_active) return 0;
+    c->carry_active = want;
+    if (!c->loaded || (!c->g_fwd && !c->g_greedy)) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return rebuild_graphs(c);
+}
+
 int run_token(rwkv_ctx *c, bool with_argmax)
 {
     hipGraphExec_t g = with_argmax ? c->g_greedy : c->g_fwd;
@@ -1138,6 +1163,8 @@ int rwkv_create(rwkv_ctx **out, int device)
     }
     *c->herr = 0u;
     c->d_herr = static_cast<unsigned *>(dp);
+    g_ctx_live[device & 63].fetch_add(1, std::memory_order_acq_rel);
+    g_ctx_epoch.fetch_add(1u, std::memory_order_acq_rel);
     *out = c;
     return 0;
 }
@@ -1193,6 +1220,7 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
     for (uint64_t t = 0; t < T; t++)
         if (tokens[t] >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id %llu out of range", (unsigned long long)tokens[t]);
     HIPCHK(hipSetDevice(c->device));
+    { const int rcp = carry_policy(c); if (rcp) return rcp; }
     if (T >= 2 && c->seq_ok && c->l0 == 0 && c->l1 == c->L) {   // prompt chunks (GPT) / batched decode step of T streams (PARRALEL): weights read once per <= 32 rows
         const uint64_t nchunks = (T + SEQ_T - 1) / SEQ_T;
         int rc = 0;
@@ -1259,6 +1287,7 @@ int rwkv_stage_forward(rwkv_ctx *c, uint64_t token, uint32_t slot, uint64_t *pic
     if (slot >= c->maxT) return fail(RWKV_E_ARG, "state slot %u out of range (max context %llu)", slot, (unsigned long long)c->maxT);
     if (c->l0 == 0 && token >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
     HIPCHK(hipSetDevice(c->device));
+    { const int rcp = carry_policy(c); if (rcp) return rcp; }
     c->h_ctl[0].token = token; c->h_ctl[0].slot = slot; c->h_ctl[0].out_row = slot; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     const bool last = c->l1 == c->L;
@@ -1321,6 +1350,7 @@ int rwkv_decode_greedy(rwkv_ctx *c, uint64_t first_token, uint64_t n, uint64_t *
     if (first_token >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
     if (n == 0 || n > c->gen_cap) return fail(RWKV_E_ARG, "n_tokens must be in 1..%u", c->gen_cap);
     HIPCHK(hipSetDevice(c->device));
+    { const int rcp = carry_policy(c); if (rcp) return rcp; }
     c->h_ctl[0].token = first_token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     for (uint64_t i = 0; i < n; i++) {
@@ -1377,6 +1407,7 @@ int rwkv_decode_typical(rwkv_ctx *c, uint64_t first_token, uint64_t n, float tem
     if (n == 0 || n > c->gen_cap) return fail(RWKV_E_ARG, "n_tokens must be in 1..%u", c->gen_cap);
     if (!(temp > 0.f)) return fail(RWKV_E_ARG, "need temp > 0");
     HIPCHK(hipSetDevice(c->device));
+    { const int rcp = carry_policy(c); if (rcp) return rcp; }
     c->h_ctl[0].token = first_token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     for (uint64_t i = 0; i < n; i++) {
@@ -1397,6 +1428,8 @@ void rwkv_free(rwkv_ctx *c)
     if (c->g_fwd) { (void)hipGraphExecDestroy(c->g_fwd); c->g_fwd = nullptr; }
     if (c->g_greedy) { (void)hipGraphExecDestroy(c->g_greedy); c->g_greedy = nullptr; }
     rwkv_pipe_free(c);        // (no graphs left to re-capture)
+    g_ctx_live[c->device & 63].fetch_sub(1, std::memory_order_acq_rel);
+    g_ctx_epoch.fetch_add(1u, std::memory_order_acq_rel);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->herr) (void)hipHostFree(c->herr);
@@ -1445,6 +1478,7 @@ int rwkv_profile_token(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint64
     if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
     if (token >= RWKV_VOCAB || reps <= 0) return fail(RWKV_E_ARG, "bad token / reps");
     HIPCHK(hipSetDevice(c->device));
+    { const int rcp = carry_policy(c); if (rcp) return rcp; }
     const uint64_t L = c->L, D = c->D, V = RWKV_VOCAB;
     const int nev = (int)(4 * (c->l1 - c->l0) + 4);
     std::vector<hipEvent_t> ev(nev);
@@ -1489,6 +1523,7 @@ int rwkv_profile_batched(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint
     if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
     if (token >= RWKV_VOCAB || reps <= 0) return fail(RWKV_E_ARG, "bad token / reps");
     HIPCHK(hipSetDevice(c->device));
+    { const int rcp = carry_policy(c); if (rcp) return rcp; }
     c->h_ctl[0].token = token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     int rc = enqueue_token(c, true, nullptr);   // valid inputs for every class
@@ -1541,6 +1576,7 @@ int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, ui
     const size_t n = (size_t)c->grid * NW * 8;
     if (cap < n) return fail(RWKV_E_ARG, "need room for %zu stamps", n);
     HIPCHK(hipSetDevice(c->device));
+    { const int rcp = carry_policy(c); if (rcp) return rcp; }
     if (!c->tl) { int rc = dalloc(c, &c->tl, n); if (rc) return rc; }
     HIPCHK(hipMemsetAsync(c->tl, 0, n * 8, c->stream));
     c->h_ctl[0].token = token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
@@ -1718,6 +1754,7 @@ int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps
     if (rank == 0)
         for (int k = 0; k < S; k++) bad_id = bad_id || first_tokens[k] >= RWKV_VOCAB;
     HIPCHK(hipSetDevice(c->device));
+    { const int rcp = carry_policy(c); if (rcp) return rcp; }
     if (c->pipe_ring_cap < n_items) {
         if (c->pipe_ring) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->pipe_ring); c->pipe_ring = nullptr; c->pipe_ring_cap = 0; }
         HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->pipe_ring), sizeof(Ctl) * n_items, hipHostMallocDefault));

@@ -484,3 +484,49 @@ def test_damaged_carried_rows_fail_the_call(fault_libs):
         out.stdout[-500:] + out.stderr[-400:]
     ok = _run_py(_CARRY_PROBE.format(root=ROOT, L=2, D=4096), RWKV_LIB=lib, RWKV_CARRY="0")
     assert "IDS" in ok.stdout and "RWKVERROR" not in ok.stdout, ok.stdout[-400:]
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_two_contexts_decoding_at_once_do_not_take_each_others_rows(built, shared, monkeypatch):
+    """two contexts of one process, a stream and a host thread each, greedy-decoding AT THE SAME TIME.  With the carry forced on
+    (RWKV_CARRY_SHARED=1) their kernels interleave on the CUs, so a workgroup regularly finds that another context's kernel has had
+    its CU since its predecessor left rows there (every ring kernel clears the stamp on entry; the stamp carries the context's
+    nonce): it must then load its rows itself -- ids equal to the same decode run alone, no RWKV_E_DEVICE from the row-sum check.
+    By default the engine turns the carry off while a context is not alone on its device (engine.hip carry_policy: the rows would be
+    streamed for nothing) and re-captures its token graphs: same ids again."""
+    import threading
+    if shared:
+        monkeypatch.setenv("RWKV_CARRY_SHARED", "1")
+    else:
+        monkeypatch.delenv("RWKV_CARRY_SHARED", raising=False)
+    import torch
+    from rwkv_cpp_accelerated_amd import engine
+    L, D, steps = 4, 4096, 96
+    ms, alone = [], []
+    for i in range(2):
+        m = engine.RWKV(resident=True)
+        m.loadTensors(L, D, mf.synthetic_tensors(L, D, seed=31 + i))
+        ms.append(m)
+    for i, m in enumerate(ms):
+        alone.append(m.decode_greedy(5 + i, steps).copy())
+    for rep in range(3):
+        outs, errs = [None, None], []
+
+        def run(i):
+            try:
+                outs[i] = ms[i].decode_greedy(5 + i, steps)
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+        for m in ms:                    # same starting point as the run alone
+            m.reset_state()
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        for i in range(2):
+            assert np.array_equal(outs[i], alone[i]), (rep, i)
+    for m in ms:
+        m.close()
+    torch.cuda.synchronize()
