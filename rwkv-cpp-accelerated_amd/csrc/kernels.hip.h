@@ -934,6 +934,18 @@ struct GldsCtl {            // LDS control block of the ring (80 dwords)
 // them as landed and starts its stream behind them; if not -- another kernel ran on the CU in between, the block landed elsewhere
 // -- it loads everything as before.  Every ring kernel clears the stamp on entry, so one is only ever alive between two adjacent
 // kernels of one graph replay; the weights behind it are immutable for the life of the context.
+// A kernel of this engine that is NOT part of the decode chain but whose LDS allocation reaches past a ring kernel's control block
+// (the chunk path's GEMMs: another context, another process of the same engine sharing the GPU) may run on a CU between two decode
+// kernels and write over carried rows WITHOUT writing over the stamp (its allocation is not written everywhere).  It clears the
+// stamp of every row size first, so the consumer loads its rows itself instead of failing the row-sum check.
+__device__ __forceinline__ void carry_kill_stamps(unsigned char *smem, unsigned alloc_bytes)
+{
+    if (threadIdx.x < 20) {
+        const unsigned S = threadIdx.x / 4 + 1;
+        const unsigned off = (unsigned)RED_BYTES + 4u * S * 3072u + (unsigned)offsetof(GldsCtl, stamp) + 4u * (threadIdx.x & 3);
+        if (off + 4u <= alloc_bytes) *reinterpret_cast<unsigned *>(smem + off) = 0u;
+    }
+}
 struct RingCarry {
     const uint8_t *w_next;      // the next ring kernel's weights: its group g = rows_next rows of D bytes from w_next + g * rows_next * D
     int rows_next, n_out;       // prefetch n_out groups of rows_next rows for it (0: none)

@@ -526,6 +526,11 @@ struct SeqGemmArgs {
                                  // staged, 3 first batch / chunk multiplied and emitted, 4 last weights multiplied, 5 end
 };
 constexpr int SEQ_NT = 512;      // GEMM workgroup: 8 waves, two per SIMD
+// dynamic LDS of the GEMM kernels
+constexpr size_t seq_gemm_smem(int ntw, int nkb, bool mts, int nvs) { return (size_t)((!mts && ntw * nkb <= 16) ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
+constexpr size_t seq_gemm_p_smem(int nkb, int nvs, bool multi) { return (size_t)(multi ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
+constexpr int SEQ_TB = 5;        // weight tiles (16 rows each) per workgroup pass of k_seq_gemm_ks
+constexpr size_t SEQ_KS_SMEM = sizeof(float) * SEQ_O * SEQ_TB * 2 * 4 * 64 + sizeof(float) * SEQ_T;
 constexpr int SEQ_NW = SEQ_NT / 64;
 
 // value of one slice: scale_o (M + cA_o + CU * rowsum_o)
@@ -545,6 +550,8 @@ template <int TAG, int NTW, int NKB, bool MTS, int NVS>
 __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    carry_kill_stamps(smem, (unsigned)seq_gemm_smem(NTW, NKB, MTS, NVS));
+    __syncthreads();      // (in front of this kernel's own copies into the same places)
     constexpr bool DB = !MTS && NTW * NKB <= 16;        // second weight register set + second LDS buffer
     constexpr int CHU = NVS * NKB * 384;                // units of one LDS buffer: [vector][k][row tile][limb][lane]
     u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
@@ -782,6 +789,8 @@ template <int TAG, int NTW, int NKB, int NVS, int DEPTH, bool MULTI>
 __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    carry_kill_stamps(smem, (unsigned)seq_gemm_p_smem(NKB, NVS, MULTI));
+    __syncthreads();      // (in front of this kernel's own copies into the same places)
     static_assert(NKB % DEPTH == 0, "the rolling buffer's slot of a k-block must be a compile-time value");
     constexpr int NBUF = MULTI ? 2 : 1;
     constexpr int CHU = NVS * NKB * 384;                // units of one LDS buffer: [vector][k][row tile][limb][lane]
@@ -938,11 +947,8 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
         }
     tl_stamp(a.tl, 5);
 }
-constexpr size_t seq_gemm_p_smem(int nkb, int nvs, bool multi) { return (size_t)(multi ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
-constexpr size_t seq_gemm_smem(int ntw, int nkb, bool mts, int nvs) { return (size_t)((!mts && ntw * nkb <= 16) ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
 
 // ------------------------------------------------------------------------------------------
-constexpr int SEQ_TB = 5;        // weight tiles (16 rows each) per workgroup pass of k_seq_gemm_ks
 // operands of one k-block: B fragments of NTL tiles and the A fragments of the pass's vector
 template <int NTL> struct SeqFrag { u32x4 bw[NTL]; u32x4 af[2][3]; };
 template <int NTL>
@@ -1000,6 +1006,8 @@ __device__ __forceinline__ void seq_pass(i32x4 (&acc)[SEQ_TB][2][3], const u32x4
 __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_ks(SeqGemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    carry_kill_stamps(smem, (unsigned)SEQ_KS_SMEM);
+    __syncthreads();      // (this kernel does write the places it clears, later)
     float (*accl)[SEQ_TB][2][4][64] = reinterpret_cast<float (*)[SEQ_TB][2][4][64]>(smem);   // [octant][tile][row tile][reg][lane], 80 KiB
     float *sol = reinterpret_cast<float *>(smem + sizeof(float) * SEQ_O * SEQ_TB * 2 * 4 * 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1082,6 +1090,5 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_ks(SeqGemmArgs a)
     }
 }
 
-constexpr size_t SEQ_KS_SMEM = sizeof(float) * SEQ_O * SEQ_TB * 2 * 4 * 64 + sizeof(float) * SEQ_T;
 
 } // namespace rwkvk
