@@ -1,5 +1,5 @@
 // dmabench.hip -- what does ONE loader wave per CU sustain with global_load_lds_dwordx4 into an LDS ring, and what do the pieces of
-// the one-launch token's loader protocol (csrc/mega.hip.h) cost?  256 workgroups x 512 threads, wave 7 loads, waves 0..6 consume.
+// the ring loader protocol (round 2: built for the one-launch token, now the ring kernels of csrc/kernels.hip.h) cost?  256 workgroups x 512 threads, wave 7 loads, waves 0..6 consume.
 //   mode 0: issue only (vmcnt cap), nobody reads the ring
 //   mode 1: + vmcnt read (s_getreg IB_STS) and a `landed` store per unit
 //   mode 2: + consumers: wait landed, copy a 4-unit group to registers, free it; loader waits for room through freeq flags (in order)
