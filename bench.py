@@ -27,6 +27,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+USABLE_CPUS = None               # (usable CPUs, cgroup quota): read at the top of main()
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290
 
 
@@ -35,10 +36,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)     # BASELINE: 1024-token greedy continuation
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--model", default=os.environ.get("RWKV_BENCH_MODEL", "7B"))
+    ap.add_argument("--model", default=os.environ.get("RWKV_BENCH_MODEL"), help="default: 7B on one GPU (BASELINE config 3, the headline); "
+                    "14B when the layers are pipelined over N > 1 GPUs (BASELINE config 4)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the timed tokens of the CPU baseline leg (8 to 32 tokens)")
     ap.add_argument("--ref-steps", type=int, default=1024, help="greedy steps of the reference's own kernel (oracle/_ref/libref.so) "
                     "timed on this GPU and used as the parity gate of the engine (north_star: 1024); 0 = skip")
     ap.add_argument("--ref-seconds", type=float, default=150.0, help="wall-time bound of the reference-kernel leg")
@@ -49,6 +51,14 @@ def main():
     ap.add_argument("--parallel", choices=["pipeline", "replicas"], default=os.environ.get("RWKV_BENCH_PARALLEL", "pipeline"),
                     help="N > 1: layer pipeline over RCCL send/recv with N streams in flight (default), or N independent replicas")
     args = ap.parse_args()
+    if args.model is None:
+        args.model = "14B" if args.gpus > 1 and args.parallel == "pipeline" else "7B"
+    # the CPU baseline's OpenMP placement must be fixed before the first OpenMP runtime of the process is loaded (torch brings one) --
+    # and the CPUs this process may use must be read BEFORE that: a bound OpenMP runtime pins the main thread to its first place
+    global USABLE_CPUS
+    USABLE_CPUS = usable_cpus()
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
     import numpy as np
     import torch
@@ -69,7 +79,7 @@ def main():
         if os.environ.get("RWKV_BENCH_ONE_DEVICE") == "1":
             local_rank = 0
         kw = dict(device_id=torch.device("cuda", local_rank)) if backend == "nccl" else {}
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180), **kw)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1800), **kw)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -105,11 +115,13 @@ def main():
         ids = m.decode_greedy(first, args.warmup)
         first = int(ids[-1])
 
+    m.carry_stats()                                   # (zeroes the carry counters: what is read below is the timed region's)
     sync_all()
     t0 = time.perf_counter()
     ids = m.decode_greedy(first, args.steps)          # synchronises the engine stream before returning
     sync_all()
     dt = time.perf_counter() - t0
+    c_hit, c_miss, c_rep = m.carry_stats()
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -190,8 +202,13 @@ def main():
                  for k, v in per_launch.items()},
         load_s=round(load_s, 2),
         carry=dict(RWKV_CARRY=os.environ.get("RWKV_CARRY", "default: 32 KiB per workgroup where rows are 4 KiB (7B), 20 where they are 3 KiB (3B), else off"),
-                   note="ring kernels leave the first rows of the next ring kernel in the CU's LDS across the kernel boundary; "
-                        "checked against their row sums before use (DESIGN.md 4.5; 7B: 565 -> 572 tokens/s, profiles/r03/carry.txt)"),
+                   timed_region=dict(found=c_hit, not_found=c_miss, reloaded_after_failed_check=c_rep,
+                                     hit_rate=(round(c_hit / (c_hit + c_miss), 6) if c_hit + c_miss else None)),
+                   note="ring kernels leave the first rows of the next ring kernel in the CU's LDS across the kernel boundary; every carried "
+                        "group is checked against a position-weighted row sum before use and re-loaded from memory if the check fails "
+                        "(DESIGN.md 4.5).  timed_region = workgroup launches of the TIMED decode that found / did not find their rows "
+                        "(one counter word per workgroup, counted inside the timed region itself).  The carry changes no result "
+                        "(bit-identical logits with RWKV_CARRY=0, tests/test_engine_gpu.py) and is worth +1.3 % at 7B"),
         hbm_resident_bytes=dict(total=m.resident_bytes(),
                                 note="device bytes of this context: decode-layout weights + embedding + state + scratch"
                                      + (", plus the SECOND copy of the matrices in the MFMA B-operand image of the chunk path "
@@ -302,30 +319,41 @@ def main():
 
 
 def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
-    """N > 1: the model's layers are pipelined across the N GPUs (stage s = rank s holds layers [l0_s, l1_s), stage 0 the
-    embedding, the last stage the head).  The hop is INSIDE the engine: ncclSend / ncclRecv (RCCL over xGMI) of the residual
-    vector (f64[D]) on the engine's own stream, the picked id fed back device to device, no host wait per tick
-    (rwkv_pipe_decode).  N independent greedy streams are in flight, one per stage, so every GPU is busy: a "step" = one
-    token of every stream.  value = N*K tokens / max-over-ranks time.  torch.distributed only carries the 128-byte RCCL id,
-    the barriers and the timing reduction.  (RWKV_BENCH_BACKEND=gloo: the Python schedule over torch P2P ops instead.)"""
+    """N > 1 (BASELINE config 4: RWKV-4-Raven-14B by default): the model's layers are pipelined across the N GPUs (stage s = rank s
+    holds layers [l0_s, l1_s), stage 0 the embedding, the last stage the head).  The hop is INSIDE the engine: ncclSend / ncclRecv
+    (RCCL over xGMI) of the residual vector (f64[D]) on the engine's own stream, the picked id fed back device to device, no host
+    wait per tick (rwkv_pipe_decode).  Three numbers:
+      * `value`: N independent greedy streams in flight, one per stage, so every GPU is busy -- a "step" = one token of every
+        stream; value = N*K tokens / max-over-ranks time (weak scaling: the aggregate is what scales);
+      * `one_stream`: ONE stream through all the stages -- the latency of single-stream decode on the pipeline,
+        t_tok(1 GPU) + (N - 1) hops + the fed-back id; it does NOT get faster with N;
+      * `hop`: event pairs around the per-tick RCCL group on every rank's stream (min = the hop itself).
+    Before anything is timed the LAST rank decodes the same streams on a whole-model context of its own GPU and compares
+    (`parity_vs_single_gpu`: picks of every stream identical, last-step logits bit-identical).  torch.distributed only carries
+    the 128-byte RCCL id, the barriers and the timing reduction.  RWKV_BENCH_BACKEND=gloo: dry run on one box (Python schedule
+    over torch P2P ops; with RWKV_RCCL_LIB=tests/_build/libfake_rccl.so the NATIVE schedule over the shared-memory stand-in)."""
     import faulthandler
     import numpy as np
     import torch
-    from rwkv_cpp_accelerated_amd import modelfile as mf, pipeline
+    from rwkv_cpp_accelerated_amd import engine, modelfile as mf, pipeline
     # the engine-side RCCL schedule has run with several ranks only over the shared-memory stand-in (tests/fake_rccl.cpp): a transport
     # that hangs on real xGMI must fail visibly (stack dump + exit) instead of stalling the whole run
-    faulthandler.dump_traceback_later(int(os.environ.get("RWKV_BENCH_WATCHDOG_S", "600")), exit=True)
+    faulthandler.dump_traceback_later(int(os.environ.get("RWKV_BENCH_WATCHDOG_S", "900")), exit=True)
     tensors = mf.synthetic_tensors_torch(L, D, seed=args.seed, device=dev)     # same seed on every rank: one model
     l0, l1 = pipeline.partition_layers(L, world, D)[rank]
-    native = dist.get_backend() == "nccl" and os.environ.get("RWKV_BENCH_NATIVE", "1") == "1"
+    native = (dist.get_backend() == "nccl" or bool(os.environ.get("RWKV_RCCL_LIB"))) and os.environ.get("RWKV_BENCH_NATIVE", "1") == "1"
     stage = pipeline.EngineStage(tensors, L, D, l0, l1, n_slots=world, device=local_rank, prefill=native and args.prefill_chunks > 0)
-    del tensors
-    torch.cuda.empty_cache()
+    lastr = rank == world - 1
+    if not (lastr or rank == 0):
+        del tensors
+        tensors = None
+        torch.cuda.empty_cache()
     native_note = None
     if native:
         # the engine-side communicator has never met a second GPU before the driver's own multi-GPU run (a gpurun box has one
         # GPU and RCCL refuses two ranks on one device): if ANY rank fails to join, every rank falls back to the Python
-        # schedule over torch.distributed's own RCCL point-to-point ops, and the bench line says so
+        # schedule over torch.distributed's own RCCL point-to-point ops, and the bench line says so (and the run exits non-zero
+        # unless RWKV_BENCH_ALLOW_FALLBACK=1: a number measured on the fallback is not the product's)
         ok = 1
         try:
             pipeline.pipe_connect(stage, dist, rank, world)
@@ -342,21 +370,73 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     rng = np.random.default_rng(1)
     first = [int(x) for x in rng.integers(2, mf.VOCAB, world)]
 
-    def run(n):
+    def run(n, n_streams=None):
         if native:
-            return pipeline.run_pipeline_native(stage, rank, world, first, n)
-        return pipeline.run_pipeline(stage, dist, rank, world, first, n, device=dev)
+            return pipeline.run_pipeline_native(stage, rank, world, first, n, n_streams=n_streams)
+        return pipeline.run_pipeline(stage, dist, rank, world, first, n, device=dev, n_streams=n_streams)
 
+    def timed(n, n_streams=None):
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(n, n_streams)
+        dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- parity first: the same streams on ONE GPU (the last rank builds a whole-model context beside its stage) ----
+    n_par = int(os.environ.get("RWKV_BENCH_PARITY_STEPS", "12"))
+    stage.m.reset_state()
+    picks = run(n_par)
+    parity = None
+    if lastr:
+        lg_pipe = stage.m.logits(world).reshape(world, mf.VOCAB).copy()          # row k: the last step of stream k
+        try:
+            ref = engine.RWKV(device=local_rank, resident=True)
+            ref.loadTensors(L, D, tensors, maxGPT=1)
+            same_ids, same_logits, worst = True, True, 0.0
+            for k in range(world):
+                ref.reset_state()
+                ids = ref.decode_greedy(first[k], n_par)
+                same_ids = same_ids and [int(i) for i in ids] == [int(i) for i in picks[k]]
+                # logits of the last step: feed the last-but-one pick (or the first token) once more on a fresh replay
+                ref.reset_state()
+                tk = first[k]
+                for i in range(n_par):
+                    lg = ref.forward(tk)[: mf.VOCAB]
+                    tk = int(ids[i])
+                same_logits = same_logits and bool(np.array_equal(lg, lg_pipe[k]))
+                worst = max(worst, float(np.abs(lg.astype(np.float64) - lg_pipe[k]).max() / max(1e-30, float(np.abs(lg).max()))))
+            ref.close()
+            parity = dict(streams=world, steps=n_par, picks_identical=bool(same_ids), last_step_logits_bit_identical=bool(same_logits),
+                          max_rel_logit_err=float(f"{worst:.3e}"),
+                          note="the pipeline's streams decoded again on a whole-model context on the last rank's GPU, from the same zero state")
+        except Exception as e:          # noqa: BLE001
+            parity = dict(skipped=f"whole-model context on the last rank: {e}")
+    if lastr and rank != 0:
+        del tensors
+        tensors = None
+        torch.cuda.empty_cache()
+
+    # ---- timed: N streams in flight (the headline), then ONE stream in flight, then the hop ----
     if args.warmup > 0:
         run(max(1, args.warmup // world))
-    dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    dist.barrier(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = timed(args.steps)
+    one_steps = max(4, min(args.steps, int(os.environ.get("RWKV_BENCH_ONE_STREAM_STEPS", "128"))))
+    run(2, 1)
+    dt1 = timed(one_steps, 1)
+    hop = None
+    if native:
+        stage.m.pipe_profile(True)
+        run(min(64, args.steps))
+        hs = stage.m.pipe_hop_stats()
+        stage.m.pipe_profile(False)
+        mine = torch.tensor([hs["mean_us"], hs["min_us"], hs["max_us"]], device=dev, dtype=torch.float64)
+        allh = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        hop = dict(per_rank_us=[dict(mean=round(float(v[0]), 2), min=round(float(v[1]), 2), max=round(float(v[2]), 2)) for v in allh],
+                   note="hipEvent pair on the rank's engine stream around the tick's ncclGroupStart .. ncclGroupEnd {send x | send id | recv x | recv id}, "
+                        f"{hs['n']} ticks with {world} streams in flight; min = the hop itself (the peer's data was waiting), mean includes waiting for the peer")
     B_tok = mf.bytes_per_token(L, D)
     tok_s = world * args.steps / dt
     # per-stage roofline: every token of every stream crosses every stage, so stage s streams its share of the bytes
@@ -365,6 +445,9 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     per_stage = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(per_stage, mine)
     per_stage = [round(float(v.item()), 1) for v in per_stage]
+    par_box = [parity]
+    dist.broadcast_object_list(par_box, src=world - 1)
+    parity = par_box[0]
     prefill = None
     if native and args.prefill_chunks > 0:
         n_tok = 32 * max(args.prefill_chunks, 2 * world)
@@ -378,29 +461,45 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
         dist.all_reduce(tp, op=dist.ReduceOp.MAX)
         prefill = dict(prompt_tokens=n_tok, tokens_per_s=round(n_tok / float(tp.item()), 1),
                        note="pipelined RWKV::loadContext: 32-token chunks as micro-batches, stage s on chunk t - s (rwkv_pipe_prefill)")
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        import rwkv_cpp_accelerated_amd as pkg
+        cpu = cpu_baseline(pkg, mf, tensors, L, D, [first[0]] + [int(x) for x in rng.integers(2, mf.VOCAB, 3)], args.cpu_seconds)
+    dist.barrier()
+    transport = ("RCCL ncclSend/ncclRecv of the residual vector inside the engine, on its stream" if native and dist.get_backend() == "nccl"
+                 else "the engine's native schedule over the shared-memory RCCL stand-in (tests/fake_rccl.cpp; dry run)" if native
+                 else "torch.distributed P2P ops (Python schedule)" + ("" if native_note is None else " -- FALLBACK: the engine-side RCCL transport did not come up"))
     if rank == 0:
         worst = min(per_stage)
         print(json.dumps(dict(
-            metric="tokens/sec single-stream RWKV-4 uint8 greedy decode", value=round(tok_s, 2), unit="tokens/s",
+            metric=f"tokens/sec RWKV-4 uint8 greedy decode, layers pipelined over {world} GPUs, AGGREGATE of {world} streams in flight (one per stage); "
+                   "one_stream.tokens_per_s is the single-stream rate on the same pipeline",
+            value=round(tok_s, 2), unit="tokens/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 5),
             higher_is_better=True, scaling="weak", vs_baseline=None,
             dtype="u8 weights x 23-bit fixed-point activations, exact u32 accumulate (v_dot4_u32_u8); f32/f64 epilogues, f64 state",
             data="synthetic",
             config=dict(workload=f"RWKV-4-Raven-{args.model} uint8 greedy decode (L={L}, D={D}), layers pipelined over {world} GPUs, "
                                  f"{world} independent streams in flight (one per stage), {args.steps} tokens per stream",
-                        parallelism=f"pp{world}: layer pipeline, " + ("RCCL ncclSend/ncclRecv of the residual vector inside the engine, on its stream"
-                                                                       if native else "torch.distributed P2P ops (Python schedule)") +
-                                    f" (f64[{D}] between stages, greedy id fed back last->first stage)",
+                        parallelism=f"pp{world}: layer pipeline, {transport} (f64[{D}] between stages, greedy id fed back last->first stage)",
                         layer_ranges=pipeline.partition_layers(L, world, D), bytes_per_token=B_tok),
             roofline=dict(bound="hbm", kernel="stage (all decode kernels of a rank's layers)", achieved=worst, peak=HBM_PEAK_GBPS, unit="GB/s",
                           frac=round(worst / HBM_PEAK_GBPS, 4), traffic=None, per_stage_GBps=per_stage,
                           method="algorithmic bytes of the stage's layers per token x tokens through the stage / wall time of the timed region; "
                                  "the slowest stage is quoted"),
             end_to_end=dict(achieved_GBps=round(B_tok * tok_s / 1e9, 1), frac_of_aggregate_peak=round(B_tok * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)),
-            per_stream_tokens_per_s=round(args.steps / dt, 2), prefill=prefill, transport_fallback=native_note)), flush=True)
+            per_stream_tokens_per_s=round(args.steps / dt, 2),
+            one_stream=dict(tokens_per_s=round(one_steps / dt1, 2), ms_per_token=round(1e3 * dt1 / one_steps, 5), steps=one_steps,
+                            achieved_GBps=round(B_tok * one_steps / dt1 / 1e9, 1), frac_of_8TBps=round(B_tok * one_steps / dt1 / 1e9 / HBM_PEAK_GBPS, 4),
+                            note=f"ONE stream in flight through the {world} stages (rwkv_pipe_decode_streams, n_streams = 1): "
+                                 "t_tok(1 GPU) + (N - 1) hops + the fed-back id per token (SURVEY 8e); N - 1 GPUs idle at any time"),
+            hop=hop, parity_vs_single_gpu=parity, cpu_baseline=cpu,
+            prefill=prefill, transport_fallback=native_note)), flush=True)
     faulthandler.cancel_dump_traceback_later()
     dist.barrier()
     dist.destroy_process_group()
+    if native_note is not None and os.environ.get("RWKV_BENCH_ALLOW_FALLBACK") != "1":
+        raise SystemExit(3)     # the line above is on record; a fallback-transport number must not pass for the product's
 
 
 def ref_kernel_leg(mf, tensors, L, D, prompt, engine_model, steps, budget_s, B_tok):
@@ -516,36 +615,75 @@ def chunk_gate_leg(mf, tensors, L, D, prompt, engine_model):
     return g
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota.  (The GPU boxes show 256 logical CPUs
+    and grant 16 CPUs' worth of time -- cpu.max = "1600000 100000": 256 OpenMP threads then take 42 s per 7B token, 64 take 0.2 s;
+    profiles/r04/cpu_leg.txt.  That, not "first touch", was the 2x spread of round 3's baseline.)"""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(p)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, math.ceil(quota)))
+    return n, quota
+
+
 def cpu_baseline(pkg, mf, tensors, L, D, prompt, budget_s, engine_model=None):
-    """rank 0, N=1 leg: time the oracle on a bounded sample of the same workload -- and, since the oracle's
-    logits of the FULL-SIZE model are at hand, use them as the checker of the engine (teacher-forced)."""
+    """rank 0 leg: time the oracle (the CPU restatement of rwkv.cu:493-593; OpenMP over blocks of 64 output columns) on a bounded
+    sample of the same workload -- 2 warm-up tokens, then 8-32 timed greedy tokens (as many as fit the budget), each timed on its
+    own: min / median / mean are reported, the VALUE is tokens / (sum of the timed tokens).  Threads = the CPUs the process may really
+    use (affinity mask capped by the cgroup quota, usable_cpus()); `cores` is that number -- the threads actually used.  OpenMP is
+    pinned (OMP_PROC_BIND=close, OMP_PLACES=cores, set in main() before any OpenMP runtime is loaded).  Since the oracle's logits of
+    the FULL-SIZE model are at hand, they also check the engine."""
+    import glob
+    import statistics
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     pkg.build.build_oracle()
     import oracle_lib
-    cores = os.cpu_count() or 1
+    usable, quota = USABLE_CPUS if USABLE_CPUS else usable_cpus()
+    threads = int(os.environ.get("RWKV_BENCH_CPU_THREADS", usable))
     t0 = time.time()
     host = [None if t is None else t.cpu().numpy() for t in tensors]
     copy_s = time.time() - t0
-    om = oracle_lib.Oracle().from_tensors(L, D, host)
+    ora = oracle_lib.Oracle()
+    ora.set_threads(threads)      # (torch.distributed.run exports OMP_NUM_THREADS=1 to the ranks of the N > 1 line; the others wait at a barrier)
+    om = ora.from_tensors(L, D, host)
     st = om.new_state()
-    t0 = time.perf_counter()
-    lg = om.forward([prompt[0]], st)
-    one = time.perf_counter() - t0
-    n = int(max(1, min(31, (budget_s - one) // max(one, 1e-3))))
-    t0 = time.perf_counter()
-    tk = int(np.argmax(lg[0][1:])) + 1
-    fed, refs = [prompt[0]], [lg[0].copy()]
-    for i in range(n):
-        fed.append(tk)
+    fed, refs, per = [], [], []
+    tk = int(prompt[0])
+    n_warm, n = 2, 8
+    t_leg = time.perf_counter()
+    for i in range(n_warm + 32):
+        t0 = time.perf_counter()
         lg = om.forward([tk], st)
-        refs.append(lg[0].copy())
+        dt1 = time.perf_counter() - t0
+        fed.append(tk); refs.append(lg[0].copy())
         tk = int(np.argmax(lg[0][1:])) + 1
-    dt = time.perf_counter() - t0
+        if i == n_warm - 1:
+            n = int(max(8, min(32, budget_s // max(dt1, 1e-3))))       # the second warm-up token is the estimate
+        if i >= n_warm:
+            per.append(dt1)
+            if len(per) >= n or (len(per) >= 2 and time.perf_counter() - t_leg > 4 * budget_s):     # (hard bound: a throttled box must not hang the line)
+                break
     om.close()
-    out = dict(value=round(n / dt, 4), unit="tokens/s", cores=cores, kind="port",
-               sample=f"{n} greedy tokens of the same synthetic model after a 1-token warm-up "
-                      f"(oracle/rwkv_oracle.c, OpenMP over output columns; weights copied to host in {copy_s:.1f}s)")
+    out = dict(value=round(len(per) / sum(per), 4), unit="tokens/s", cores=ora.num_threads(), kind="port",
+               host=dict(logical_cpus=os.cpu_count() or 1, usable_cpus=usable, cgroup_cpu_quota=quota,
+                         numa_nodes=len(glob.glob("/sys/devices/system/node/node[0-9]*")) or 1,
+                         OMP_PROC_BIND=os.environ.get("OMP_PROC_BIND"), OMP_PLACES=os.environ.get("OMP_PLACES")),
+               seconds_per_token=dict(min=round(min(per), 4), median=round(statistics.median(per), 4), mean=round(sum(per) / len(per), 4)),
+               sample=f"{len(per)} timed greedy tokens of the same synthetic model after {n_warm} warm-up tokens, each token timed on its own "
+                      f"(oracle/rwkv_oracle.c on {ora.num_threads()} OpenMP threads = the CPUs this process may use; weights copied to host in {copy_s:.1f}s)")
     if engine_model is not None:      # full-size parity: same tokens through the engine, logits vs the oracle's
         engine_model.reset_state()
         worst, same = 0.0, True

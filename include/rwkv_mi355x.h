@@ -27,9 +27,11 @@ extern "C" {
 
 /* Version of this C-ABI: bumped whenever an existing entry point changes its argument list or meaning (additions alone do
  * not bump it).  3: rwkv_decode_typical / rwkv_sample_typical take `flags`; the one-launch-token hooks (rwkv_one_launch,
- * rwkv_debug_mega_timeline) are gone; bounded device-side waits report RWKV_E_DEVICE.  rwkv_abi_version() returns the value the
+ * rwkv_debug_mega_timeline) are gone; bounded device-side waits report RWKV_E_DEVICE.  4: weight rows carried in LDS that fail
+ * their check are re-loaded instead of failing the call (no more "arrived damaged" error); the carry counters are on by default
+ * (rwkv_debug_carry_stats).  rwkv_abi_version() returns the value the
  * library was built with: a binding compares it with the header it was compiled against. */
-#define RWKV_MI355X_ABI_VERSION 3
+#define RWKV_MI355X_ABI_VERSION 4
 int rwkv_abi_version(void);
 
 #define RWKV_VOCAB 50277u /* hard-wired in the reference: rwkv.h:126, rwkv.cu:471,589 */
@@ -149,11 +151,20 @@ int rwkv_sync(rwkv_ctx *ctx);
  *                        n_steps tokens each; first_tokens[world] is read on rank 0, picks[world][n_steps] written on
  *                        the last rank.  The hop (f64[n_embed] forward, the picked id u64 back to rank 0) and the stage
  *                        graph alternate on one stream; the host does not wait inside the loop
+ *   rwkv_pipe_decode_streams   the same with only the first n_streams (1..world) streams' slots of the schedule filled:
+ *                        n_streams = 1 is ONE stream through all the stages -- the latency of single-stream decode on
+ *                        the pipeline, t_tok + (world - 1) hops + the fed-back id; picks stays [world][n_steps]
+ *   rwkv_pipe_profile / rwkv_pipe_hop_stats   hop timing: event pairs around the per-tick RCCL group of the last
+ *                        rwkv_pipe_decode* call; out4 = {ticks measured, mean, min, max microseconds} (min = the hop
+ *                        itself, the peer's data was waiting; the mean includes waiting for the peer)
  *   rwkv_pipe_prefill    RWKV::loadContext (rwkv.h:395-413) across the stages: the prompt's 32-token chunks are the
  *                        micro-batches, stage s works on chunk t - s at tick t; needs max_ctx >= 32; tokens read on rank 0 */
 int rwkv_pipe_unique_id(void *out128);
 int rwkv_pipe_init(rwkv_ctx *ctx, const void *id128, int rank, int world);
 int rwkv_pipe_decode(rwkv_ctx *ctx, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks);
+int rwkv_pipe_decode_streams(rwkv_ctx *ctx, const uint64_t *first_tokens, uint64_t n_steps, uint64_t n_streams, uint64_t *picks);
+int rwkv_pipe_profile(rwkv_ctx *ctx, int on);
+int rwkv_pipe_hop_stats(rwkv_ctx *ctx, double *out4);
 int rwkv_pipe_prefill(rwkv_ctx *ctx, const uint64_t *tokens, uint64_t n_tokens);
 void rwkv_pipe_free(rwkv_ctx *ctx);
 
@@ -179,9 +190,12 @@ void *rwkv_stream(rwkv_ctx *ctx);
  * max_ctx > 1 on a whole-model context, the SECOND resident copy of the matrices in the MFMA B-operand image of the chunk
  * path (+7.2 GB at 7B, +13.9 GB at 14B). */
 uint64_t rwkv_resident_bytes(const rwkv_ctx *ctx);
-/* debug: with RWKV_CARRY_COUNT=1 in the environment at load time, out2[0] / out2[1] = workgroup launches of the decode kernels that
- * found / did not find, in their CU's LDS, the first weight rows their predecessor was asked to leave there;
- * counted since the previous call. */
+/* Carry counters since the previous call: out3[0] / out3[1] = workgroup launches of the decode kernels that found /
+ * did not find, in their CU's LDS, the first weight rows their predecessor was asked to leave there; out3[2] = carried row groups
+ * whose position-weighted checksum failed and that were re-loaded from memory before use (0 unless something else wrote the CU's
+ * LDS in between).  One counter word per workgroup, so counting is on whenever the context carries (RWKV_CARRY_COUNT=0: off).
+ * rwkv_debug_carry_hits = the first two (ABI 3 entry point). */
+int rwkv_debug_carry_stats(rwkv_ctx *ctx, uint64_t *out3);
 int rwkv_debug_carry_hits(rwkv_ctx *ctx, uint64_t *out2);
 /* Algorithmic HBM bytes of one token (13*L*D^2 + V*D uint8 weight bytes
  * + 168*L*D + 40*D bytes of vectors/state). */

@@ -25,6 +25,9 @@
  *   - rwkv.cu:44 sqrt() of a float -> sqrtf(); rwkv.cu:43 divides in double,
  *     rwkv.cu:444 divides mean/emb in float.
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -34,7 +37,10 @@
 #define V_SIZE 50277ULL
 #define JSPLIT 16ULL   /* MM8_ONE_JSPLIT, rwkv.cu:21 */
 #define EMBBLOCK 16ULL /* rwkv.cu:24: each device thread owns 16 consecutive elements */
-#define KCHUNK 256ULL  /* output columns per OpenMP work item (host parallelisation only) */
+#ifndef KCHUNK
+#define KCHUNK 64ULL
+#endif
+/* KCHUNK: output columns per OpenMP work item (host parallelisation only; the summation order per column does not depend on it) */
 
 enum { MODE_PARRALEL = 0, MODE_GPT = 1 }; /* enums/enum.h:2-5 */
 
@@ -444,4 +450,23 @@ int oracle_stage_forward(const oracle_model *m, uint64_t token, double *x, uint6
     }
     free(buffer1); free(ffnk_in); free(ffnr_in); free(buffer2); free(buffer3); free(buffer4); free(ffnrbuffer);
     return 0;
+}
+
+/* threads the OpenMP loops above run on (bench.py's cpu_baseline reports it next to the host's core count) */
+int oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+/* torch.distributed.run exports OMP_NUM_THREADS=1 to its workers: bench.py's N > 1 line sets the count for its CPU leg explicitly */
+void oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }

@@ -137,8 +137,8 @@ struct Pipe {
     const char *(*GetErrorString)(int) = nullptr;
 };
 
-// decode kernels that stream through the LDS ring: -1 = by model width (measured on MI355X, profiles/r02/ring_sweep.txt):
-// rows of 3-4 KiB gain 4-5 % with k_att, k_ffn_rk and k_ffnv on the ring; 5 KiB rows (few, large slots) ~0; <= 2 KiB rows lose
+// decode kernels that stream through the LDS ring: -1 = by model width (measured on MI355X, profiles/r02/ring_sweep.txt,
+// profiles/r04/early_take_ab.txt): rows of 3-5 KiB gain 2-5 % with k_att, k_ffn_rk and k_ffnv on the ring; <= 2 KiB rows lose
 #ifndef RWKV_RING
 #define RWKV_RING -1
 #endif
@@ -190,6 +190,7 @@ struct rwkv_ctx {
     double *lnstat = nullptr;                         // [3][2] mean, rstd per site
     uint8_t *w_kvr = nullptr, *w_att = nullptr, *w_frk = nullptr, *w_fv = nullptr, *w_head = nullptr;
     unsigned *rs_kvr = nullptr, *rs_att = nullptr, *rs_frk = nullptr, *rs_fv = nullptr, *rs_head = nullptr;   // row sums
+    unsigned *rw_kvr = nullptr, *rw_att = nullptr, *rw_frk = nullptr, *rw_fv = nullptr;                       // position-weighted row sums (kernels.hip.h carry_verify)
     // state + scratch (device)
     double *state[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double *x = nullptr, *partA = nullptr, *partF = nullptr;
@@ -228,6 +229,10 @@ struct rwkv_ctx {
     hipEvent_t sp_end = nullptr;
     double *x_in = nullptr;                       // decode: residual vector received from the previous stage (nullptr: c->x)
     struct Pipe *pipe = nullptr;                  // RCCL transport of the layer pipeline (rwkv_pipe_init)
+    bool pipe_prof = false;                       // rwkv_pipe_profile: bracket the ticks' RCCL groups with event pairs
+    static constexpr size_t HOP_EV = 512;
+    hipEvent_t hop_ev[2 * HOP_EV] = {};
+    double hop_stats[4] = {0.0, 0.0, 0.0, 0.0};
     Ctl *pipe_ring = nullptr;                     // pinned control blocks of rwkv_pipe_decode's items (grown on demand, kept)
     uint64_t pipe_ring_cap = 0;
     double *sq_state = nullptr;                   // [D] LayerNorm output of the chunk's last token
@@ -360,6 +365,7 @@ struct ArgMaker {
         int n = (c->carry_kib + per / 2) / per;
         n = std::max(n, 1);
         n = std::min(n, std::min(G / 2, units() / (2 * rows_of(cls))));
+        n = std::min(n, GLDS_FQ / 2);            // RingLoader::adopt books them in gend[] / freeq[] (GLDS_FQ entries)
         return std::max(n, 0);
     }
     const uint8_t *weights_of(int cls, uint64_t l) const
@@ -418,7 +424,7 @@ struct ArgMaker {
         const size_t lo = (size_t)l * D;
         AttArgs aa;
         aa.x = c->x; aa.st = site_static(0, l); aa.dy = site_dyn(0, l == c->l0 ? n_first : grid);
-        aa.w = c->w_kvr + (size_t)(l - c->l0) * 3 * D * D; aa.rs = c->rs_kvr + (size_t)(l - c->l0) * D * 3;
+        aa.w = c->w_kvr + (size_t)(l - c->l0) * 3 * D * D; aa.rs = c->rs_kvr + (size_t)(l - c->l0) * D * 3; aa.rw = c->rw_kvr + (size_t)(l - c->l0) * D * 3;
         aa.uw = c->uw + lo; aa.ew = c->ew + lo;
         aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
         aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
@@ -430,7 +436,7 @@ struct ArgMaker {
     {
         const size_t lo = (size_t)l * D;
         AttOutArgs ao;
-        ao.w = c->w_att + (size_t)(l - c->l0) * D * D; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
+        ao.w = c->w_att + (size_t)(l - c->l0) * D * D; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.rw = c->rw_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
         ao.x = c->x; ao.lnw = c->ln + (4 * l + 2) * D; ao.lnb = c->ln + (4 * l + 3) * D; ao.lnstat = c->lnstat + 0;
         ao.sxy = c->state[0] + lo; ao.st = site_static(1, l); ao.dy = site_dyn(1, grid); ao.sdd = c->state[4] + lo;
         ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.ns = 0; ao.tl = tl_of(2, l); ao.herr = c->d_herr; ao.cy = carry(2, l);
@@ -441,7 +447,7 @@ struct ArgMaker {
         const size_t lo = (size_t)l * D;
         FfnRKArgs fa;
         fa.x = c->x; fa.st = site_static(1, l); fa.dy = site_dyn(1, grid);
-        fa.w = c->w_frk + (size_t)(l - c->l0) * 5 * D * D; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5;
+        fa.w = c->w_frk + (size_t)(l - c->l0) * 5 * D * D; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5; fa.rw = c->rw_frk + (size_t)(l - c->l0) * D * 5;
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.partM = c->partMF; fa.ctl = c->ctl; fa.D = D;
         fa.ns = 0; fa.tl = tl_of(3, l); fa.herr = c->d_herr; fa.cy = carry(3, l);
@@ -454,7 +460,7 @@ struct ArgMaker {
     {
         const size_t lo = (size_t)l * D;
         FfnVArgs fv;
-        fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
+        fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.rw = c->rw_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
         fv.rgate = c->rgate; fv.x = c->x; fv.lnw = c->ln + (4 * l + 4) * D; fv.lnb = c->ln + (4 * l + 5) * D; fv.lnstat = c->lnstat + 2;
         fv.sdd = c->state[4] + lo; fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D; fv.tl = tl_of(4, l);
         fv.ns = 0; fv.herr = c->d_herr; fv.cy = carry(4, l);
@@ -542,9 +548,6 @@ int device_check(rwkv_ctx *c)
     if (!c->herr || *c->herr == 0u) return 0;
     const unsigned code = *c->herr;
     *c->herr = 0u;
-    if (code == 5u)
-        return fail(RWKV_E_DEVICE, "weight rows carried across a kernel boundary in LDS arrived damaged (code 5: another process's kernel had the CU in between?) -- "
-                                   "the results of this call are invalid; RWKV_CARRY=0 turns the carry off");
     return fail(RWKV_E_DEVICE, "a device-side wait gave up (code %u: LDS ring hand-off timed out; is the GPU shared or preempted?) -- "
                                "the results of this call are invalid; RWKV_RING=0 selects the register kernels", code);
 }
@@ -673,13 +676,18 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         return fail(RWKV_E_ARG, "RWKV_GRID=%d is too small for n_embed=%llu (need >= %llu workgroups)", c->grid, (unsigned long long)D, (unsigned long long)((D + 511) / 512));
     HIPCHK(hipSetDevice(c->device));
     c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
-    if (c->ring < 0) c->ring = (c->S == 3 || c->S == 4) ? 13 : (c->S == 5 ? 5 : 0);
+    if (c->ring < 0) c->ring = c->S >= 3 ? 13 : 0;      // (5 KiB rows: k_ffnv joined the ring in round 4, with the early take: 21.4 -> 20.8 us, profiles/r04/early_take_ab.txt)
     if (c->carry_kib < 0) c->carry_kib = c->S == 4 ? 32 : c->S == 3 ? 20 : 0;
     if (c->l1 == UINT64_MAX) c->l1 = L;
-    if (getenv("RWKV_CARRY_COUNT") && !c->carry_hits) {
-        int rcc = dalloc(c, &c->carry_hits, 4);
-        if (rcc) return rcc;
-        HIPCHK(hipMemset(c->carry_hits, 0, 16));
+    {   // carry counters, one set per workgroup (found / not found / groups re-loaded after a failed check): a fire-and-forget atomic on the
+        // workgroup's own word per launch (RWKV_CARRY_COUNT=0: none).  Round 3 counted on ONE word and paid 6 % for it: 256 arrivals on a
+        // word are a 3 us chain of memory-side atomics (profiles/r04/atomicbench.txt)
+        const char *e = getenv("RWKV_CARRY_COUNT");
+        if (!(e && e[0] == '0') && c->carry_kib > 0 && !c->carry_hits) {
+            int rcc = dalloc(c, &c->carry_hits, (size_t)c->grid * 4);
+            if (rcc) return rcc;
+            HIPCHK(hipMemset(c->carry_hits, 0, (size_t)c->grid * 16));
+        }
     }
     if (c->l0 >= c->l1 || c->l1 > L) return fail(RWKV_E_ARG, "layer range [%llu, %llu) does not fit a %llu-layer model", (unsigned long long)c->l0, (unsigned long long)c->l1, (unsigned long long)L);
     const uint64_t l0 = c->l0, l1 = c->l1, nl = l1 - l0;
@@ -771,15 +779,19 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if (!rc) rc = dalloc(c, &c->rs_frk, nl * 5 * D);
     if (!rc) rc = dalloc(c, &c->rs_fv, nl * D);
     if (!rc) rc = dalloc(c, &c->rs_head, V);
+    if (!rc) rc = dalloc(c, &c->rw_kvr, nl * 3 * D);
+    if (!rc) rc = dalloc(c, &c->rw_att, nl * D);
+    if (!rc) rc = dalloc(c, &c->rw_frk, nl * 5 * D);
+    if (!rc) rc = dalloc(c, &c->rw_fv, nl * D);
     if (!rc) {
-        auto rowsum = [&](const uint8_t *w, unsigned *rs, uint64_t rows, uint64_t N) {
-            k_rowsum<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream>>>(w, rs, (size_t)rows, (int)N);
+        auto rowsum = [&](const uint8_t *w, unsigned *rs, unsigned *rw, uint64_t rows, uint64_t N) {
+            k_rowsum<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream>>>(w, rs, rw, (size_t)rows, (int)N, (int)D);
         };
-        rowsum(c->w_kvr, c->rs_kvr, nl * 3 * D, D);
-        rowsum(c->w_att, c->rs_att, nl * D, D);
-        rowsum(c->w_frk, c->rs_frk, nl * 5 * D, D);
-        rowsum(c->w_fv, c->rs_fv, nl * D, 4 * D);
-        if (last) rowsum(c->w_head, c->rs_head, V, D);
+        rowsum(c->w_kvr, c->rs_kvr, c->rw_kvr, nl * 3 * D, D);
+        rowsum(c->w_att, c->rs_att, c->rw_att, nl * D, D);
+        rowsum(c->w_frk, c->rs_frk, c->rw_frk, nl * 5 * D, D);
+        rowsum(c->w_fv, c->rs_fv, c->rw_fv, nl * D, 4 * D);
+        if (last) rowsum(c->w_head, c->rs_head, nullptr, V, D);
     }
     hipError_t se = hipStreamSynchronize(c->stream);
     if (staging) (void)hipFree(staging);
@@ -1113,6 +1125,15 @@ int carry_policy(rwkv_ctx *c)
     return rebuild_graphs(c);
 }
 
+// Start of every entry point that launches kernels: the device error word belongs to ONE call.  An entry point that left early
+// (a failed HIP call) never consumed it, and a code raised then would surface -- attributed to the wrong operation -- from whatever
+// synchronises next; so it is cleared here, then the carry policy is brought up to date.
+int begin_call(rwkv_ctx *c)
+{
+    if (c->herr) *c->herr = 0u;
+    return carry_policy(c);
+}
+
 int run_token(rwkv_ctx *c, bool with_argmax)
 {
     hipGraphExec_t g = with_argmax ? c->g_greedy : c->g_fwd;
@@ -1220,7 +1241,7 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
     for (uint64_t t = 0; t < T; t++)
         if (tokens[t] >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id %llu out of range", (unsigned long long)tokens[t]);
     HIPCHK(hipSetDevice(c->device));
-    { const int rcp = carry_policy(c); if (rcp) return rcp; }
+    { const int rcp = begin_call(c); if (rcp) return rcp; }
     if (T >= 2 && c->seq_ok && c->l0 == 0 && c->l1 == c->L) {   // prompt chunks (GPT) / batched decode step of T streams (PARRALEL): weights read once per <= 32 rows
         const uint64_t nchunks = (T + SEQ_T - 1) / SEQ_T;
         int rc = 0;
@@ -1287,7 +1308,7 @@ int rwkv_stage_forward(rwkv_ctx *c, uint64_t token, uint32_t slot, uint64_t *pic
     if (slot >= c->maxT) return fail(RWKV_E_ARG, "state slot %u out of range (max context %llu)", slot, (unsigned long long)c->maxT);
     if (c->l0 == 0 && token >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
     HIPCHK(hipSetDevice(c->device));
-    { const int rcp = carry_policy(c); if (rcp) return rcp; }
+    { const int rcp = begin_call(c); if (rcp) return rcp; }
     c->h_ctl[0].token = token; c->h_ctl[0].slot = slot; c->h_ctl[0].out_row = slot; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     const bool last = c->l1 == c->L;
@@ -1350,7 +1371,7 @@ int rwkv_decode_greedy(rwkv_ctx *c, uint64_t first_token, uint64_t n, uint64_t *
     if (first_token >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
     if (n == 0 || n > c->gen_cap) return fail(RWKV_E_ARG, "n_tokens must be in 1..%u", c->gen_cap);
     HIPCHK(hipSetDevice(c->device));
-    { const int rcp = carry_policy(c); if (rcp) return rcp; }
+    { const int rcp = begin_call(c); if (rcp) return rcp; }
     c->h_ctl[0].token = first_token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     for (uint64_t i = 0; i < n; i++) {
@@ -1407,7 +1428,7 @@ int rwkv_decode_typical(rwkv_ctx *c, uint64_t first_token, uint64_t n, float tem
     if (n == 0 || n > c->gen_cap) return fail(RWKV_E_ARG, "n_tokens must be in 1..%u", c->gen_cap);
     if (!(temp > 0.f)) return fail(RWKV_E_ARG, "need temp > 0");
     HIPCHK(hipSetDevice(c->device));
-    { const int rcp = carry_policy(c); if (rcp) return rcp; }
+    { const int rcp = begin_call(c); if (rcp) return rcp; }
     c->h_ctl[0].token = first_token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     for (uint64_t i = 0; i < n; i++) {
@@ -1434,6 +1455,7 @@ void rwkv_free(rwkv_ctx *c)
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->herr) (void)hipHostFree(c->herr);
     for (auto &e : c->xs_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->hop_ev) if (e) (void)hipEventDestroy(e);
     for (auto &row : c->sp_done) for (auto &e : row) if (e) (void)hipEventDestroy(e);
     if (c->sp_end) (void)hipEventDestroy(c->sp_end);
     for (int k = 1; k < rwkv_ctx::SPLIT_MAX; k++) { if (c->sp_stream[k]) (void)hipStreamDestroy(c->sp_stream[k]); delete c->sp_scratch[k]; }
@@ -1449,20 +1471,30 @@ void *rwkv_stream(rwkv_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int rwkv_abi_version(void) { return RWKV_MI355X_ABI_VERSION; }
 uint64_t rwkv_resident_bytes(const rwkv_ctx *c) { return c ? (uint64_t)c->alloc_bytes : 0; }
 
-// debug (RWKV_CARRY_COUNT=1 at load): workgroup launches that found / did not find the rows their predecessor was asked to leave
-// in LDS since the last call
-int rwkv_debug_carry_hits(rwkv_ctx *c, uint64_t *out2)
+// carry counters since the last call: [0] workgroup launches that found the rows their predecessor was asked to leave in LDS, [1] that
+// did not (they stream the rows themselves), [2] carried groups whose check failed and that were re-loaded from memory (kernels.hip.h
+// carry_verify).  All zero when the context does not carry (RWKV_CARRY=0, rows other than 3-4 KiB, RWKV_CARRY_COUNT=0).
+int rwkv_debug_carry_stats(rwkv_ctx *c, uint64_t *out3)
 {
-    if (!c || !out2) return fail(RWKV_E_ARG, "NULL argument");
-    out2[0] = out2[1] = 0;
+    if (!c || !out3) return fail(RWKV_E_ARG, "NULL argument");
+    out3[0] = out3[1] = out3[2] = 0;
     if (!c->carry_hits) return 0;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    unsigned h[2] = {0u, 0u};
-    HIPCHK(hipMemcpy(h, c->carry_hits, 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(c->carry_hits, 0, 8));
-    out2[0] = h[0]; out2[1] = h[1];
+    std::vector<unsigned> h((size_t)c->grid * 4, 0u);
+    HIPCHK(hipMemcpy(h.data(), c->carry_hits, h.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(c->carry_hits, 0, h.size() * 4));
+    for (int b = 0; b < c->grid; b++)
+        for (int k = 0; k < 3; k++) out3[k] += h[(size_t)b * 4 + k];
     return 0;
+}
+int rwkv_debug_carry_hits(rwkv_ctx *c, uint64_t *out2)      // the first two of the above (round-3 entry point)
+{
+    uint64_t t[3];
+    if (!out2) return fail(RWKV_E_ARG, "NULL argument");
+    const int rc = rwkv_debug_carry_stats(c, t);
+    out2[0] = t[0]; out2[1] = t[1];
+    return rc;
 }
 
 uint64_t rwkv_bytes_per_token(const rwkv_ctx *c)
@@ -1478,7 +1510,7 @@ int rwkv_profile_token(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint64
     if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
     if (token >= RWKV_VOCAB || reps <= 0) return fail(RWKV_E_ARG, "bad token / reps");
     HIPCHK(hipSetDevice(c->device));
-    { const int rcp = carry_policy(c); if (rcp) return rcp; }
+    { const int rcp = begin_call(c); if (rcp) return rcp; }
     const uint64_t L = c->L, D = c->D, V = RWKV_VOCAB;
     const int nev = (int)(4 * (c->l1 - c->l0) + 4);
     std::vector<hipEvent_t> ev(nev);
@@ -1523,7 +1555,7 @@ int rwkv_profile_batched(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint
     if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
     if (token >= RWKV_VOCAB || reps <= 0) return fail(RWKV_E_ARG, "bad token / reps");
     HIPCHK(hipSetDevice(c->device));
-    { const int rcp = carry_policy(c); if (rcp) return rcp; }
+    { const int rcp = begin_call(c); if (rcp) return rcp; }
     c->h_ctl[0].token = token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
     HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     int rc = enqueue_token(c, true, nullptr);   // valid inputs for every class
@@ -1576,7 +1608,7 @@ int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, ui
     const size_t n = (size_t)c->grid * NW * 8;
     if (cap < n) return fail(RWKV_E_ARG, "need room for %zu stamps", n);
     HIPCHK(hipSetDevice(c->device));
-    { const int rcp = carry_policy(c); if (rcp) return rcp; }
+    { const int rcp = begin_call(c); if (rcp) return rcp; }
     if (!c->tl) { int rc = dalloc(c, &c->tl, n); if (rc) return rc; }
     HIPCHK(hipMemsetAsync(c->tl, 0, n * 8, c->stream));
     c->h_ctl[0].token = token; c->h_ctl[0].slot = 0; c->h_ctl[0].out_row = 0; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
@@ -1611,7 +1643,7 @@ int rwkv_mm8_one(rwkv_ctx *c, uint64_t N, uint64_t M, const float *x, const uint
     hipLaunchKernelGGL(k_retile, rg, dim3(256), 0, c->stream, w, wt, (int)N, (int)M, 1, 1, 0);
     unsigned *rsum = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&rsum), M * sizeof(unsigned)) != hipSuccess) { (void)hipFree(wt); return fail(RWKV_E_DEVICE, "hipMalloc failed"); }
-    k_rowsum<<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, c->stream>>>(wt, rsum, (size_t)M, (int)N);
+    k_rowsum<<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, c->stream>>>(wt, rsum, nullptr, (size_t)M, (int)N, (int)N);
     Mm8Args a{wt, rsum, x, r, o, y, (int)N, (int)M};
     const int S = (int)(((quarters ? N / 4 : N) + 1023) / 1024);
     const size_t smem = RED_BYTES + (size_t)(quarters ? 4 : 1) * S * 3072;
@@ -1736,7 +1768,10 @@ int rwkv_pipe_init(rwkv_ctx *c, const void *id128, int rank, int world)
 //   control block of the item (pinned ring -> device)   -> ONE RCCL group { send x to r+1 | send the previous pick to
 //   rank 0 (last rank) | recv x from r-1 | recv the fed-back id into the control block (rank 0) }   -> the stage's graph.
 // first_tokens: [world] (read on rank 0).  picks: [world][n_steps] (written on the last rank; may be NULL elsewhere).
-int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks)
+// n_streams < world leaves the other streams' slots of the schedule empty: n_streams = 1 is ONE stream through all the stages, i.e.
+// the latency of single-stream decode on the pipeline, t_tok + (S - 1) hops + the fed-back id (SURVEY 8e "expected scaling").
+// With rwkv_pipe_profile(ctx, 1) every tick whose RCCL group holds a receive is bracketed by an event pair (rwkv_pipe_hop_stats).
+int rwkv_pipe_decode_streams(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps, uint64_t n_streams, uint64_t *picks)
 {
     if (!c) return fail(RWKV_E_ARG, "NULL ctx");
     if (!c->loaded || !c->pipe) return fail(RWKV_E_STATE, "needs a loaded context with rwkv_pipe_init done");
@@ -1744,6 +1779,7 @@ int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps
     const int S = p->world, rank = p->rank;
     const bool lastr = rank == S - 1;
     const uint64_t n_items = (uint64_t)S * n_steps;
+    if (n_streams == 0 || n_streams > (uint64_t)S) return fail(RWKV_E_ARG, "n_streams must be in 1..world");
     if (n_steps == 0 || n_items > c->gen_cap) return fail(RWKV_E_ARG, "world * n_steps must be in 1..%u", c->gen_cap);
     if ((uint64_t)S > c->maxT) return fail(RWKV_E_ARG, "needs max_ctx >= %d state slots (one per stream in flight)", S);
     if (rank == 0 && !first_tokens) return fail(RWKV_E_ARG, "rank 0 needs first_tokens");
@@ -1752,9 +1788,11 @@ int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps
     // the error when the schedule has drained (the argument checks above depend only on values every rank shares).
     bool bad_id = false;
     if (rank == 0)
-        for (int k = 0; k < S; k++) bad_id = bad_id || first_tokens[k] >= RWKV_VOCAB;
+        for (int k = 0; k < (int)n_streams; k++) bad_id = bad_id || first_tokens[k] >= RWKV_VOCAB;
     HIPCHK(hipSetDevice(c->device));
-    { const int rcp = carry_policy(c); if (rcp) return rcp; }
+    // (a failure here must not strand the peers in their ncclRecv either: it is reported once the schedule has drained; without
+    // re-captured graphs run_token launches the kernels one by one)
+    const int rc_begin = begin_call(c);
     if (c->pipe_ring_cap < n_items) {
         if (c->pipe_ring) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->pipe_ring); c->pipe_ring = nullptr; c->pipe_ring_cap = 0; }
         HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->pipe_ring), sizeof(Ctl) * n_items, hipHostMallocDefault));
@@ -1763,16 +1801,23 @@ int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps
     Ctl *ring = c->pipe_ring;
     for (uint64_t j = 0; j < n_items; j++) {
         const uint64_t stream = j % S, step = j / S;
-        ring[j].token = (rank == 0 && step == 0) ? (first_tokens[stream] < RWKV_VOCAB ? first_tokens[stream] : 0) : 0;
+        ring[j].token = (rank == 0 && step == 0 && stream < n_streams) ? (first_tokens[stream] < RWKV_VOCAB ? first_tokens[stream] : 0) : 0;
         ring[j].slot = (unsigned)stream; ring[j].out_row = (unsigned)stream; ring[j].step = (unsigned)j; ring[j].pad = 0;
     }
-    auto has_work = [&](int r, uint64_t t) { return t >= (uint64_t)r && t - r < n_items; };
+    auto active = [&](uint64_t j) { return j % (uint64_t)S < n_streams; };
+    auto has_work = [&](int r, uint64_t t) { return t >= (uint64_t)r && t - r < n_items && active(t - r); };
     int rc = 0;
+    size_t hop_n = 0;
     for (uint64_t tick = 0; tick < n_items + S - 1 && !rc; tick++) {
         const bool work = has_work(rank, tick);
-        const bool feedback = tick >= (uint64_t)S && tick < n_items;   // stage 0 starts a step >= 1: its token is the last stage's pick
+        const bool feedback = tick >= (uint64_t)S && tick < n_items && active(tick);   // stage 0 starts a step >= 1: its token is the last stage's pick
         const uint64_t j = tick - rank;
         if (work && hipMemcpyAsync(c->ctl, &ring[j], sizeof(Ctl), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(RWKV_E_DEVICE, "control block copy failed"); break; }
+        bool timed = c->pipe_prof && S > 1 && ((rank > 0 && work) || (rank == 0 && feedback)) && hop_n < rwkv_ctx::HOP_EV;
+        if (timed) {      // (a failure here only drops the measurement: the schedule must go on, the peers are waiting)
+            if (!c->hop_ev[2 * hop_n] && (hipEventCreate(&c->hop_ev[2 * hop_n]) != hipSuccess || hipEventCreate(&c->hop_ev[2 * hop_n + 1]) != hipSuccess)) timed = false;
+            if (timed && hipEventRecord(c->hop_ev[2 * hop_n], c->stream) != hipSuccess) timed = false;
+        }
         if (S > 1) {
             int r = p->GroupStart();
             if (!r && rank < S - 1 && has_work(rank + 1, tick)) r = p->Send(c->x, c->D, kNcclFloat64, rank + 1, p->comm, c->stream);
@@ -1781,6 +1826,7 @@ int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps
             if (!r && rank == 0 && feedback) r = p->Recv(&c->ctl->token, 1, kNcclUint64, S - 1, p->comm, c->stream);
             const int r2 = p->GroupEnd();
             if (r || r2) { rc = pipe_fail(p, r ? r : r2, "RCCL hop"); break; }
+            if (timed && hipEventRecord(c->hop_ev[2 * hop_n + 1], c->stream) == hipSuccess) hop_n++;
         } else if (feedback) {
             // one stage: the pick of the previous step is already in ctl->token ... but the control block was just overwritten
             HIPCHK(hipMemcpyAsync(&c->ctl->token, c->gen + (j - 1), sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
@@ -1794,9 +1840,40 @@ int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps
         if (hipMemcpy(g.data(), c->gen, n_items * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RWKV_E_DEVICE, "copy of the picks failed");
         else for (uint64_t j = 0; j < n_items; j++) picks[(j % S) * n_steps + j / S] = g[j];
     }
-    if (!rc) rc = device_check(c);
+    { const int dc = device_check(c); if (!rc) rc = dc; }      // always consumed: a code raised here must not surface from a later call
+    if (!rc && rc_begin) rc = rc_begin;
+    if (!rc && c->pipe_prof) {
+        double sum = 0.0, mn = 1e30, mx = 0.0;
+        for (size_t i = 0; i < hop_n; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->hop_ev[2 * i], c->hop_ev[2 * i + 1]) != hipSuccess) continue;
+            sum += ms; mn = std::min(mn, (double)ms); mx = std::max(mx, (double)ms);
+        }
+        c->hop_stats[0] = (double)hop_n; c->hop_stats[1] = hop_n ? 1e3 * sum / hop_n : 0.0; c->hop_stats[2] = hop_n ? 1e3 * mn : 0.0; c->hop_stats[3] = 1e3 * mx;
+    }
     if (!rc && bad_id) rc = fail(RWKV_E_ARG, "token id out of range (the schedule ran with id 0 in its place)");
     return rc;
+}
+
+int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks)
+{
+    if (!c || !c->pipe) return fail(RWKV_E_STATE, "needs a loaded context with rwkv_pipe_init done");
+    return rwkv_pipe_decode_streams(c, first_tokens, n_steps, (uint64_t)c->pipe->world, picks);
+}
+// hop timing (off by default: two event records per tick): out4 = {ticks measured, mean, min, max us} of the span, on this rank's
+// stream, from just before the tick's RCCL group {send | recv} to just behind it, over the ticks of the last rwkv_pipe_decode* call
+// whose group held a receive.  The MIN is the hop itself (the peer's data was waiting); the mean includes waiting for the peer.
+int rwkv_pipe_profile(rwkv_ctx *c, int on)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    c->pipe_prof = on != 0;
+    return 0;
+}
+int rwkv_pipe_hop_stats(rwkv_ctx *c, double *out4)
+{
+    if (!c || !out4) return fail(RWKV_E_ARG, "NULL argument");
+    for (int k = 0; k < 4; k++) out4[k] = c->hop_stats[k];
+    return 0;
 }
 
 // ---- prompt chunks on a pipeline stage -----------------------------------------------------------------------
@@ -1861,6 +1938,7 @@ int rwkv_pipe_prefill(rwkv_ctx *c, const uint64_t *tokens, uint64_t n_tokens)
     const int S = p->world, rank = p->rank;
     if (n_tokens == 0 || (rank == 0 && !tokens)) return fail(RWKV_E_ARG, "empty prompt");
     HIPCHK(hipSetDevice(c->device));
+    if (c->herr) *c->herr = 0u;
     // k_seq_embed indexes the table with the id: validate the whole prompt on rank 0.  A bad id must not strand the other ranks in
     // their ncclRecv, so the schedule runs with id 0 in its place and the error is reported once it has drained.
     std::vector<uint64_t> clean;
@@ -1891,6 +1969,7 @@ int rwkv_pipe_prefill(rwkv_ctx *c, const uint64_t *tokens, uint64_t n_tokens)
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (!rc && e != hipSuccess) rc = fail(RWKV_E_DEVICE, "pipeline prefill: %s", hipGetErrorString(e));
+    { const int dc = device_check(c); if (!rc) rc = dc; }
     if (!rc && bad_id) rc = fail(RWKV_E_ARG, "token id out of range (the schedule ran with id 0 in its place)");
     return rc;
 }

@@ -861,8 +861,8 @@ constexpr int GLDS_SPIN = 1 << 18;    // bound of every wait loop (a lost hand-o
 // is path-insensitive, and the loader wave's instruction count is the stream's ceiling) and REPORTED once per wave, behind the
 // kernel's closing barrier (ring_report), to the context's error word (mapped host memory; engine.hip device_check reads it after
 // the stream synchronisation and fails the call with RWKV_E_DEVICE): the kernel still ends, but nobody is handed its results.
-// codes: 1 loader found no room, 2 a group never landed, 3 the prologue never staged, 4 the loader's own DMA never completed,
-// 5 rows carried over from the previous kernel do not add up to their row sums (ring_groups)
+// codes: 1 loader found no room, 2 a group never landed, 3 the prologue never staged (or the carried rows were never verified),
+// 4 the loader's own DMA never completed.  (5, "carried rows damaged", is gone: round 4 repairs them in place, carry_verify.)
 __device__ __forceinline__ void wait_count(const unsigned *p, unsigned least, unsigned &fail)
 {
     bool ok = false;
@@ -915,7 +915,7 @@ struct GldsCtl {            // LDS control block of the ring (80 dwords)
     unsigned staged;        // prologue waves that have staged their part of the vector
     unsigned landed;        // ring units (rows of S KiB) whose DMA has completed: loader -> consumers, monotonic
     unsigned carried;       // groups at the head of the workgroup's share that the PREVIOUS kernel's loader left in the ring (carry)
-    unsigned pad[1];
+    unsigned verified;      // consumer waves that have checked (and, where damaged, re-loaded) the carried groups they are responsible for
     unsigned freeq[GLDS_FQ];   // freeq[k % FQ] = k + 1: group k has been copied out of the ring
     unsigned gend[GLDS_FQ];    // the loader's own: end unit of group k
     unsigned stamp[4];         // carry (below): what the previous ring kernel left in the ring for this workgroup
@@ -953,7 +953,7 @@ struct RingCarry {
     int n_in;                   // groups the previous ring kernel was asked to leave for this one
     unsigned tag_in[2], tag_out[2];
     int pos0;                   // ring position of this kernel's first unit
-    unsigned *hits;             // debug (RWKV_CARRY_COUNT=1): [0] workgroups that found their rows, [1] that did not
+    unsigned *hits;             // counters per workgroup, [block][4]: launches that found their rows / did not / carried groups re-loaded after a failed check
     int xq_bytes;               // LDS reserved for the staged vectors in front of the control block (the same for all kernels that carry)
 };
 constexpr int NC = NW - 1;              // consumer waves of a ring kernel
@@ -1009,7 +1009,11 @@ template <int S> struct RingLoader {
         const unsigned v = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 7);
         return (v & 0xfu) | ((v >> 18) & 0x30u);
     }
-    __device__ __forceinline__ void poll_landed() { publish((issued * (unsigned)S - in_flight()) / (unsigned)S); }
+    __device__ __forceinline__ void poll_landed()
+    {
+        const unsigned tot = issued * (unsigned)S, f = in_flight();
+        publish(tot > f ? (tot - f) / (unsigned)S : 0u);        // (saturating: never announce more than was issued, whatever vmcnt holds)
+    }
     __device__ __forceinline__ void advance_tail()
     {
         const unsigned g = tail + (unsigned)(lane & 31);
@@ -1106,7 +1110,6 @@ __device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_
         const unsigned want = (lane & 3) == 0 ? cy.tag_in[0] : (lane & 3) == 1 ? cy.tag_in[1] : (lane & 3) == 2 ? (unsigned)blockIdx.x : (unsigned)cy.n_in;
         have = __builtin_amdgcn_ballot_w64(got != want) == 0ull ? (unsigned)cy.n_in : 0u;
         have = (int)have <= g1 - g0 ? have : 0u;
-        if (cy.hits != nullptr && lane == 0) __hip_atomic_fetch_add(cy.hits + (have ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the control block is this wave's to zero: nobody else touches it before the order barrier
     for (int i = lane; i < (int)(sizeof(GldsCtl) / 4); i += 64) reinterpret_cast<unsigned *>(ctl)[i] = 0u;
@@ -1124,6 +1127,12 @@ __device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_
         for (int r = 0; r < rows; r++) ld.row(src + (size_t)r * stride);
     }
     ld.finish();
+    // carry counters: a word per workgroup (256 arrivals on ONE word are a 3 us chain of memory-side atomics, profiles/r04/atomicbench.txt),
+    // and only HERE, behind the loader's last DMA: the loader reads its own vmcnt to tell what has landed, and any other vector memory
+    // operation of this wave in flight would be counted as a DMA piece (round 4 found it the hard way: with the counter at the head of
+    // the loader, a workgroup that did NOT find its rows announced `issued * S - in_flight` = -1 = everything as landed)
+    if (CARRY && cy.n_in > 0 && cy.hits != nullptr && lane == 0)
+        __hip_atomic_fetch_add(cy.hits + (size_t)blockIdx.x * 4 + (have ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if RWKV_TEST_CORRUPT_CARRY
     if (CARRY && cy.n_out > 0 && lane == 0) *reinterpret_cast<__attribute__((address_space(3))) unsigned *>(ring + cpos * (unsigned)(S * 1024) + 64u) ^= 0x00010000u;
 #else
@@ -1156,52 +1165,100 @@ __device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, cons
 }
 // Rows that were CARRIED into this kernel (the first ctl->carried groups of the workgroup: they have been sitting in LDS since the
 // previous kernel, across a boundary at which another process's kernel may have had the CU) are checked before anybody is handed
-// the token: their bytes must add up to the row sums the engine keeps for the 2^22 offset anyway (`rs`: nrs sums per group, the
-// group's first at rs[g * nrs]).  Run by the consumer waves that have nothing to do while waves 0..3 stage the vector (widx of
-// nw), straight from the ring, off the streaming loop; a mismatch is recorded like a lost hand-off (code 5) and fails the call.
+// them, and RE-LOADED where the check fails (round 4; round 3 failed the call): LDS content across a kernel boundary is not something
+// the programming model promises, so a damaged row must cost a reload, not the token.  The check is a POSITION-WEIGHTED sum of the
+// row's bytes -- sum over 16-byte pieces c of (c + 1) * sum_i (1 + i) u[16 c + i], modulo 2^32 -- against the table the engine builds
+// at load next to the row sums (`rw`, k_rowsum: nrs entries per group, the group's first at rw[g * nrs]); a plain byte sum (round 3)
+// passes any permutation and any pair of compensating changes.  Run by the consumer waves that have nothing to do while waves 0..3
+// stage the vector (widx of nw), straight from the ring, off the streaming loop; every consumer waits for `verified` behind the
+// "staged" wait (it has long been reached by then).  The repair is a plain copy global -> registers -> ring by the wave that found
+// the damage: cold path, compiler-visible loads, nothing of it in the streaming loop.
+constexpr unsigned CK_PAT0 = 0x04030201u, CK_PAT1 = 0x08070605u, CK_PAT2 = 0x0c0b0a09u, CK_PAT3 = 0x100f0e0du;
+__device__ __forceinline__ unsigned ck_piece(const u32x4 &w, int c)
+{
+    unsigned t = __builtin_amdgcn_udot4(w[0], CK_PAT0, 0u, false);
+    t = __builtin_amdgcn_udot4(w[1], CK_PAT1, t, false);
+    t = __builtin_amdgcn_udot4(w[2], CK_PAT2, t, false);
+    t = __builtin_amdgcn_udot4(w[3], CK_PAT3, t, false);
+    return t * (unsigned)(c + 1);
+}
+struct CarryCheck { unsigned char *ring; int nu, pos0, chunks, g0; const unsigned *rw; int nrs; const uint8_t *w; unsigned *hits; };
 template <int R, int S>
-__device__ __forceinline__ void carry_verify(const unsigned char *ring, int nu, int pos0, const GldsCtl *ctl, int chunks, const unsigned *rs, int nrs,
-                                             int g0, int lane, int widx, int nw, unsigned &fail)
+__device__ __forceinline__ void carry_verify(const CarryCheck &ck, GldsCtl *ctl, int lane, int widx, int nw)
 {
     const int ncar = (int)ctl->carried;
     for (int k = widx; k < ncar; k += nw) {
         unsigned want = 0u;
-        if (lane < nrs) want = rs[(size_t)(g0 + k) * nrs + lane];
+        if (lane < ck.nrs) want = ck.rw[(size_t)(ck.g0 + k) * ck.nrs + lane];
         unsigned t = 0u;
-        unsigned p0 = ((unsigned)pos0 + (unsigned)k * R) % (unsigned)nu;
+        unsigned p0 = ((unsigned)ck.pos0 + (unsigned)k * R) % (unsigned)ck.nu;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const u32x4 *p = reinterpret_cast<const u32x4 *>(ring + (size_t)p0 * (S * 1024)) + lane;
+            const u32x4 *p = reinterpret_cast<const u32x4 *>(ck.ring + (size_t)p0 * (S * 1024)) + lane;
 #pragma unroll
             for (int s = 0; s < S; s++)
-                if (lane + 64 * s < chunks) {
-                    const u32x4 w = p[s * 64];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) t = __builtin_amdgcn_udot4(w[q], 0x01010101u, t, false);
-                }
-            p0 = p0 + 1 == (unsigned)nu ? 0u : p0 + 1;
+                if (lane + 64 * s < ck.chunks) t += ck_piece(p[s * 64], lane + 64 * s);
+            p0 = p0 + 1 == (unsigned)ck.nu ? 0u : p0 + 1;
         }
-        fail = wave_sum_dpp(t) == wave_sum_dpp(want) ? fail : 5u;          // R * S KiB * 255 < 2^32
+        if (wave_sum_dpp(t) != wave_sum_dpp(want)) {
+            // damaged: this group's rows once more, from memory into the ring (the layout the DMA writes: piece s of a unit holds
+            // the row's 16-byte chunk min(lane + 64 s, chunks - 1) at lane * 16)
+            const uint8_t *src = ck.w + (size_t)(ck.g0 + k) * R * ((size_t)ck.chunks << 4);
+            unsigned q0 = ((unsigned)ck.pos0 + (unsigned)k * R) % (unsigned)ck.nu;
+            for (int r = 0; r < R; r++) {
+                u32x4 *p = reinterpret_cast<u32x4 *>(ck.ring + (size_t)q0 * (S * 1024)) + lane;
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    int c = lane + 64 * s;
+                    c = c < ck.chunks ? c : ck.chunks - 1;
+                    p[s * 64] = *reinterpret_cast<const u32x4 *>(src + (size_t)r * ((size_t)ck.chunks << 4) + ((size_t)c << 4));
+                }
+                q0 = q0 + 1 == (unsigned)ck.nu ? 0u : q0 + 1;
+            }
+            if (ck.hits != nullptr && lane == 0) __hip_atomic_fetch_add(ck.hits + (size_t)blockIdx.x * 4 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    if (lane == 0) __hip_atomic_fetch_add(&ctl->verified, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-struct CarryCheck { const unsigned char *ring; int nu, pos0, chunks, g0; const unsigned *rs; int nrs; };
-// the consumer waves' streaming loop (wave < NC): same pre / epi contract as stream_groups
-template <int R, int S, int PAT, class Pre, class Epi>
+// EARLY TAKE (round 4).  The ring holds what HBM delivers while waves 0..3 run the prologue; when the prologue outlasts the ring --
+// 14B: vectors staged at 6.5 us, the ring (110-125 KiB) full at 4.4-5 us, the loader idle for ~2 us of every k_att / k_ffn_rk launch
+// (profiles/r04/timelines_14B_1B5.txt) -- the stream waits for the consumers.  The consumer waves that do NOT stage (4..6) therefore take
+// the workgroup's FIRST groups (the loader's tail only moves over LEADING free groups: freeing groups 4..6 would buy nothing) out of
+// the ring into registers as soon as they land, BEFORE the vectors are staged: three groups (45-75 KiB) more room for the loader.  So
+// the wait for "staged" (ready()) sits inside the first iteration, between the take and the dot products, and the first group of
+// wave w is (w + 3) mod 7.  The first group's epilogue inputs are still requested right in front of its dot products (an early
+// scattered global load would sit in the CU's in-order return queue in front of the stream).
+// Measured (profiles/r04/early_take_ab.txt, A/B on one box): 14B k_att 19.0 -> 18.0 us, token +1.5 %; at 3-4 KiB rows, where the ring
+// covers the prologue anyway and the first groups are the CARRIED ones, it loses 0.5 % (7B) / 3 % (3B) -- so: on for rows >= 5 KiB.
+#ifndef RWKV_EARLY_TAKE
+#define RWKV_EARLY_TAKE 2       // 0 off, 1 on, 2 by row size
+#endif
+template <int S> __device__ __forceinline__ constexpr bool early_take() { return RWKV_EARLY_TAKE == 1 || (RWKV_EARLY_TAKE == 2 && S >= 5); }
+// the consumer waves' streaming loop (wave < NC): same pre / epi contract as stream_groups; ready() = wait until the vectors are staged
+// and fetch the scalars the epilogues need (called once, by every wave)
+template <int R, int S, int PAT, class Pre, class Epi, class Ready>
 __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
-                                            int chunks, Pre pre, Epi epi, unsigned &fail, unsigned long long *g_tl_groups = nullptr, int pos0 = 0)
+                                            int chunks, Pre pre, Epi epi, Ready ready, unsigned &fail, unsigned long long *g_tl_groups = nullptr, int pos0 = 0)
 {
 #ifdef RWKV_TL_GROUPS
     // debug build (tools/timeline.py): where a consumer wave's time goes.  Stamps of the wave: 1 inputs of its first group requested,
     // 2 first group taken, 4 its dot products and reductions done, 3 its epilogue done (5 stays "staged", 6 / 7 the kernel's end)
     int rr = 0;
 #endif
-    for (int g = g0 + wave; g < g1; g += NC) {
-        const auto in = pre(g);
+    constexpr int NWP = NT / 2 / 64;
+    constexpr bool ET = early_take<S>();
+    bool first = true;
+    if (!ET) { ready(); first = false; }
+    const bool late_pre = ET && wave >= NWP;       // the waves that take their first group before the vectors are staged
+    for (int g = g0 + (ET ? (wave + NC - NWP) % NC : wave); g < g1; g += NC) {
+        decltype(pre(g)) in;
+        if (!(first && late_pre)) in = pre(g);
 #ifdef RWKV_TL_GROUPS
         if (rr == 0) tl_stamp(g_tl_groups, 1);
 #endif
         u32x4 w[R][S];
         glds_take<R, S>(w, g - g0, nu, ring, ctl, lane, fail, pos0);
+        if (first) { ready(); if (late_pre) in = pre(g); first = false; }
 #ifdef RWKV_TL_GROUPS
         asm volatile("" : "+v"(w[R - 1][S - 1]));
         if (rr < 1) tl_stamp(g_tl_groups, 2);
@@ -1225,6 +1282,7 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
         rr++;
 #endif
     }
+    if (first) ready();      // a wave without a group still meets the others (time-outs are reported per wave)
 }
 // ring kernels: the control block is zeroed before the order barrier
 __device__ __forceinline__ void ring_init(GldsCtl *gc)
@@ -1235,7 +1293,7 @@ __device__ __forceinline__ void ring_init(GldsCtl *gc)
 // publish the scalars, the others wait; contains the workgroup's order barrier, which the loader executes once as well
 template <int NV, int S, int RC = 0>
 __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &dy, const double *x, int D, double *red, unsigned *xq,
-                                          SiteRed<NV> &sr, bool publish_stats, GldsCtl *gc, unsigned long long *tl, unsigned &fail,
+                                          bool publish_stats, GldsCtl *gc, unsigned long long *tl, unsigned &fail,
                                           const CarryCheck &ck = CarryCheck{})
 {
     constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
@@ -1276,10 +1334,21 @@ __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &d
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&gc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         __syncthreads();   // order
-        if constexpr (RC > 0)
-            carry_verify<RC, S>(ck.ring, ck.nu, ck.pos0, gc, ck.chunks, ck.rs, ck.nrs, ck.g0, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6) - NWP, NC - NWP, fail);
+        if constexpr (RC > 0) {
+            carry_verify<RC, S>(ck, gc, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6) - NWP, NC - NWP);
+            wait_count(&gc->verified, NC - NWP, fail);      // these waves take the first (= the carried) groups next: all of them checked
+        }
     }
+}
+// ... and its second half, run by every consumer wave inside its first group (ring_groups' ready()): the vectors are staged, the
+// carried rows checked (and repaired); the scalars of the site come out of LDS
+template <int NV, int RC>
+__device__ __forceinline__ void ring_site_ready(double *red, GldsCtl *gc, SiteRed<NV> &sr, unsigned &fail, unsigned long long *tl)
+{
+    constexpr int NWP = NT / 2 / 64;
+    float *bc = reinterpret_cast<float *>(red + RED_BC);
     wait_count(&gc->staged, NWP, fail);
+    if constexpr (RC > 0) wait_count(&gc->verified, NC - NWP, fail);
 #pragma unroll
     for (int m = 0; m < NV; m++) { sr.S[m] = (double)bc[m]; sr.amax[m] = bc[4 + m]; }
     sr.mean = sr.rstd = 0.0;
@@ -1288,7 +1357,7 @@ __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &d
 // plain-vector prologue of a ring kernel (k_attout, k_ffnv), same roles
 template <int NVEC, int S, int RC = 0>
 __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, const float *partM, int n_part, int D, double *red, unsigned *xq,
-                                         float &Sf, float &amax, GldsCtl *gc, unsigned long long *tl, unsigned &fail, const CarryCheck &ck = CarryCheck{})
+                                         GldsCtl *gc, unsigned long long *tl, unsigned &fail, const CarryCheck &ck = CarryCheck{})
 {
     constexpr int XVD = xvd<S>();
     constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
@@ -1333,9 +1402,19 @@ __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, 
         if (lane == 0) __hip_atomic_fetch_add(&gc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         __syncthreads();   // order
-        if constexpr (RC > 0) carry_verify<RC, S>(ck.ring, ck.nu, ck.pos0, gc, ck.chunks, ck.rs, ck.nrs, ck.g0, lane, wave - NWP, NC - NWP, fail);
+        if constexpr (RC > 0) {
+            carry_verify<RC, S>(ck, gc, lane, wave - NWP, NC - NWP);
+            wait_count(&gc->verified, NC - NWP, fail);
+        }
     }
+}
+template <int RC>
+__device__ __forceinline__ void ring_vec_ready(double *red, GldsCtl *gc, float &Sf, float &amax, unsigned &fail, unsigned long long *tl)
+{
+    constexpr int NWP = NT / 2 / 64;
+    float *bc = reinterpret_cast<float *>(red + RED_BC);
     wait_count(&gc->staged, NWP, fail);
+    if constexpr (RC > 0) wait_count(&gc->verified, NC - NWP, fail);
     Sf = bc[0]; amax = bc[4];
     tl_stamp(tl, 5);
 }
@@ -1392,6 +1471,7 @@ struct AttArgs {
     SiteDyn dy;
     const uint8_t *w;                     // [D][3][D] u8: rows K_i, V_i, R_i of channel i
     const unsigned *rs;                   // [D][3] row sums of w (for the 2^22 limb offset)
+    const unsigned *rw;                   // [D][3] position-weighted row sums (check of rows carried in LDS, carry_verify)
     const double *uw, *ew;                // precomputed bonus+decay and exp(decay), [D]
     const float *r_att, *o_att;           // att_out scale / offset (to pre-scale the gated wkv)
     double *saa, *sbb;                    // state arrays [slots][L][D], already offset to this layer
@@ -1471,10 +1551,10 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
             fail = glds_loader<3, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
             tl_stamp(a.tl, 2);
         } else {
-            SiteRed<3> sr;
-            ring_site<3, S, CARRY && RWKV_CARRY_VERIFY ? 3 : 0>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rs, 3});
-            scalars(sr);
-            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl, CARRY ? a.cy.pos0 : 0);
+            constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 3 : 0;
+            ring_site<3, S, RC>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, 3, a.w, a.cy.hits});
+            auto ready = [&]() { SiteRed<3> sr; ring_site_ready<3, RC>(red, gc, sr, fail, a.tl); scalars(sr); };
+            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[3][S], wB[3][S];
@@ -1498,6 +1578,7 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
 struct AttOutArgs {
     const uint8_t *w;      // [D][D] u8 rows = output channels
     const unsigned *rs;    // [D] row sums
+    const unsigned *rw;    // [D] position-weighted row sums (carry_verify)
     const float *ybuf;     // [D] pre-scaled input vector
     const double *partS;   // [n_part] partial offset sums (n_part <= NT)
     const float *partM;    // [n_part] partial max |ybuf|
@@ -1578,10 +1659,10 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
             fail = glds_loader<R, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
             tl_stamp(a.tl, 2);
         } else {
-            ring_vec<1, S, CARRY && RWKV_CARRY_VERIFY ? R : 0>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl, fail,
-                                                              CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rs, R});
-            sc = scale_of(amax);
-            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, nullptr, CARRY ? a.cy.pos0 : 0);
+            constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? R : 0;
+            ring_vec<1, S, RC>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, R, a.w, a.cy.hits});
+            auto ready = [&]() { ring_vec_ready<RC>(red, gc, Sf, amax, fail, a.tl); sc = scale_of(amax); };
+            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, nullptr, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[R][S], wB[R][S];
@@ -1606,6 +1687,7 @@ struct FfnRKArgs {
     SiteDyn dy;
     const uint8_t *w;                 // [D][5][D]: rows ffn_k out 4i..4i+3, then ffn_r out i
     const unsigned *rs;               // [D][5] row sums
+    const unsigned *rw;               // [D][5] position-weighted row sums (carry_verify)
     const float *r_fv, *o_fv;         // ffn_v scale / offset [4D]
     float *hbuf;                      // [4D] relu^2(k) * r_fv
     float *rgate;                     // [D] sigmoid(r)
@@ -1676,10 +1758,10 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
             fail = glds_loader<5, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
             tl_stamp(a.tl, 2);
         } else {
-            SiteRed<2> sr;
-            ring_site<2, S, CARRY && RWKV_CARRY_VERIFY ? 5 : 0>(a.st, a.dy, a.x, D, red, xq, sr, true, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rs, 5});
-            scalars(sr);
-            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl, CARRY ? a.cy.pos0 : 0);
+            constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 5 : 0;
+            ring_site<2, S, RC>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, 5, a.w, a.cy.hits});
+            auto ready = [&]() { SiteRed<2> sr; ring_site_ready<2, RC>(red, gc, sr, fail, a.tl); scalars(sr); };
+            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[5][S], wB[5][S];
@@ -1703,6 +1785,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
 struct FfnVArgs {
     const uint8_t *w;      // [D][4D] u8: row i = output channel i, as 4 quarter-rows of D bytes
     const unsigned *rs;    // [D] row sums (whole 4D row)
+    const unsigned *rw;    // [D] position-weighted sums of the row's four quarter-rows (carry_verify)
     const float *hbuf;     // [4D] pre-scaled hidden vector
     const double *partS;
     const float *partM;    // [n_part] partial max |hbuf|
@@ -1773,9 +1856,10 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
             fail = glds_loader<4, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
             tl_stamp(a.tl, 2);
         } else {
-            ring_vec<4, S, CARRY && RWKV_CARRY_VERIFY ? 4 : 0>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, Sf, amax, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rs, 1});
-            sc = scale_of(amax);
-            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail, a.tl, CARRY ? a.cy.pos0 : 0);
+            constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 4 : 0;
+            ring_vec<4, S, RC>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, 1, a.w, a.cy.hits});
+            auto ready = [&]() { ring_vec_ready<RC>(red, gc, Sf, amax, fail, a.tl); sc = scale_of(amax); };
+            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[4][S], wB[4][S];
@@ -1862,10 +1946,9 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
         if (wave == NC) {
             fail = glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
         } else {
-            SiteRed<1> sr;
-            ring_site<1, S>(a.st, a.dy, a.x, D, red, xq, sr, false, gc, nullptr, fail);
-            Sf = (float)sr.S[0]; sc = scale_of(sr.amax[0]);
-            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, fail);
+            ring_site<1, S>(a.st, a.dy, a.x, D, red, xq, false, gc, nullptr, fail);
+            auto ready = [&]() { SiteRed<1> sr; ring_site_ready<1, 0>(red, gc, sr, fail, nullptr); Sf = (float)sr.S[0]; sc = scale_of(sr.amax[0]); };
+            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail);
         }
     } else {
         u32x4 wA[R][S], wB[R][S];
@@ -2018,22 +2101,26 @@ __global__ void k_retile(const uint8_t *__restrict__ src, uint8_t *__restrict__ 
     }
 }
 
-// row sums of a re-tiled matrix: rs[row] = sum_j w_t[row][j]; one wave per row (load time)
-__global__ void k_rowsum(const uint8_t *__restrict__ w_t, unsigned *__restrict__ rs, size_t rows, int N)
+// row sums of a re-tiled matrix: rs[row] = sum_j w_t[row][j]; one wave per row (load time).  rw != nullptr: also the
+// position-weighted sum that carry_verify checks rows carried in LDS against -- over the row's units of `unit` bytes (the ring's
+// unit: D bytes; an ffn_v row is four of them), piece c of a unit weighted (c + 1), byte i of a piece (1 + i), modulo 2^32
+__global__ void k_rowsum(const uint8_t *__restrict__ w_t, unsigned *__restrict__ rs, unsigned *__restrict__ rw, size_t rows, int N, int unit)
 {
     const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const u32x4 *p = reinterpret_cast<const u32x4 *>(w_t + row * (size_t)N);
-    unsigned acc = 0;
+    const int upc = unit >> 4;
+    unsigned acc = 0, wacc = 0;
     for (int c = lane; c < (N >> 4); c += 64) {
         const u32x4 v = p[c];
 #pragma unroll
         for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_udot4(v[q], 0x01010101u, acc, false);
+        wacc += ck_piece(v, c % upc);
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    if (lane == 0) rs[row] = acc;
+    for (int m = 32; m >= 1; m >>= 1) { acc += __shfl_xor(acc, m, 64); wacc += __shfl_xor(wacc, m, 64); }
+    if (lane == 0) { rs[row] = acc; if (rw) rw[row] = wacc; }
 }
 
 // uw = bonus + decay, ew = exp(decay)   (constants of rwkv.cu:247-252, hoisted out of the token loop)

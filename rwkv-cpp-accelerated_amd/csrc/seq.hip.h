@@ -899,6 +899,12 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
             // block f has landed when only what was requested behind it is outstanding: up to DEPTH - 1 blocks, and -- for the first
             // DEPTH steps behind a re-staging -- the DMA pieces
             WaitBlocks<NTW, PW, DEPTH - 1>::run(min(DEPTH - 1, nkb - 1 - f), more && k <= DEPTH - 1);
+            // load_b_asm hands out its destination before the data is there (hipcc does not track asm loads): tell the compiler that
+            // block f's registers CHANGE here, so that no read of them can be scheduled above the wait.  (A copy of a register made
+            // between the request and this point would still be wrong; none is made -- DEPTH and the slot are compile-time values, the
+            // parity gates run for every RWKV_SEQ_DEPTH knob.)
+#pragma unroll
+            for (int i = 0; i < NTW; i++) asm volatile("" : "+v"(bwr[k % DEPTH][i]));
             __builtin_amdgcn_sched_barrier(0);
             u32x4 av[2][3];
             auto read_a = [&](int vv) {
@@ -924,7 +930,16 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
             __builtin_amdgcn_sched_barrier(0);
         }
         if (c == 0) tl_stamp(a.tl, 3);
-        if (more) __syncthreads();      // every wave's pieces of chunk c + 1 have landed (waited for above); everyone has left chunk c's buffer
+        if (more) {
+            // Every wave's pieces of chunk c + 1 must have LANDED before anybody reads the other buffer.  The waits above do not say
+            // so when DEPTH == NKB (ffn_v): every one of them ran with `dma` = true and allowed the PW pieces to be outstanding, and in
+            // the next chunk a wave only proves that ITS OWN pieces have landed (in-order completion behind its next weight block)
+            // while read_a reads what the other waves staged.  Behind the DMA this wave has requested only the blocks of
+            // steps k = 1 .. NKB - 1, of which at most DEPTH - 1 (the next chunk's first) can still be in flight: wait until nothing
+            // else is.
+            WaitBlocks<NTW, PW, DEPTH - 1>::run(min(DEPTH - 1, nkb - (c + 1) * NKB), false);
+            __syncthreads();            // ... and everyone has left chunk c's buffer
+        }
     }
     tl_stamp(a.tl, 4);
     // (the record and the row sums are first TOUCHED here: hipcc's own wait for them -- it cannot see the asm requests behind them --

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("RWKV_LIB") or os.path.join(_HERE, "csrc", "librwkv_mi
 MODE_PARRALEL, MODE_GPT = 0, 1   # reference enums/enum.h:2-5
 SAMPLE_BAN0, SAMPLE_RECIPE = 1, 2   # include/rwkv_mi355x.h
 N_KCLASS = 7
-ABI_VERSION = 3                   # RWKV_MI355X_ABI_VERSION of include/rwkv_mi355x.h
+ABI_VERSION = 4                   # RWKV_MI355X_ABI_VERSION of include/rwkv_mi355x.h
 KCLASS_NAMES = ["first", "att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head", "argmax"]
 
 # every entry point declared in include/rwkv_mi355x.h (tests check the library exports all of them)
@@ -27,8 +27,8 @@ ABI_SYMBOLS = [
     "rwkv_create", "rwkv_load_file", "rwkv_load_tensors", "rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx",
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
-    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_debug_carry_hits", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
-    "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode",
+    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_debug_carry_hits", "rwkv_debug_carry_stats", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
+    "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode", "rwkv_pipe_decode_streams", "rwkv_pipe_profile", "rwkv_pipe_hop_stats",
     "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device",
 ]
 
@@ -75,6 +75,8 @@ def lib():
     L.rwkv_resident_bytes.argtypes = [vp]; L.rwkv_resident_bytes.restype = u64
     if hasattr(L, "rwkv_debug_carry_hits"):      # debug counters: absent from tuning variants built from older sources
         L.rwkv_debug_carry_hits.argtypes = [vp, C.POINTER(u64)]; L.rwkv_debug_carry_hits.restype = i32
+    if hasattr(L, "rwkv_debug_carry_stats"):
+        L.rwkv_debug_carry_stats.argtypes = [vp, C.POINTER(u64)]; L.rwkv_debug_carry_stats.restype = i32
     if L.rwkv_abi_version() != ABI_VERSION:
         raise RWKVError(f"{LIB_PATH} has C-ABI version {L.rwkv_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
     L.rwkv_sample_typical.argtypes = [vp, u64, C.c_float, C.c_float, C.c_double, i32, C.POINTER(u64)]; L.rwkv_sample_typical.restype = i32
@@ -86,6 +88,9 @@ def lib():
     L.rwkv_pipe_unique_id.argtypes = [vp]; L.rwkv_pipe_unique_id.restype = i32
     L.rwkv_pipe_init.argtypes = [vp, vp, i32, i32]; L.rwkv_pipe_init.restype = i32
     L.rwkv_pipe_decode.argtypes = [vp, C.POINTER(u64), u64, C.POINTER(u64)]; L.rwkv_pipe_decode.restype = i32
+    L.rwkv_pipe_decode_streams.argtypes = [vp, C.POINTER(u64), u64, u64, C.POINTER(u64)]; L.rwkv_pipe_decode_streams.restype = i32
+    L.rwkv_pipe_profile.argtypes = [vp, i32]; L.rwkv_pipe_profile.restype = i32
+    L.rwkv_pipe_hop_stats.argtypes = [vp, C.POINTER(C.c_double)]; L.rwkv_pipe_hop_stats.restype = i32
     L.rwkv_pipe_prefill.argtypes = [vp, C.POINTER(u64), u64]; L.rwkv_pipe_prefill.restype = i32
     L.rwkv_pipe_free.argtypes = [vp]; L.rwkv_pipe_free.restype = None
     L.rwkv_tensor_device.argtypes = [vp, i32]; L.rwkv_tensor_device.restype = vp
@@ -236,11 +241,21 @@ class RWKV:
         assert len(unique_id) == 128
         _chk(lib().rwkv_pipe_init(self._h, C.create_string_buffer(unique_id, 128), rank, world))
 
-    def pipe_decode(self, first_tokens, n_steps: int, world: int, last: bool):
-        ft = (C.c_uint64 * world)(*[int(t) for t in first_tokens]) if first_tokens is not None else None
+    def pipe_decode(self, first_tokens, n_steps: int, world: int, last: bool, n_streams: int | None = None):
+        """greedy decode of n_streams (default: world) streams over the stages; [world][n_steps] ids on the last rank"""
+        ft = (C.c_uint64 * world)(*([int(t) for t in first_tokens] + [0] * world)[:world]) if first_tokens is not None else None
         picks = (C.c_uint64 * (world * n_steps))() if last else None
-        _chk(lib().rwkv_pipe_decode(self._h, ft, n_steps, picks))
+        _chk(lib().rwkv_pipe_decode_streams(self._h, ft, n_steps, world if n_streams is None else n_streams, picks))
         return np.frombuffer(picks, dtype=np.uint64).reshape(world, n_steps).astype(np.int64) if last else None
+
+    def pipe_profile(self, on: bool = True):
+        _chk(lib().rwkv_pipe_profile(self._h, 1 if on else 0))
+
+    def pipe_hop_stats(self):
+        """{n, mean_us, min_us, max_us} of the event pairs around the per-tick RCCL group of the last pipe_decode"""
+        out = (C.c_double * 4)()
+        _chk(lib().rwkv_pipe_hop_stats(self._h, out))
+        return dict(n=int(out[0]), mean_us=float(out[1]), min_us=float(out[2]), max_us=float(out[3]))
 
     def pipe_prefill(self, tokens, n_tokens: int):
         arr = (C.c_uint64 * n_tokens)(*[int(t) for t in tokens]) if tokens is not None else None
@@ -356,6 +371,13 @@ class RWKV:
         out = (C.c_uint64 * 2)()
         _chk(lib().rwkv_debug_carry_hits(self._h, out))
         return int(out[0]), int(out[1])
+
+    def carry_stats(self):
+        """(found, not found, repaired) since the last call: workgroup launches whose first weight rows were / were not waiting in LDS, and
+        carried row groups re-loaded from memory after a failed check (kernels.hip.h carry_verify)"""
+        out = (C.c_uint64 * 3)()
+        _chk(lib().rwkv_debug_carry_stats(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def stream(self) -> int:
         return int(lib().rwkv_stream(self._h) or 0)

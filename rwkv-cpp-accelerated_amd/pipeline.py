@@ -62,7 +62,7 @@ class EngineStage:
         return self.m.stage_forward(token, slot, want_pick)
 
 
-def run_pipeline(stage, dist, rank, world, first_tokens, n_steps, device=None):
+def run_pipeline(stage, dist, rank, world, first_tokens, n_steps, device=None, n_streams=None):
     """Greedy decode of `world` independent streams (stream k starts from first_tokens[k]) for
     n_steps tokens each.  Returns the [world][n_steps] picked ids on the LAST stage (rank world-1),
     None elsewhere.  `stage`: .x (residual tensor handed between stages), .forward(token, slot, want_pick).
@@ -82,7 +82,8 @@ def run_pipeline(stage, dist, rank, world, first_tokens, n_steps, device=None):
             tk = stage.forward(tk, 0, want_pick=True); out[0, i] = tk
         return out
     n_items = S * n_steps
-    has_work = lambda r, t: 0 <= t - r < n_items
+    ns = S if n_streams is None else int(n_streams)           # only the first ns streams' slots of the schedule are filled
+    has_work = lambda r, t: 0 <= t - r < n_items and (t - r) % S < ns
     picks = np.zeros((S, n_steps), dtype=np.int64) if rank == S - 1 else None
     # a backend that cannot move device tensors point to point (gloo: the single-GPU test of this very code path)
     # gets the hop staged through host memory; RCCL moves stage.x directly
@@ -94,7 +95,7 @@ def run_pipeline(stage, dist, rank, world, first_tokens, n_steps, device=None):
     x_recv = torch.empty_like(stage.x, device=cdev) if host_staging else stage.x
     for tick in range(n_items + S - 1):
         ops = []
-        feedback = S <= tick < n_items
+        feedback = S <= tick < n_items and tick % S < ns
         if rank < S - 1 and has_work(rank + 1, tick):
             x_send.copy_(stage.x)                                   # stage.x is about to be overwritten by the recv
             ops.append(dist.P2POp(dist.isend, x_send, rank + 1))
@@ -134,9 +135,10 @@ def pipe_connect(stage, dist, rank, world):
     stage.m.pipe_init(box[0], rank, world)
 
 
-def run_pipeline_native(stage, rank, world, first_tokens, n_steps):
-    """greedy decode of `world` streams with the hop inside the engine (pipe_connect first).  [world][n_steps] ids on the last rank."""
-    return stage.m.pipe_decode(first_tokens if rank == 0 else None, n_steps, world, last=(rank == world - 1))
+def run_pipeline_native(stage, rank, world, first_tokens, n_steps, n_streams=None):
+    """greedy decode of `world` streams (or only the first n_streams of them: 1 = one stream through all the stages) with the hop
+    inside the engine (pipe_connect first).  [world][n_steps] ids on the last rank."""
+    return stage.m.pipe_decode(first_tokens if rank == 0 else None, n_steps, world, last=(rank == world - 1), n_streams=n_streams)
 
 
 def run_prefill_native(stage, rank, tokens, n_tokens):

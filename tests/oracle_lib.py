@@ -38,7 +38,17 @@ class Oracle:
         L.oracle_argmax_ban0.argtypes = [vp]; L.oracle_argmax_ban0.restype = u64
         L.oracle_tensor_elems.argtypes = [u64, u64, u64]; L.oracle_tensor_elems.restype = u64
         L.oracle_tensor_type.argtypes = [u64]; L.oracle_tensor_type.restype = u64
+        if hasattr(L, "oracle_num_threads"):
+            L.oracle_num_threads.argtypes = []; L.oracle_num_threads.restype = i32
         self.L = L
+
+    def set_threads(self, n: int):
+        if hasattr(self.L, "oracle_set_threads"):
+            self.L.oracle_set_threads.argtypes = [i32]; self.L.oracle_set_threads.restype = None
+            self.L.oracle_set_threads(int(n))
+
+    def num_threads(self) -> int:
+        return int(self.L.oracle_num_threads()) if hasattr(self.L, "oracle_num_threads") else 1
 
     # -- whole model -------------------------------------------------------------------------
     def open_file(self, path):

@@ -54,14 +54,14 @@ class OracleStage:
         return parity.argmax_ban0(self.logits) if want_pick else None
 
 
-def _worker(rank, world, port, first_tokens, q):
+def _worker(rank, world, port, first_tokens, q, n_streams=None):
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     l0, l1 = pipeline.partition_layers(L, world, D)[rank]
     st = OracleStage(mf.synthetic_tensors(L, D, seed=SEED), l0, l1, world)
-    picks = pipeline.run_pipeline(st, dist, rank, world, first_tokens, STEPS)
+    picks = pipeline.run_pipeline(st, dist, rank, world, first_tokens, STEPS, n_streams=n_streams)
     if rank == world - 1:
         q.put(picks)
     dist.barrier()
@@ -83,6 +83,31 @@ def test_pipeline_equals_single_process(world, oracle):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, first, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = q.get(timeout=240)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world,n_streams", [(3, 2)])
+def test_fewer_streams_than_stages_in_flight(world, n_streams, oracle):
+    """bench.py's `one_stream` leg (N > 1): only the first n_streams streams' slots of the schedule are filled -- n_streams = 1 is ONE
+    stream through all the stages, the pipeline's single-stream latency.  The filled streams must decode exactly as alone; the
+    others' rows stay empty and nobody waits for a hop that is never sent."""
+    first = [11, 222, 3333][:world]
+    om = oracle.from_tensors(L, D, mf.synthetic_tensors(L, D, seed=SEED))
+    want = np.zeros((world, STEPS), np.int64)
+    for k, tk in enumerate(first[:n_streams]):
+        st = om.new_state()
+        for i in range(STEPS):
+            tk = parity.argmax_ban0(om.forward([tk], st)[0]); want[k, i] = tk
+    om.close()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, first, q, n_streams)) for r in range(world)]
     [p.start() for p in procs]
     got = q.get(timeout=240)
     [p.join(timeout=60) for p in procs]
