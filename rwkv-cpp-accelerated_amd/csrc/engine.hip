@@ -1838,7 +1838,7 @@ int rwkv_pipe_decode_streams(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t
     if (!rc && lastr) {
         std::vector<uint64_t> g(n_items);
         if (hipMemcpy(g.data(), c->gen, n_items * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RWKV_E_DEVICE, "copy of the picks failed");
-        else for (uint64_t j = 0; j < n_items; j++) picks[(j % S) * n_steps + j / S] = g[j];
+        else for (uint64_t j = 0; j < n_items; j++) picks[(j % S) * n_steps + j / S] = active(j) ? g[j] : 0;     // (rows of streams that did not run: zero)
     }
     { const int dc = device_check(c); if (!rc) rc = dc; }      // always consumed: a code raised here must not surface from a later call
     if (!rc && rc_begin) rc = rc_begin;

@@ -894,11 +894,15 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
         for (int k = 0; k < NKB; k++) {
             if (k >= n) continue;                   // (wave-uniform) past the slice's end
             const int f = c * NKB + k;
-            load_k(f + DEPTH - 1, (k + DEPTH - 1) % DEPTH);
+            // the re-staging DMA is requested IN FRONT of this step's weight block: the wait for that block (step k = DEPTH - 1, at
+            // the latest the chunk's last step) then proves that this wave's pieces have landed -- loads complete in order --, so
+            // every wave reaches the end-of-chunk barrier with its share of the next image in LDS (requested behind
+            // the block, the pieces were never waited for when DEPTH == NKB)
             if (k == 0 && more) stage_a(c + 1, (c + 1) & 1);
+            load_k(f + DEPTH - 1, (k + DEPTH - 1) % DEPTH);
             // block f has landed when only what was requested behind it is outstanding: up to DEPTH - 1 blocks, and -- for the first
-            // DEPTH steps behind a re-staging -- the DMA pieces
-            WaitBlocks<NTW, PW, DEPTH - 1>::run(min(DEPTH - 1, nkb - 1 - f), more && k <= DEPTH - 1);
+            // DEPTH - 1 steps behind a re-staging -- the DMA pieces
+            WaitBlocks<NTW, PW, DEPTH - 1>::run(min(DEPTH - 1, nkb - 1 - f), more && k < DEPTH - 1);
             // load_b_asm hands out its destination before the data is there (hipcc does not track asm loads): tell the compiler that
             // block f's registers CHANGE here, so that no read of them can be scheduled above the wait.  (A copy of a register made
             // between the request and this point would still be wrong; none is made -- DEPTH and the slot are compile-time values, the
@@ -931,14 +935,11 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
         }
         if (c == 0) tl_stamp(a.tl, 3);
         if (more) {
-            // Every wave's pieces of chunk c + 1 must have LANDED before anybody reads the other buffer.  The waits above do not say
-            // so when DEPTH == NKB (ffn_v): every one of them ran with `dma` = true and allowed the PW pieces to be outstanding, and in
-            // the next chunk a wave only proves that ITS OWN pieces have landed (in-order completion behind its next weight block)
-            // while read_a reads what the other waves staged.  Behind the DMA this wave has requested only the blocks of
-            // steps k = 1 .. NKB - 1, of which at most DEPTH - 1 (the next chunk's first) can still be in flight: wait until nothing
-            // else is.
+            // Every wave's pieces of chunk c + 1 have LANDED here (see the request order above; the restated wait is satisfied
+            // already and costs nothing -- as a wait for pieces requested BEHIND the block it cost the ffn_v GEMM 0.9 us per launch);
+            // behind the barrier everyone has left chunk c's buffer and may read the other one
             WaitBlocks<NTW, PW, DEPTH - 1>::run(min(DEPTH - 1, nkb - (c + 1) * NKB), false);
-            __syncthreads();            // ... and everyone has left chunk c's buffer
+            __syncthreads();
         }
     }
     tl_stamp(a.tl, 4);

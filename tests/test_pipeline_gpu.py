@@ -141,6 +141,12 @@ def _native_worker(rank, world, port, first_tokens, L, D, seed, steps, prompt, q
         pipeline.run_prefill_native(st, rank, prompt, len(prompt))
         lg = st.m.logits(32)[: mf.VOCAB * ((len(prompt) - 1) % 32 + 1)].reshape(-1, mf.VOCAB)[-1].copy() if rank == world - 1 else None
         picks = pipeline.run_pipeline_native(st, rank, world, first_tokens, steps)
+        # ONE stream through all the stages (bench.py's `one_stream` leg), with the hop timing on: fresh state, stream 0 only
+        st.m.reset_state()
+        st.m.pipe_profile(True)
+        picks1 = pipeline.run_pipeline_native(st, rank, world, first_tokens, steps, n_streams=1)
+        hop = st.m.pipe_hop_stats()
+        st.m.pipe_profile(False)
         bad = None
         if rank == 0:                                    # a bad id must fail on rank 0 WITHOUT stranding the other ranks
             try:
@@ -152,7 +158,7 @@ def _native_worker(rank, world, port, first_tokens, L, D, seed, steps, prompt, q
         if rank == 0:
             q.put(("rank0", bad))
         if rank == world - 1:
-            q.put(("ok", picks, lg))
+            q.put(("ok", picks, lg, picks1, hop))
         dist.barrier()
         st.m.close()
         dist.destroy_process_group()
@@ -194,7 +200,7 @@ def test_native_transport_with_several_ranks_on_one_gpu(eng_mod, world):
                 p.kill()
     assert "error" not in res, res["error"]
     assert "out of range" in (res["rank0"][1] or ""), res["rank0"]
-    _, picks, lg = res["ok"]
+    _, picks, lg, picks1, hop = res["ok"]
     t = mf.synthetic_tensors(L, D, seed=seed)
     m = eng_mod.RWKV(resident=True); m.loadTensors(L, D, t, maxGPT=32)
     for i in range(0, len(prompt), 32):
@@ -208,4 +214,12 @@ def test_native_transport_with_several_ranks_on_one_gpu(eng_mod, world):
         for _ in range(steps):
             cur = parity.argmax_ban0(m.forward(cur)[: mf.VOCAB]); ids.append(cur)
         assert list(picks[k]) == ids, k
+    # rwkv_pipe_decode_streams with n_streams = 1: stream 0 from a fresh state, the other streams' rows untouched, and the last rank's
+    # receives (x from rank world - 2, every step) bracketed by event pairs
+    m.reset_state()
+    cur, ids = first[0], []
+    for _ in range(steps):
+        cur = parity.argmax_ban0(m.forward(cur)[: mf.VOCAB]); ids.append(cur)
+    assert list(picks1[0]) == ids and not picks1[1:].any(), picks1
+    assert hop["n"] == steps and 0.0 < hop["min_us"] <= hop["mean_us"] <= hop["max_us"], hop
     m.close()

@@ -1,15 +1,19 @@
 #!/bin/bash
 # One GPU-box session that produces everything profiles/rNN/ holds: GPU tests, the full bench line (reference-kernel
 # gate + CPU baseline legs included), rocprofv3 kernel-trace stats of the bench command, a separate PMC pass (FETCH_SIZE
-# only, no trace domains), the prefill report with per-kernel statistics, the other model sizes.  usage: tools/gpu_round.sh [r03]
+# only, no trace domains), the prefill report with per-kernel statistics, the other model sizes, the N = 2 dry runs of the multi-GPU bench line.  usage: tools/gpu_round.sh [r04]
 cd "$(dirname "$0")/.."
-R=$PWD; TAG=${1:-r03}; O=$R/gpurun_out/$TAG
+R=$PWD; TAG=${1:-r04}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 export PYTHONUNBUFFERED=1
 if [ -z "$SKIP_TESTS" ]; then
   timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rs 2>&1 | grep -v "^loading\|^n_layers\|^n_embed" | tail -8 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
 fi
 timeout 900 python bench.py 2>$O/bench7b_full.err | tail -1 > $O/bench7b_full.json; cut -c1-300 $O/bench7b_full.json
+# the N > 1 line as the driver will run it, dry on the one GPU: 2 ranks, torch.distributed over gloo; (a) the engine's NATIVE schedule over the
+# shared-memory RCCL stand-in (tests/fake_rccl.cpp), 14B by default; (b) the Python schedule over torch P2P ops
+RWKV_BENCH_BACKEND=gloo RWKV_BENCH_ONE_DEVICE=1 RWKV_RCCL_LIB=$R/tests/_build/libfake_rccl.so timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 64 --warmup 8 --prefill-chunks 2 2>$O/bench_n2_dryrun_native.err | grep '^{"metric"' | tail -1 > $O/bench_n2_dryrun_native.json; echo "native dry run: exit $? $(wc -c < $O/bench_n2_dryrun_native.json) bytes"
+RWKV_BENCH_BACKEND=gloo RWKV_BENCH_ONE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 16 --warmup 2 --model 1B5 --no-cpu-baseline 2>$O/bench_n2_dryrun_python.err | grep '^{"metric"' | tail -1 > $O/bench_n2_dryrun_python.json; echo "python dry run: exit $? $(wc -c < $O/bench_n2_dryrun_python.json) bytes"
 bash tools/seq_trace.sh $O 2>&1 | tail -16
 python - $O <<'PY'
 import json, subprocess, sys, os
