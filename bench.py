@@ -244,8 +244,9 @@ def main():
                                note="GPT-mode chunk (RWKV::loadContext path): v_mfma_i32_16x16x64_i8 over three activation limbs; includes logits for all 32 positions")
         if args.long_prompt >= 64:
             # a prompt of several chunks handed over in ONE call (RWKV::loadContext with maxContext >= the prompt, rwkv.h:395-413):
-            # still 32 rows per mm8_seq pass, but the chunks run as a three-stage software pipeline on three streams (engine.hip
-            # rwkv_forward).  Timed without the download of the T x V logits (only the last row matters to loadContext).
+            # passes of 64 rows (two 32-row halves that share every weight fragment: weights read once per 64 rows, round 4) as a
+            # three-stage software pipeline on three streams (engine.hip rwkv_forward).  Timed without the download of the T x V
+            # logits (only the last row matters to loadContext).
             import ctypes as C
             lp = [int(x) for x in np.random.default_rng(11).integers(2, mf.VOCAB, args.long_prompt)]
             arr = (C.c_uint64 * len(lp))(*lp)
@@ -260,8 +261,9 @@ def main():
             dtl = (time.perf_counter() - t0) / 2
             line["prefill"]["long_prompt"] = dict(prompt_tokens=len(lp), tokens_per_s=round(len(lp) / dtl, 1), ms=round(dtl * 1e3, 2),
                                                   weight_GBps=round(wbytes * (len(lp) / 32) / dtl / 1e9, 1),
-                                                  note="one rwkv_forward call, 32-row chunks as a software pipeline over RWKV_SEQ_STAGES (default 3) streams on the one GPU "
-                                                       "(stage k on chunk i while stage k - 1 is on chunk i + 1); RWKV_SEQ_STAGES=1 gives the one-stream schedule")
+                                                  note="one rwkv_forward call: passes of 64 rows (two halves per weight fragment; RWKV_SEQ_ROWS=32: the 32-row schedule, bit-identical "
+                                                       "results) as a software pipeline over RWKV_SEQ_STAGES (default 3) streams on the one GPU (stage k on pass i while "
+                                                       "stage k - 1 is on pass i + 1); RWKV_SEQ_STAGES=1 gives the one-stream schedule")
         # the same kernels as a batched decode step: 32 independent streams (MODE PARRALEL, state slot per stream)
         m.reset_state()
         m.forward(prompt, engine.MODE_PARRALEL)
@@ -288,7 +290,7 @@ def main():
                 run_many()
             dtm = (time.perf_counter() - t0) / args.prefill_chunks
             line["batched_decode"]["streams_96"] = dict(ms_per_step=round(dtm * 1e3, 3), aggregate_tokens_per_s=round(len(many) / dtm, 1),
-                                                        note="three 32-row passes per step as a software pipeline over the stages (RWKV_SEQ_STAGES)")
+                                                        note="a 64-row and a 32-row pass per step as a software pipeline over the stages (RWKV_SEQ_STAGES)")
 
     # ---- BASELINE config 2 beside the headline: RWKV-4-Raven-1B5 single-stream decode on the same GPU ----
     if rank == 0 and args.model == "7B" and args.config2_steps > 0:

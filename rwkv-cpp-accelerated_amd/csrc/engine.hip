@@ -161,6 +161,7 @@ struct rwkv_ctx {
     uint64_t L = 0, D = 0, maxT = 1;
     uint64_t l0 = 0, l1 = UINT64_MAX;   // pipeline stage: this context owns layers [l0, l1) (whole model by default)
     int S = 0;               // ceil(D / 1024): 1 KiB row pieces per lane
+    int seq_rows = SEQ_TM;   // chunk path: rows per weight pass, 64 (two halves, round 4) or 32 (env RWKV_SEQ_ROWS)
     int seq_pipe = 15;       // chunk path: GEMM kinds (bit 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v) that run as k_seq_gemm_p (env RWKV_SEQ_PIPE)
     int carry_kib = -1;      // ring kernels: KiB of the NEXT ring kernel's rows a workgroup's loader leaves in LDS (kernels.hip.h "CARRY"; env RWKV_CARRY, 0 = off;
                              // default: where it pays -- 32 at 4 KiB rows (7B: +1.3 %), 20 at 3 KiB rows (3B: +3.3 %; 32: -0.7 %) -- else 0 (14B: -2.2 %;
@@ -637,6 +638,10 @@ int seq_smem_limits()
     SEQ_ALLOW_P(2, 5, 8, 2, RWKV_SEQ_DEPTH2, false); SEQ_ALLOW_P(2, 4, 10, 2, 2, false);
     SEQ_ALLOW_P(3, 1, 8, 1, 8, true); SEQ_ALLOW_P(3, 1, 10, 1, 10, true);
 #undef SEQ_ALLOW_P
+#define SEQ_ALLOW_P2(TAG, NTW, NKB, NVS, DEPTH, MULTI) if (!rc) rc = allow_smem(k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI, 2>, seq_gemm_p_smem(NKB, NVS, MULTI, 2))
+    SEQ_ALLOW_P2(0, 3, 2, 3, 2, true); SEQ_ALLOW_P2(1, 1, 8, 1, 8, false); SEQ_ALLOW_P2(1, 1, 10, 1, 10, false);
+    SEQ_ALLOW_P2(2, 3, 2, 2, 2, true); SEQ_ALLOW_P2(3, 1, 4, 1, 4, true);
+#undef SEQ_ALLOW_P2
     if (!rc) rc = allow_smem(k_seq_gemm_ks, SEQ_KS_SMEM);
     return rc;
 }
@@ -840,31 +845,33 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     {
         const char *e = getenv("RWKV_SEQ");
         if (max_ctx > 1 && D % 64 == 0 && !(e && e[0] == '0')) {
-            if ((rc = dalloc(c, &c->sq_tokens, (size_t)SQ_RING * SEQ_T))) return rc;
-            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_sq_tokens), sizeof(unsigned long long) * SQ_RING * SEQ_T, hipHostMallocDefault));
+            if ((rc = dalloc(c, &c->sq_tokens, (size_t)SQ_RING * SEQ_TM))) return rc;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_sq_tokens), sizeof(unsigned long long) * SQ_RING * SEQ_TM, hipHostMallocDefault));
             for (int r = 0; r < SQ_RING; r++) HIPCHK(hipEventCreateWithFlags(&c->sq_ev[r], hipEventDisableTiming));
-            if ((rc = dalloc(c, &c->sq_x[0], (size_t)SEQ_T * D))) return rc;
-            if ((rc = dalloc(c, &c->sq_x[1], (size_t)SEQ_T * D))) return rc;
+            // (everything per chunk is sized for a pass of SEQ_TM = 64 rows = two halves: half 1's images / records / partial values sit
+            // right behind half 0's, seq.hip.h SEQ_TM)
+            if ((rc = dalloc(c, &c->sq_x[0], (size_t)SEQ_TM * D))) return rc;
+            if ((rc = dalloc(c, &c->sq_x[1], (size_t)SEQ_TM * D))) return rc;
             if ((rc = dalloc(c, &c->sq_state, (size_t)D))) return rc;
-            if ((rc = dalloc(c, &c->sq_y, (size_t)SEQ_T * D))) return rc;
+            if ((rc = dalloc(c, &c->sq_y, (size_t)SEQ_TM * D))) return rc;
             for (int k = 0; k < 3; k++) {
-                if ((rc = dalloc(c, &c->sq_img[k], a_image_bytes(D) / 4))) return rc;
-                HIPCHK(hipMemsetAsync(c->sq_img[k], 0, a_image_bytes(D), c->stream));
+                if ((rc = dalloc(c, &c->sq_img[k], 2 * a_image_bytes(D) / 4))) return rc;
+                HIPCHK(hipMemsetAsync(c->sq_img[k], 0, 2 * a_image_bytes(D), c->stream));
             }
-            if ((rc = dalloc(c, &c->sq_imgh, a_image_bytes(4 * D) / 4))) return rc;
-            HIPCHK(hipMemsetAsync(c->sq_imgh, 0, a_image_bytes(4 * D), c->stream));
-            if ((rc = dalloc(c, &c->sq_qpart, (size_t)3 * SEQ_T * SEQ_O))) return rc;
-            if ((rc = dalloc(c, &c->sq_qparta, (size_t)SEQ_T * SEQ_O))) return rc;
-            if ((rc = dalloc(c, &c->sq_qparth, (size_t)SEQ_T * SEQ_O))) return rc;
-            HIPCHK(hipMemsetAsync(c->sq_qpart, 0, sizeof(SeqPart) * 3 * SEQ_T * SEQ_O, c->stream));
-            HIPCHK(hipMemsetAsync(c->sq_qparta, 0, sizeof(SeqPart) * SEQ_T * SEQ_O, c->stream));
-            HIPCHK(hipMemsetAsync(c->sq_qparth, 0, sizeof(SeqPart) * SEQ_T * SEQ_O, c->stream));
-            if ((rc = dalloc(c, &c->sq_stat, (size_t)SEQ_T * SEQ_O))) return rc;
-            {   // accumulator images: [slice][tile][2][4][64] floats, tiles = classes x 16-channel blocks
+            if ((rc = dalloc(c, &c->sq_imgh, 2 * a_image_bytes(4 * D) / 4))) return rc;
+            HIPCHK(hipMemsetAsync(c->sq_imgh, 0, 2 * a_image_bytes(4 * D), c->stream));
+            if ((rc = dalloc(c, &c->sq_qpart, (size_t)2 * 3 * SEQ_T * SEQ_O))) return rc;
+            if ((rc = dalloc(c, &c->sq_qparta, (size_t)2 * SEQ_T * SEQ_O))) return rc;
+            if ((rc = dalloc(c, &c->sq_qparth, (size_t)2 * SEQ_T * SEQ_O))) return rc;
+            HIPCHK(hipMemsetAsync(c->sq_qpart, 0, sizeof(SeqPart) * 2 * 3 * SEQ_T * SEQ_O, c->stream));
+            HIPCHK(hipMemsetAsync(c->sq_qparta, 0, sizeof(SeqPart) * 2 * SEQ_T * SEQ_O, c->stream));
+            HIPCHK(hipMemsetAsync(c->sq_qparth, 0, sizeof(SeqPart) * 2 * SEQ_T * SEQ_O, c->stream));
+            if ((rc = dalloc(c, &c->sq_stat, (size_t)SEQ_TM * SEQ_O))) return rc;
+            {   // accumulator images: [half][slice][tile][2][4][64] floats, tiles = classes x 16-channel blocks
                 const size_t cbd = ((size_t)D + 15) / 16;
-                if ((rc = dalloc(c, &c->sq_pk3, (size_t)SEQ_O * 3 * cbd * 512))) return rc;
-                if ((rc = dalloc(c, &c->sq_pk5, (size_t)SEQ_O * 5 * cbd * 512))) return rc;
-                if ((rc = dalloc(c, &c->sq_pk1, (size_t)SEQ_O * cbd * 512))) return rc;
+                if ((rc = dalloc(c, &c->sq_pk3, (size_t)2 * SEQ_O * 3 * cbd * 512))) return rc;
+                if ((rc = dalloc(c, &c->sq_pk5, (size_t)2 * SEQ_O * 5 * cbd * 512))) return rc;
+                if ((rc = dalloc(c, &c->sq_pk1, (size_t)2 * SEQ_O * cbd * 512))) return rc;
             }
             // second resident copy of the matrices: MFMA B-operand images (seq.hip.h k_bimage) + row sums per octant of K
             {
@@ -903,7 +910,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     return 0;
 }
 
-// One chunk (n <= SEQ_T rows) through the MFMA path (seq.hip.h) for THIS context's layers [l0, l1); logits rows
+// One pass (n <= SEQ_TM = 64 rows: one or two halves of <= 32) through the MFMA path (seq.hip.h) for THIS context's layers [l0, l1); logits rows
 // [row0, row0 + n) on the stage that holds the head.
 // par == false: GPT-mode semantics of rwkv.cu:493-593 -- n tokens of one sequence, state slot 0, token
 // shift along the chunk.  par == true: PARRALEL mode (rwkv.cu:236-240) -- n independent sequences, one
@@ -932,7 +939,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
     if (first) {
         const int slot = (int)(c->sq_n % SQ_RING);
         if (c->sq_n >= SQ_RING) HIPCHK(hipEventSynchronize(c->sq_ev[slot]));   // the copy that last used this pinned slot is done
-        unsigned long long *h = c->h_sq_tokens + (size_t)slot * SEQ_T, *d = c->sq_tokens + (size_t)slot * SEQ_T;
+        unsigned long long *h = c->h_sq_tokens + (size_t)slot * SEQ_TM, *d = c->sq_tokens + (size_t)slot * SEQ_TM;
         for (int t = 0; t < n; t++) h[t] = tokens[t];
         HIPCHK(hipMemcpyAsync(d, h, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(c->sq_ev[slot], st));
@@ -942,25 +949,42 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
     }
     const size_t LD = (size_t)L * D;
     const int egrid = n * SEQ_O;
+    // a pass of 33 .. 64 rows has two halves (seq.hip.h SEQ_TM): the GEMMs read the weights ONCE for both, everything per half sits
+    // at these element offsets behind half 0's
+    const bool two = n > SEQ_T;
+    const size_t cbd_ = ((size_t)D + 15) / 16;
+    const size_t h_img = a_image_bytes(D) / 4, h_imgh = a_image_bytes(4 * (size_t)D) / 4;                  // 32-bit words
+    const size_t h_part3 = (size_t)3 * SEQ_T * SEQ_O, h_part1 = (size_t)SEQ_T * SEQ_O;                     // records
+    const size_t h_pk3 = (size_t)SEQ_O * 3 * cbd_ * 512, h_pk5 = (size_t)SEQ_O * 5 * cbd_ * 512, h_pk1 = (size_t)SEQ_O * cbd_ * 512;   // floats
     const bool big = (D >> 6) > 8 * SEQ_O;       // octants of K = D longer than 8 k-blocks (D > 4096): the NKB = 10 instances
     static const int v012[5] = {0, 1, 2, 0, 0}, v0[5] = {0, 0, 0, 0, 0}, v00001[5] = {0, 0, 0, 0, 1};
     bool tl_layer = false;     // debug timeline (rwkv_debug_timeline with RWKV_TL_CLASS = 10 + GEMM kind): the middle layer's GEMM stamps its phases
     // kind 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v: tile-per-wave GEMM over the 8 K-slices, partial values into pk
     auto gemm = [&](int kind, const uint8_t *bimg, const unsigned *rs8, int N, int K, int Q, const int *voq, unsigned *const *img, const SeqPart *qpart,
-                    float *pk, double *state_dst) {
+                    float *pk, double *state_dst, size_t gh_img, size_t gh_part, size_t gh_pk) {
         SeqGemmArgs g{};
         g.bimg = reinterpret_cast<const u32x4 *>(bimg); g.rs8 = rs8; g.N = N; g.K = K; g.Q = Q;
         for (int q = 0; q < 5; q++) g.vec_of_q[q] = q < Q ? voq[q] : voq[Q - 1];
         for (int k = 0; k < 3; k++) g.img[k] = reinterpret_cast<const u32x4 *>(img[k]);
         g.part = qpart; g.pk = pk; g.out = nullptr; g.T = n;
+        g.img_h = gh_img / 4; g.part_h = gh_part; g.pk_h = gh_pk;      // (images: 16-byte units)
         g.tl = (c->tl_on && c->tl_cls == 10 + kind && tl_layer) ? c->tl : nullptr;
         g.cp_src = S.state; g.cp_dst = state_dst; g.cp_n = (state_dst && !par) ? D : 0;   // GPT: commit the site's state behind it
         const int nch = (N + Q - 1) / Q, ntiles = Q * ((nch + 15) / 16);
-        const int ntw_max = kind == 0 ? 3 : kind == 2 ? (big ? 4 : 5) : 1;
+        const int ntw_max = kind == 0 ? 3 : kind == 2 ? (two ? 3 : big ? 4 : 5) : 1;      // (two halves: twice the accumulators per weight tile)
         const int RB = (ntiles + SEQ_NW * ntw_max - 1) / (SEQ_NW * ntw_max);
         g.ntw = (ntiles + SEQ_NW * RB - 1) / (SEQ_NW * RB);
         const dim3 grid(SEQ_O * RB), blk(SEQ_NT);
 #define SEQ_LAUNCH_P(TAG, NTW, NKB, NVS, DEPTH, MULTI) k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI><<<grid, blk, seq_gemm_p_smem(NKB, NVS, MULTI), st>>>(g)
+#define SEQ_LAUNCH_P2(TAG, NTW, NKB, NVS, DEPTH, MULTI) k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI, 2><<<grid, blk, seq_gemm_p_smem(NKB, NVS, MULTI, 2), st>>>(g)
+        if (two) {      // both halves per weight fragment: short k-block groups re-staged into the other LDS buffer (the image of two halves is twice as large)
+            if (kind == 0) SEQ_LAUNCH_P2(0, 3, 2, 3, 2, true);
+            else if (kind == 1) { if (big) SEQ_LAUNCH_P2(1, 1, 10, 1, 10, false); else SEQ_LAUNCH_P2(1, 1, 8, 1, 8, false); }
+            else if (kind == 2) SEQ_LAUNCH_P2(2, 3, 2, 2, 2, true);
+            else SEQ_LAUNCH_P2(3, 1, 4, 1, 4, true);
+            return;
+        }
+#undef SEQ_LAUNCH_P2
         if (c->seq_pipe & (1 << kind)) {       // the GEMM as a software pipeline over k-blocks (seq.hip.h k_seq_gemm_p; RWKV_SEQ_PIPE bit per kind)
             if (kind == 0) { if (big) SEQ_LAUNCH_P(0, 3, 10, 2, 2, false); else SEQ_LAUNCH_P(0, 3, 8, 3, RWKV_SEQ_DEPTH0, false); }
             else if (kind == 1) { if (big) SEQ_LAUNCH_P(1, 1, 10, 1, 10, false); else SEQ_LAUNCH_P(1, 1, 8, 1, 8, false); }
@@ -980,6 +1004,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         SeqResidArgs r{};
         r.x = x; r.pk = S.pk1; r.qpart = qpart; r.pk_gate = S.pk5; r.qpart_gate = S.qpart + (size_t)1 * SEQ_T * SEQ_O;   // ffn r = vector 1 of the ln2 site
         r.stat = S.stat; r.D = D; r.T = n;
+        r.pk_h = h_pk1; r.pkg_h = h_pk5; r.part_h = h_part1; r.partg_h = h_part3;
         if (mode == 0) k_seq_resid<0><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(r);
         else if (mode == 1) k_seq_resid<1><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(r);
         else k_seq_resid<2><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(r);
@@ -992,6 +1017,7 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         s.par = par && state; s.state_par = state; s.slot_stride = LD; s.slot0 = (int)row0;
         for (int q = 0; q < 3; q++) s.img[q] = S.img[q];
         s.part = S.qpart; s.D = D; s.T = n;
+        s.img_h = h_img; s.part_h = h_part3;
         if (nv == 3) k_seq_site<3><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(s);
         else if (nv == 2) k_seq_site<2><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(s);
         else k_seq_site<1><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(s);
@@ -1007,12 +1033,13 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
             const double *mix[3] = {c->mixk + lo, c->mixv + lo, c->mixr + lo};
             const float *r[3] = {c->kr + lo, c->vr + lo, c->rr + lo}, *o[3] = {c->o1 + lo, c->o2 + lo, c->o3 + lo};
             site(3, c->ln + (4 * l + 2) * D, c->ln + (4 * l + 3) * D, mix, r, o, c->state[0] + lo);
-            gemm(0, c->b_kvr + wl * 3 * CBd * 16 * D, c->r8_kvr + wl * SEQ_O * 3 * (size_t)D, 3 * D, D, 3, v012, S.img, S.qpart, S.pk3, c->state[0] + lo);
-            SeqWkvArgs wa{S.pk3, S.qpart, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, S.y, D, n, par ? 1 : 0, LD, (int)row0};
-            k_seq_wkv<<<dim3(n_wkv), dim3(SEQ_T * WKV_CH), 0, st>>>(wa);
-            SeqStageArgs sa{S.y, nullptr, nullptr, c->attr + lo, c->atto + lo, S.img[0], S.qparta, D, n};
+            gemm(0, c->b_kvr + wl * 3 * CBd * 16 * D, c->r8_kvr + wl * SEQ_O * 3 * (size_t)D, 3 * D, D, 3, v012, S.img, S.qpart, S.pk3, c->state[0] + lo, h_img, h_part3, h_pk3);
+            SeqWkvArgs wa{S.pk3, S.qpart, c->uw + lo, c->ew + lo, c->state[1] + lo, c->state[2] + lo, S.y, D, n, par ? 1 : 0, LD, (int)row0, h_pk3, h_part3};
+            if (two) k_seq_wkv<SEQ_TM><<<dim3(n_wkv), dim3(SEQ_TM * WKV_CH), 0, st>>>(wa);
+            else k_seq_wkv<SEQ_T><<<dim3(n_wkv), dim3(SEQ_T * WKV_CH), 0, st>>>(wa);
+            SeqStageArgs sa{S.y, nullptr, nullptr, c->attr + lo, c->atto + lo, S.img[0], S.qparta, D, n, 0, 0, h_img, h_part1};
             k_seq_stage<0><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(sa);
-            gemm(1, c->b_att + wl * CBd * 16 * D, c->r8_att + wl * SEQ_O * (size_t)D, D, D, 1, v0, S.img, S.qparta, S.pk1, nullptr);
+            gemm(1, c->b_att + wl * CBd * 16 * D, c->r8_att + wl * SEQ_O * (size_t)D, D, D, 1, v0, S.img, S.qparta, S.pk1, nullptr, h_img, h_part1, h_pk1);
             // x = f32(x) + att_out; statistics for ln2.  (Round 3 tried this launch and the site behind it as ONE launch whose (row, octant)
             // workgroups meet on a per-row arrival counter: +3.6 us per fused launch, profiles/r03/prefill_fuse.txt -- the in-launch
             // all-to-all costs more than the kernel boundary it replaces.)
@@ -1022,10 +1049,10 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
             const double *mix[3] = {c->fmixk + lo, c->fmixr + lo, nullptr};
             const float *r[3] = {c->fkr + lo, c->frr + lo, nullptr}, *o[3] = {c->fko + lo, c->fro + lo, nullptr};
             site(2, c->ln + (4 * l + 4) * D, c->ln + (4 * l + 5) * D, mix, r, o, c->state[4] + lo);
-            gemm(2, c->b_frk + wl * 5 * CBd * 16 * D, c->r8_frk + wl * SEQ_O * 5 * (size_t)D, 5 * D, D, 5, v00001, S.img, S.qpart, S.pk5, c->state[4] + lo);
-            SeqStageArgs sh{nullptr, S.pk5, S.qpart, c->fvr + 4 * lo, c->fvo + 4 * lo, S.imgh, S.qparth, 4 * D, n};
+            gemm(2, c->b_frk + wl * 5 * CBd * 16 * D, c->r8_frk + wl * SEQ_O * 5 * (size_t)D, 5 * D, D, 5, v00001, S.img, S.qpart, S.pk5, c->state[4] + lo, h_img, h_part3, h_pk5);
+            SeqStageArgs sh{nullptr, S.pk5, S.qpart, c->fvr + 4 * lo, c->fvo + 4 * lo, S.imgh, S.qparth, 4 * D, n, h_pk5, h_part3, h_imgh, h_part1};
             k_seq_stage<1><<<dim3(egrid), dim3(SEQ_ENT), 0, st>>>(sh);
-            gemm(3, c->b_fv + wl * CBd * 16 * 4 * D, c->r8_fv + wl * SEQ_O * (size_t)D, D, 4 * D, 1, v0, imgh3, S.qparth, S.pk1, nullptr);
+            gemm(3, c->b_fv + wl * CBd * 16 * 4 * D, c->r8_fv + wl * SEQ_O * (size_t)D, D, 4 * D, 1, v0, imgh3, S.qparth, S.pk1, nullptr, h_imgh, h_part1, h_pk1);
             resid(2, S.qparth);     // x += ffn_v * sigmoid(r); statistics for the next site
         }
     }
@@ -1035,8 +1062,13 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         SeqGemmArgs g{};
         g.bimg = reinterpret_cast<const u32x4 *>(c->b_head); g.rs8 = c->r8_head; g.N = (int)V; g.K = D; g.Q = 1;
         for (int k = 0; k < 3; k++) g.img[k] = reinterpret_cast<const u32x4 *>(S.img[k]);
-        g.part = S.qpart; g.out = c->logits + row0 * V; g.T = n;
+        g.part = S.qpart; g.out = c->logits + row0 * V; g.T = two ? SEQ_T : n;
         k_seq_gemm_ks<<<dim3(c->grid), dim3(SEQ_NT), SEQ_KS_SMEM, st>>>(g);
+        if (two) {      // the head once per half (its weights are 3 % of a pass's bytes; 240 accumulator registers would not fit one wave)
+            for (int k = 0; k < 3; k++) g.img[k] = reinterpret_cast<const u32x4 *>(S.img[k] + h_img);
+            g.part = S.qpart + h_part3; g.out = c->logits + (row0 + SEQ_T) * V; g.T = n - SEQ_T;
+            k_seq_gemm_ks<<<dim3(c->grid), dim3(SEQ_NT), SEQ_KS_SMEM, st>>>(g);
+        }
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1061,31 +1093,31 @@ int split_setup(rwkv_ctx *c)
         for (int b = 0; b < want; b++) HIPCHK(hipEventCreateWithFlags(&c->sp_done[k][b], hipEventDisableTiming));
     }
     int rc = 0;
-    for (int k = 2; k < want && !rc; k++) rc = dalloc(c, &c->sq_x[k], (size_t)SEQ_T * D);
+    for (int k = 2; k < want && !rc; k++) rc = dalloc(c, &c->sq_x[k], (size_t)SEQ_TM * D);
     for (int k = 1; k < want && !rc; k++) {
         SeqScratch *S = new SeqScratch();
         c->sp_scratch[k] = S;
         if (!rc) rc = dalloc(c, &S->state, (size_t)D);
-        if (!rc) rc = dalloc(c, &S->y, (size_t)SEQ_T * D);
+        if (!rc) rc = dalloc(c, &S->y, (size_t)SEQ_TM * D);
         for (int q = 0; q < 3 && !rc; q++) {
-            rc = dalloc(c, &S->img[q], a_image_bytes(D) / 4);
-            if (!rc) HIPCHK(hipMemsetAsync(S->img[q], 0, a_image_bytes(D), c->stream));
+            rc = dalloc(c, &S->img[q], 2 * a_image_bytes(D) / 4);
+            if (!rc) HIPCHK(hipMemsetAsync(S->img[q], 0, 2 * a_image_bytes(D), c->stream));
         }
-        if (!rc) rc = dalloc(c, &S->imgh, a_image_bytes(4 * D) / 4);
-        if (!rc) HIPCHK(hipMemsetAsync(S->imgh, 0, a_image_bytes(4 * D), c->stream));
-        if (!rc) rc = dalloc(c, &S->qpart, (size_t)3 * SEQ_T * SEQ_O);
-        if (!rc) rc = dalloc(c, &S->qparta, (size_t)SEQ_T * SEQ_O);
-        if (!rc) rc = dalloc(c, &S->qparth, (size_t)SEQ_T * SEQ_O);
+        if (!rc) rc = dalloc(c, &S->imgh, 2 * a_image_bytes(4 * D) / 4);
+        if (!rc) HIPCHK(hipMemsetAsync(S->imgh, 0, 2 * a_image_bytes(4 * D), c->stream));
+        if (!rc) rc = dalloc(c, &S->qpart, (size_t)2 * 3 * SEQ_T * SEQ_O);
+        if (!rc) rc = dalloc(c, &S->qparta, (size_t)2 * SEQ_T * SEQ_O);
+        if (!rc) rc = dalloc(c, &S->qparth, (size_t)2 * SEQ_T * SEQ_O);
         if (!rc) {
-            HIPCHK(hipMemsetAsync(S->qpart, 0, sizeof(SeqPart) * 3 * SEQ_T * SEQ_O, c->stream));
-            HIPCHK(hipMemsetAsync(S->qparta, 0, sizeof(SeqPart) * SEQ_T * SEQ_O, c->stream));
-            HIPCHK(hipMemsetAsync(S->qparth, 0, sizeof(SeqPart) * SEQ_T * SEQ_O, c->stream));
+            HIPCHK(hipMemsetAsync(S->qpart, 0, sizeof(SeqPart) * 2 * 3 * SEQ_T * SEQ_O, c->stream));
+            HIPCHK(hipMemsetAsync(S->qparta, 0, sizeof(SeqPart) * 2 * SEQ_T * SEQ_O, c->stream));
+            HIPCHK(hipMemsetAsync(S->qparth, 0, sizeof(SeqPart) * 2 * SEQ_T * SEQ_O, c->stream));
         }
-        if (!rc) rc = dalloc(c, &S->stat, (size_t)SEQ_T * SEQ_O);
+        if (!rc) rc = dalloc(c, &S->stat, (size_t)SEQ_TM * SEQ_O);
         const size_t cbd = ((size_t)D + 15) / 16;
-        if (!rc) rc = dalloc(c, &S->pk3, (size_t)SEQ_O * 3 * cbd * 512);
-        if (!rc) rc = dalloc(c, &S->pk5, (size_t)SEQ_O * 5 * cbd * 512);
-        if (!rc) rc = dalloc(c, &S->pk1, (size_t)SEQ_O * cbd * 512);
+        if (!rc) rc = dalloc(c, &S->pk3, (size_t)2 * SEQ_O * 3 * cbd * 512);
+        if (!rc) rc = dalloc(c, &S->pk5, (size_t)2 * SEQ_O * 5 * cbd * 512);
+        if (!rc) rc = dalloc(c, &S->pk1, (size_t)2 * SEQ_O * cbd * 512);
     }
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1165,6 +1197,7 @@ int rwkv_create(rwkv_ctx **out, int device)
     { const char *e = getenv("RWKV_RING"); if (e) c->ring = atoi(e); }
     { const char *e = getenv("RWKV_CARRY"); if (e) c->carry_kib = atoi(e); }
     { const char *e = getenv("RWKV_SEQ_PIPE"); if (e) c->seq_pipe = atoi(e); }
+    { const char *e = getenv("RWKV_SEQ_ROWS"); if (e) c->seq_rows = atoi(e) > SEQ_T ? SEQ_TM : SEQ_T; }
     { const char *e = getenv("RWKV_CARRY_EDGES"); if (e) c->carry_edges = atoi(e); }
     {
         static std::atomic<unsigned> serial{0u};
@@ -1243,7 +1276,9 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
     HIPCHK(hipSetDevice(c->device));
     { const int rcp = begin_call(c); if (rcp) return rcp; }
     if (T >= 2 && c->seq_ok && c->l0 == 0 && c->l1 == c->L) {   // prompt chunks (GPT) / batched decode step of T streams (PARRALEL): weights read once per <= 32 rows
-        const uint64_t nchunks = (T + SEQ_T - 1) / SEQ_T;
+        // rows per weight pass: 64 (two halves sharing every weight fragment) for calls of more than 32 rows, else 32
+        const uint64_t CH = (T > (uint64_t)SEQ_T && c->seq_rows > SEQ_T) ? (uint64_t)SEQ_TM : (uint64_t)SEQ_T;
+        const uint64_t nchunks = (T + CH - 1) / CH;
         int rc = 0;
         if (nchunks >= 2 && (rc = split_setup(c)) == 0 && c->n_split >= 2) {
             // Software pipeline over the chunks: stage k = an equal share of the layers (the last one with the head) on its
@@ -1260,8 +1295,8 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
             HIPCHK(hipEventRecord(c->sp_end, c->stream));                 // the other stages start behind whatever the context's stream holds
             for (int k = 1; k < ns; k++) HIPCHK(hipStreamWaitEvent(c->sp_stream[k], c->sp_end, 0));
             uint64_t i = 0;
-            for (uint64_t t0 = 0; t0 < T && !rc; t0 += SEQ_T, i++) {
-                const int n = (int)(T - t0 < (uint64_t)SEQ_T ? T - t0 : (uint64_t)SEQ_T);
+            for (uint64_t t0 = 0; t0 < T && !rc; t0 += CH, i++) {
+                const int n = (int)(T - t0 < CH ? T - t0 : CH);
                 const int b = (int)(i % (uint64_t)ns);
                 for (int k = 0; k < ns && !rc; k++) {
                     hipStream_t st = c->sp_stream[k];
@@ -1279,8 +1314,8 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
             if (rc) return rc;
         } else {
             if (rc) return rc;
-            for (uint64_t t0 = 0; t0 < T; t0 += SEQ_T) {
-                const int n = (int)(T - t0 < (uint64_t)SEQ_T ? T - t0 : (uint64_t)SEQ_T);
+            for (uint64_t t0 = 0; t0 < T; t0 += CH) {
+                const int n = (int)(T - t0 < CH ? T - t0 : CH);
                 rc = enqueue_chunk(c, tokens + t0, n, t0, mode == RWKV_MODE_PARRALEL);
                 if (rc) return rc;
             }

@@ -39,7 +39,11 @@
 
 namespace rwkvk {
 
-constexpr int SEQ_T = 32;                 // rows per pass: two 16-row MFMA tiles
+constexpr int SEQ_T = 32;                 // rows per HALF of a pass: two 16-row MFMA tiles
+constexpr int SEQ_TM = 64;                // rows per weight pass (round 4): one or two halves.  A pass of 33..64 rows reads every weight
+                                          // byte ONCE for both halves: the GEMMs multiply each weight fragment against both halves' activation
+                                          // images (k_seq_gemm_p's NH), everything else sees a global row tg = 32 h + t and finds half h's
+                                          // images, records and partial values `*_h` elements behind half 0's
 constexpr int SEQ_O = 8;                  // octants of a row (element-wise workgroups per row) = K-slices = XCDs
 constexpr double SEQ_CU = 4227200.0;      // 128 * (1 + 256 + 65536) - 2^22: weight-row-sum coefficient
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -198,26 +202,29 @@ struct SeqResidArgs {
     const SeqPart *qpart_gate;   //         records of the ffn r input vector
     SeqStat *stat;               // [T][SEQ_O]
     int D, T;
+    size_t pk_h, pkg_h, part_h, partg_h;   // second half of a pass (rows 32..63): element offsets of its pk / pk_gate / qpart / qpart_gate
 };
 template <int MODE>
 __global__ __launch_bounds__(SEQ_ENT) void k_seq_resid(SeqResidArgs a)
 {
     __shared__ double red[SEQ_ENW * 4];
-    const int D = a.D, t = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;
+    const int D = a.D, tg = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;      // tg: row of the pass; t: row of its half
+    const int hh = tg / SEQ_T, t = tg % SEQ_T;
+    const float *pk = a.pk + hh * a.pk_h, *pkg = a.pk_gate + hh * a.pkg_h;
     int c0, c1;
     octant_range(D, o, c0, c1);
-    const float so = MODE != 0 ? seq_so(a.qpart, 0, t) : 0.f;
-    const float sog = MODE == 2 ? seq_so(a.qpart_gate, 0, t) : 0.f;
+    const float so = MODE != 0 ? seq_so(a.qpart + hh * a.part_h, 0, t) : 0.f;
+    const float sog = MODE == 2 ? seq_so(a.qpart_gate + hh * a.partg_h, 0, t) : 0.f;
     double s[2] = {0.0, 0.0};
     for (int j = c0 + threadIdx.x; j < c1; j += SEQ_ENT) {
-        const size_t e = (size_t)t * D + j;
+        const size_t e = (size_t)tg * D + j;
         double x = a.x[e];
         if (MODE != 0) {
             const int CB = (D + 15) >> 4;
-            const float v = seq_val(a.pk, CB, j >> 4, t, j & 15, so);
+            const float v = seq_val(pk, CB, j >> 4, t, j & 15, so);
             if (MODE == 1) x = (double)((float)x + v);
             else {
-                const float r = seq_val(a.pk_gate, 5 * CB, 4 * CB + (j >> 4), t, j & 15, sog);
+                const float r = seq_val(pkg, 5 * CB, 4 * CB + (j >> 4), t, j & 15, sog);
                 const float gt = (float)(1.0 / (1.0 + exp(-(double)r)));
                 x = x + (double)(v * gt);
             }
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_resid(SeqResidArgs a)
     if (threadIdx.x == 0) {
         SeqStat r;
         r.sx = s[0]; r.sxx = s[1];
-        a.stat[t * SEQ_O + o] = r;
+        a.stat[tg * SEQ_O + o] = r;
     }
 }
 
@@ -249,6 +256,7 @@ struct SeqSiteArgs {
     unsigned *img[3];            // A-operand images
     SeqPart *part;               // [NV][T][SEQ_O]
     int D, T;
+    size_t img_h, part_h;        // second half of a pass: offsets of its images (in 32-bit words) and records
 };
 // mean, rstd of row t from its octant partials (every thread computes them: 8 tiny loads)
 __device__ __forceinline__ void seq_row_stats(const SeqStat *stat, int t, int D, double &mean, double &rstd)
@@ -268,7 +276,8 @@ template <int NV>
 __global__ __launch_bounds__(SEQ_ENT) void k_seq_site(SeqSiteArgs a)
 {
     __shared__ double red[SEQ_ENW * 4];
-    const int D = a.D, t = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;
+    const int D = a.D, t = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;      // t: row of the pass (0 .. 63)
+    const int hh = t / SEQ_T, th = t % SEQ_T;                                 // its half and the row inside the half (images, records)
     int c0, c1;
     octant_range(D, o, c0, c1);
     const bool shift = a.mix[0] != nullptr;
@@ -318,8 +327,8 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_site(SeqSiteArgs a)
 #pragma unroll
     for (int m = 0; m < NV; m++) {
         unsigned ls[3] = {0u, 0u, 0u};
-        if (live) seq_store_quad(a.img[m], qd, t, v[m], inv_scale(amax[m]), ls);
-        seq_finish(ls, So[m], c1 - c0, amax[m], a.part + ((size_t)m * SEQ_T + t) * SEQ_O + o, red);
+        if (live) seq_store_quad(a.img[m] + hh * a.img_h, qd, th, v[m], inv_scale(amax[m]), ls);
+        seq_finish(ls, So[m], c1 - c0, amax[m], a.part + hh * a.part_h + ((size_t)m * SEQ_T + th) * SEQ_O + o, red);
     }
 }
 
@@ -332,6 +341,7 @@ struct SeqStageArgs {
     unsigned *img;
     SeqPart *part;               // [T][SEQ_O]
     int K, T;
+    size_t pk_h, partk_h, img_h, part_h;     // second half of a pass: offsets of its pk / qpart_k / image (32-bit words) / records
 };
 constexpr int SEQ_SQ = 3;        // quads per thread of a stage workgroup: K / 32 <= 3 * SEQ_ENT
 // (row, octant) workgroups.  KIND 0: f = src (att_out input).  KIND 1: f = relu(k)^2 with k = ffn_k GEMM output
@@ -340,10 +350,12 @@ template <int KIND>
 __global__ __launch_bounds__(SEQ_ENT) void k_seq_stage(SeqStageArgs a)
 {
     __shared__ double red[SEQ_ENW * 4];
-    const int K = a.K, t = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;
+    const int K = a.K, tg = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;
+    const int hh = tg / SEQ_T, t = tg % SEQ_T;
+    const float *pk = a.pk + hh * a.pk_h;
     int c0, c1;
     octant_range(K, o, c0, c1);
-    const float sok = KIND == 1 ? seq_so(a.qpart_k, 0, t) : 0.f;
+    const float sok = KIND == 1 ? seq_so(a.qpart_k + hh * a.partk_h, 0, t) : 0.f;
     const int q0 = c0 >> 2, q1 = c1 >> 2;
     float v[SEQ_SQ][4];
     double So = 0.0;
@@ -355,13 +367,13 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_stage(SeqStageArgs a)
         if (qd < q1) {
             float f[4];
             if (KIND == 0) {
-                const f32x4 sv = reinterpret_cast<const f32x4 *>(a.src + (size_t)t * K)[qd];
+                const f32x4 sv = reinterpret_cast<const f32x4 *>(a.src + (size_t)tg * K)[qd];
                 f[0] = sv[0]; f[1] = sv[1]; f[2] = sv[2]; f[3] = sv[3];
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int CB = ((K >> 2) + 15) >> 4;
-                    float k = seq_val(a.pk, 5 * CB, e * CB + (qd >> 4), t, qd & 15, sok);   // hidden units 4 qd .. 4 qd + 3 = classes 0..3 of channel qd
+                    float k = seq_val(pk, 5 * CB, e * CB + (qd >> 4), t, qd & 15, sok);   // hidden units 4 qd .. 4 qd + 3 = classes 0..3 of channel qd
                     k = k * (float)(k > 0.f);
                     f[e] = k * k;                                                          // relu(k)^2, rwkv.cu:189-190
                 }
@@ -381,9 +393,9 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_stage(SeqStageArgs a)
 #pragma unroll
     for (int i = 0; i < SEQ_SQ; i++) {
         const int qd = q0 + threadIdx.x + i * SEQ_ENT;
-        if (qd < q1) seq_store_quad(a.img, qd, t, v[i], inv_s, ls);
+        if (qd < q1) seq_store_quad(a.img + hh * a.img_h, qd, t, v[i], inv_s, ls);
     }
-    seq_finish(ls, So, c1 - c0, am[0], a.part + (size_t)t * SEQ_O + o, red);
+    seq_finish(ls, So, c1 - c0, am[0], a.part + hh * a.part_h + (size_t)t * SEQ_O + o, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -397,22 +409,26 @@ struct SeqWkvArgs {
     int par;                     // PARRALEL mode: row t uses state slot slot0 + t (no recurrence along the rows)
     size_t slot_stride;
     int slot0;
+    size_t pk_h, part_h;         // second half of a pass: offsets of its pk / records
 };
-constexpr int WKV_CH = 16;       // channels per workgroup (512 threads = 16 channels x 32 rows)
+constexpr int WKV_CH = 16;       // channels per workgroup (TCAP x 16 threads: 16 channels x the rows of the pass)
 // rwkv.cu:242-255 with the GPT-mode state slot 0.  The exponentials do not depend on the state, so
 // one thread per (row, channel) evaluates them; then one thread per channel runs the (linear) state
-// recurrence along the chunk and the outputs are finished in parallel.
-__global__ __launch_bounds__(SEQ_T * WKV_CH) void k_seq_wkv(SeqWkvArgs a)
+// recurrence along the chunk and the outputs are finished in parallel.  TCAP = 32 (one half) or 64 rows.
+template <int TCAP>
+__global__ __launch_bounds__(TCAP * WKV_CH) void k_seq_wkv(SeqWkvArgs a)
 {
-    __shared__ double e1s[SEQ_T][WKV_CH], eks[SEQ_T][WKV_CH], vs[SEQ_T][WKV_CH], sgs[SEQ_T][WKV_CH], aas[SEQ_T][WKV_CH];
-    const int ch = threadIdx.x & (WKV_CH - 1), t = threadIdx.x / WKV_CH;
+    __shared__ double e1s[TCAP][WKV_CH], eks[TCAP][WKV_CH], vs[TCAP][WKV_CH], sgs[TCAP][WKV_CH], aas[TCAP][WKV_CH];
+    const int ch = threadIdx.x & (WKV_CH - 1), t = threadIdx.x / WKV_CH;     // t: row of the pass
     const int i = blockIdx.x * WKV_CH + ch;
     const bool live = i < a.D && t < a.T;
     if (live) {
-        const int CB = (a.D + 15) >> 4;
-        const float k = seq_val(a.pk, 3 * CB, 0 * CB + (i >> 4), t, i & 15, seq_so(a.qpart, 0, t));
-        const float v = seq_val(a.pk, 3 * CB, 1 * CB + (i >> 4), t, i & 15, seq_so(a.qpart, 1, t));
-        const float r = seq_val(a.pk, 3 * CB, 2 * CB + (i >> 4), t, i & 15, seq_so(a.qpart, 2, t));
+        const int CB = (a.D + 15) >> 4, hh = t / SEQ_T, th = t % SEQ_T;
+        const float *pk = a.pk + hh * a.pk_h;
+        const SeqPart *qp = a.qpart + hh * a.part_h;
+        const float k = seq_val(pk, 3 * CB, 0 * CB + (i >> 4), th, i & 15, seq_so(qp, 0, th));
+        const float v = seq_val(pk, 3 * CB, 1 * CB + (i >> 4), th, i & 15, seq_so(qp, 1, th));
+        const float r = seq_val(pk, 3 * CB, 2 * CB + (i >> 4), th, i & 15, seq_so(qp, 2, th));
         e1s[t][ch] = exp(a.uw[i] + (double)k);
         eks[t][ch] = exp((double)k);
         vs[t][ch] = (double)v;
@@ -522,13 +538,15 @@ struct SeqGemmArgs {
     const double *cp_src;        // piggy-back copy (stream-ordered behind the site kernel that produced it): the chunk's
     double *cp_dst;              // last LayerNorm output -> recurrent state; cp_n == 0: none
     int cp_n;
+    size_t img_h, part_h, pk_h;  // second half of a pass (k_seq_gemm_p with NH = 2; k_seq_gemm_ks is launched per half): offsets of its images
+                                 // (16-byte units), records and partial values
     unsigned long long *tl;      // optional phase timeline (tl_stamp; tools/gemm_timeline.py): 0 entry, 1 requests issued, 2 activation image
                                  // staged, 3 first batch / chunk multiplied and emitted, 4 last weights multiplied, 5 end
 };
 constexpr int SEQ_NT = 512;      // GEMM workgroup: 8 waves, two per SIMD
 // dynamic LDS of the GEMM kernels
 constexpr size_t seq_gemm_smem(int ntw, int nkb, bool mts, int nvs) { return (size_t)((!mts && ntw * nkb <= 16) ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
-constexpr size_t seq_gemm_p_smem(int nkb, int nvs, bool multi) { return (size_t)(multi ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
+constexpr size_t seq_gemm_p_smem(int nkb, int nvs, bool multi, int nh = 1) { return (size_t)(multi ? 2 : 1) * nh * nvs * nkb * 384 * 16 + (size_t)nh * nvs * SEQ_T * 16; }
 constexpr int SEQ_TB = 5;        // weight tiles (16 rows each) per workgroup pass of k_seq_gemm_ks
 constexpr size_t SEQ_KS_SMEM = sizeof(float) * SEQ_O * SEQ_TB * 2 * 4 * 64 + sizeof(float) * SEQ_T;
 constexpr int SEQ_NW = SEQ_NT / 64;
@@ -785,19 +803,21 @@ template <int NTW, int PW, int B> struct WaitBlocks {
 template <int NTW, int PW> struct WaitBlocks<NTW, PW, 0> {
     static __device__ __forceinline__ void run(int, bool dma) { if (dma) wait_vm<PW>(); else wait_vm<0>(); }
 };
-template <int TAG, int NTW, int NKB, int NVS, int DEPTH, bool MULTI>
+// NH = 2 (round 4): the pass has two halves of up to 32 rows; every weight fragment is multiplied against BOTH halves' activation
+// images (LDS: [half][vector][k][row tile][limb][lane]; twice the accumulators), i.e. the weights are read once per 64 rows.
+template <int TAG, int NTW, int NKB, int NVS, int DEPTH, bool MULTI, int NH = 1>
 __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    carry_kill_stamps(smem, (unsigned)seq_gemm_p_smem(NKB, NVS, MULTI));
+    carry_kill_stamps(smem, (unsigned)seq_gemm_p_smem(NKB, NVS, MULTI, NH));
     __syncthreads();      // (in front of this kernel's own copies into the same places)
     static_assert(NKB % DEPTH == 0, "the rolling buffer's slot of a k-block must be a compile-time value");
     constexpr int NBUF = MULTI ? 2 : 1;
-    constexpr int CHU = NVS * NKB * 384;                // units of one LDS buffer: [vector][k][row tile][limb][lane]
-    constexpr int PW = (NVS * NKB * 6 + SEQ_NW - 1) / SEQ_NW;      // DMA pieces (1 KiB) per wave and chunk; the last round is padded with duplicates
+    constexpr int CHU = NH * NVS * NKB * 384;           // units of one LDS buffer: [half][vector][k][row tile][limb][lane]
+    constexpr int PW = (NH * NVS * NKB * 6 + SEQ_NW - 1) / SEQ_NW;      // DMA pieces (1 KiB) per wave and chunk; the last round is padded with duplicates
     static_assert(PW + DEPTH * NTW + 2 + NTW <= 63, "k_seq_gemm_p: more than 63 vector memory operations in flight");
     u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
-    double *recl = reinterpret_cast<double *>(smem + (size_t)NBUF * CHU * 16);   // [NVS][SEQ_T]{scale, cA} of this slice
+    double *recl = reinterpret_cast<double *>(smem + (size_t)NBUF * CHU * 16);   // [NH][NVS][SEQ_T]{scale, cA} of this slice
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     tl_stamp(a.tl, 0);
     const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
@@ -813,9 +833,9 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
     const int vlo = a.vec_of_q[min(wg0, ntiles - 1) / CB], vhi = a.vec_of_q[max(wg1, 0) / CB];
     SeqPart rc;
     {
-        const int tr = threadIdx.x < NVS * SEQ_T ? (int)threadIdx.x : 0;
-        const int v = min(vlo + tr / SEQ_T, vhi), t = tr % SEQ_T;
-        rc = a.part[((size_t)v * SEQ_T + t) * SEQ_O + j];
+        const int tr = threadIdx.x < NH * NVS * SEQ_T ? (int)threadIdx.x : 0;
+        const int hh = tr / (NVS * SEQ_T), v = min(vlo + (tr / SEQ_T) % NVS, vhi), t = tr % SEQ_T;
+        rc = a.part[hh * a.part_h + ((size_t)v * SEQ_T + t) * SEQ_O + j];
     }
     const u32x4 *wt[NTW];
     int vi[NTW];
@@ -844,10 +864,11 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
     const unsigned abuf_lds = lds_addr(abuf);
     const int nvec = min(vhi - vlo + 1, NVS);
     auto piece = [&](int p, int kbs, int np, int buf) {
-        int v = p / (NKB * 6), pc = p % (NKB * 6);
-        if (v >= nvec || pc >= np) { v = 0; pc = 0; }
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(a.img[vlo + v] + (size_t)kbs * 384) + lane * 16 + (size_t)pc * 1024;
-        const unsigned dst = abuf_lds + (unsigned)(((size_t)buf * CHU + (size_t)v * NKB * 384) * 16) + (unsigned)pc * 1024u;
+        int hv = p / (NKB * 6), pc = p % (NKB * 6);
+        int hh = hv / NVS, v = hv % NVS;
+        if (hh >= NH || v >= nvec || pc >= np) { hh = 0; v = 0; pc = 0; }
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(a.img[vlo + v] + hh * a.img_h + (size_t)kbs * 384) + lane * 16 + (size_t)pc * 1024;
+        const unsigned dst = abuf_lds + (unsigned)(((size_t)buf * CHU + (size_t)(hh * NVS + v) * NKB * 384) * 16) + (unsigned)pc * 1024u;
         dma_piece_shared(np > 0 ? src : reinterpret_cast<const uint8_t *>(a.img[vlo]) + lane * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
     };
     auto stage_a = [&](int c, int buf) {
@@ -857,8 +878,9 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
 #pragma unroll
             for (int r = 0; r < PW; r++) piece(wave + r * SEQ_NW, kbs, np, buf);
         } else {
-            for (int v = 0; v < nvec; v++)
-                for (int pc = wave; pc < np; pc += SEQ_NW) piece(v * NKB * 6 + pc, kbs, np, buf);
+            for (int hv = 0; hv < NH * NVS; hv++)
+                if (hv % NVS < nvec)
+                    for (int pc = wave; pc < np; pc += SEQ_NW) piece(hv * NKB * 6 + pc, kbs, np, buf);
         }
     };
     u32x4 bwr[DEPTH][NTW];
@@ -871,13 +893,15 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
             for (int i = 0; i < NTW; i++) bwr[slot][i] = load_b_asm(wt[i] + (size_t)kb * 64);
         }
     };
-    i32x4 acc[NTW][2][3];
+    i32x4 acc[NH][NTW][2][3];
 #pragma unroll
-    for (int i = 0; i < NTW; i++)
+    for (int hh = 0; hh < NH; hh++)
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++)
+        for (int i = 0; i < NTW; i++)
 #pragma unroll
-            for (int b = 0; b < 3; b++) acc[i][mt][b] = i32x4{0, 0, 0, 0};
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) acc[hh][i][mt][b] = i32x4{0, 0, 0, 0};
 
     stage_a(0, 0);
 #pragma unroll
@@ -910,28 +934,31 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
 #pragma unroll
             for (int i = 0; i < NTW; i++) asm volatile("" : "+v"(bwr[k % DEPTH][i]));
             __builtin_amdgcn_sched_barrier(0);
-            u32x4 av[2][3];
-            auto read_a = [&](int vv) {
 #pragma unroll
-                for (int ms = 0; ms < 2; ms++)
+            for (int hh = 0; hh < NH; hh++) {
+                u32x4 av[2][3];
+                auto read_a = [&](int vv) {
 #pragma unroll
-                    for (int b = 0; b < 3; b++) av[ms][b] = ab[(((size_t)vv * NKB + k) * 2 + ms) * 3 * 64 + b * 64];
-            };
-            read_a(vi[0]);
+                    for (int ms = 0; ms < 2; ms++)
 #pragma unroll
-            for (int i = 0; i < NTW; i++) {
-                if (NVS > 1 && i > 0 && vi[i] != vi[i - 1]) read_a(vi[i]);
-                const u32x4 w = bwr[k % DEPTH][i];
-                const i32x4 bf = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+                        for (int b = 0; b < 3; b++) av[ms][b] = ab[((((size_t)hh * NVS + vv) * NKB + k) * 2 + ms) * 3 * 64 + b * 64];
+                };
+                read_a(vi[0]);
 #pragma unroll
-                for (int ms = 0; ms < 2; ms++)
+                for (int i = 0; i < NTW; i++) {
+                    if (NVS > 1 && i > 0 && vi[i] != vi[i - 1]) read_a(vi[i]);
+                    const u32x4 w = bwr[k % DEPTH][i];
+                    const i32x4 bf = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
 #pragma unroll
-                    for (int b = 0; b < 3; b++) {
-                        const i32x4 af = i32x4{(int)av[ms][b][0], (int)av[ms][b][1], (int)av[ms][b][2], (int)av[ms][b][3]};
-                        acc[i][ms][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[i][ms][b], 0, 0, 0);
-                    }
+                    for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+                        for (int b = 0; b < 3; b++) {
+                            const i32x4 af = i32x4{(int)av[ms][b][0], (int)av[ms][b][1], (int)av[ms][b][2], (int)av[ms][b][3]};
+                            acc[hh][i][ms][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[hh][i][ms][b], 0, 0, 0);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         if (c == 0) tl_stamp(a.tl, 3);
         if (more) {
@@ -945,22 +972,24 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
     tl_stamp(a.tl, 4);
     // (the record and the row sums are first TOUCHED here: hipcc's own wait for them -- it cannot see the asm requests behind them --
     // would otherwise drain the pipeline in front of the loop)
-    if (threadIdx.x < NVS * SEQ_T) { recl[2 * threadIdx.x] = scale_of(rc.amax); recl[2 * threadIdx.x + 1] = rc.cA; }
+    if (threadIdx.x < NH * NVS * SEQ_T) { recl[2 * threadIdx.x] = scale_of(rc.amax); recl[2 * threadIdx.x + 1] = rc.cA; }
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++)
+    for (int hh = 0; hh < NH; hh++)
 #pragma unroll
-        for (int i = 0; i < NTW; i++) {
-            if (!tv[i]) continue;
-            const int id = id0 + i;
-            const double *rl = recl + 2 * ((size_t)vi[i] * SEQ_T + mt * 16 + 4 * (lane >> 4));
-            float *dst = a.pk + ((((size_t)j * ntiles + id) * 2 + mt) * 4) * 64 + lane;
+        for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double M = (double)acc[i][mt][0][r] + 256.0 * (double)acc[i][mt][1][r] + 65536.0 * (double)acc[i][mt][2][r];
-                dst[r * 64] = (float)(rl[2 * r] * (M + rl[2 * r + 1] + SEQ_CU * (double)rsv[i]));   // scale_o (M + cA_o + CU rowsum_o)
+            for (int i = 0; i < NTW; i++) {
+                if (!tv[i]) continue;
+                const int id = id0 + i;
+                const double *rl = recl + 2 * (((size_t)hh * NVS + vi[i]) * SEQ_T + mt * 16 + 4 * (lane >> 4));
+                float *dst = a.pk + hh * a.pk_h + ((((size_t)j * ntiles + id) * 2 + mt) * 4) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double M = (double)acc[hh][i][mt][0][r] + 256.0 * (double)acc[hh][i][mt][1][r] + 65536.0 * (double)acc[hh][i][mt][2][r];
+                    dst[r * 64] = (float)(rl[2 * r] * (M + rl[2 * r + 1] + SEQ_CU * (double)rsv[i]));   // scale_o (M + cA_o + CU rowsum_o)
+                }
             }
-        }
     tl_stamp(a.tl, 5);
 }
 

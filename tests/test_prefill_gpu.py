@@ -218,3 +218,35 @@ def test_pipelined_gemm_is_bit_identical_to_the_up_front_gemm(eng_mod, L, D, T, 
         assert np.array_equal(outs["0"][0], outs[pipe][0]), pipe
         for a, b in zip(outs["0"][1], outs[pipe][1]):
             assert np.array_equal(a, b), pipe
+
+
+@pytest.mark.parametrize("mode,T,L,D", [("gpt", 150, 3, 768), ("gpt", 64, 2, 2048), ("gpt", 47, 2, 1024), ("par", 96, 3, 768), ("par", 70, 2, 2560)])
+def test_64_row_passes_are_bit_identical_to_32_row_chunks(eng_mod, oracle, mode, T, L, D, monkeypatch):
+    """Round 4: a forward call of more than 32 rows runs in passes of up to 64 rows = TWO halves that share every weight fragment
+    (seq.hip.h SEQ_TM; k_seq_gemm_p with NH = 2, the element-wise kernels on a global row index, k_seq_wkv over 64 rows) -- weights
+    read once per 64 rows.  It is a re-scheduling of the same arithmetic: every logits row and the whole recurrent state must be
+    bit-identical to the 32-row schedule (RWKV_SEQ_ROWS=32), for full and ragged passes (150 = 64 + 64 + 22, 47 = 32 + 15), in both
+    modes, at 1 KiB-multiple and other row sizes; and they must be the ORACLE's within tolerance."""
+    t = mf.synthetic_tensors(L, D, seed=640 + T)
+    toks = _toks(T, 5 * T)
+    md = eng_mod.MODE_GPT if mode == "gpt" else eng_mod.MODE_PARRALEL
+    outs = {}
+    for rows in ("32", "64"):
+        monkeypatch.setenv("RWKV_SEQ_ROWS", rows)
+        m = eng_mod.RWKV(resident=True)
+        m.loadTensors(L, D, t, maxGPT=T)
+        lg = m.forward(toks, md)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+        lg2 = m.forward(toks, md)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+        m.pull_state(T if mode == "par" else 1)
+        outs[rows] = (lg, lg2, [a.copy() for a in m.state.arrays()])
+        m.close()
+    assert np.array_equal(outs["32"][0], outs["64"][0])
+    assert np.array_equal(outs["32"][1], outs["64"][1])
+    for a, b in zip(outs["32"][2], outs["64"][2]):
+        assert np.array_equal(a, b)
+    om = oracle.from_tensors(L, D, t)
+    st = om.new_state(slots=T if mode == "par" else 1)
+    ref = om.forward(toks, st, mode=0 if mode == "par" else 1)
+    for i in sorted({0, 31, 32, 33, 46, 63, T - 1} & set(range(T))):
+        parity.check_logits(outs["64"][0][i], ref[i], f"{mode} row {i}")
+    om.close()

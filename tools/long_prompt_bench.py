@@ -1,4 +1,4 @@
-"""one rwkv_forward call on a long prompt (32-row chunks as a software pipeline over RWKV_SEQ_STAGES streams) and a 96-stream batched
+"""one rwkv_forward call on a long prompt (passes of RWKV_SEQ_ROWS = 64 or 32 rows as a software pipeline over RWKV_SEQ_STAGES streams) and a 96-stream batched
 step: python tools/long_prompt_bench.py [model] [tokens]"""
 import os
 import sys
