@@ -71,10 +71,32 @@ __device__ __forceinline__ float seq_so(const SeqPart *part, int m, int t)
 // Per-slice partial values of a GEMM live in the ACCUMULATOR IMAGE of the MFMA tiles, pk[slice][tile id][row tile][reg][lane]
 // (so a wave stores a register with one coalesced 256-byte store): element (chunk row t, channel ch of class q) sits in
 // tile id = q * CB + ch / 16 at lane 16 * ((t % 16) / 4) + ch % 16, register t % 4, row tile t / 16.
+// (-DRWKV_PK_ROWMAJOR=1, round 4: pk[slice][row][tile id][16 channels] instead -- a register row of the image holds FOUR chunk rows,
+// so a (row, octant) element-wise workgroup uses a quarter of every 256-byte line it touches, and row-major it reads contiguously.
+// Measured and not adopted: k_seq_stage<1> 8.7 -> 8.1 us, but k_seq_wkv<64> -- 16 channels x all rows per workgroup, whole lines of
+// the image -- 8.3 -> 12.3 us and the GEMMs' scattered 64-byte stores +0.3-1 us each: 32-token chunk 3.39 -> 3.49 ms, 512-token prompt
+// 16.7 -> 16.4 k tokens/s on one box, profiles/r04/pk_rowmajor_ab.txt.)
+#ifndef RWKV_PK_ROWMAJOR
+#define RWKV_PK_ROWMAJOR 0
+#endif
 __device__ __forceinline__ size_t pk_index(int ntiles, int slice, int id, int t, int c16)
 {
+#if RWKV_PK_ROWMAJOR
+    return ((((size_t)slice * SEQ_T + t) * ntiles + id) << 4) + c16;
+#else
     return ((((size_t)slice * ntiles + id) * 2 + (t >> 4)) * 4 + (t & 3)) * 64 + 16 * ((t & 15) >> 2) + c16;
+#endif
 }
+// where a wave's lane stores accumulator register r of (slice j, tile id, row tile mt): base pointer + r * pk_rstride(ntiles)
+__device__ __forceinline__ size_t pk_lane_base(int ntiles, int j, int id, int mt, int lane)
+{
+#if RWKV_PK_ROWMAJOR
+    return ((((size_t)j * SEQ_T + mt * 16 + 4 * (lane >> 4)) * ntiles + id) << 4) + (lane & 15);     // row t = 16 mt + 4 (lane / 16) + r
+#else
+    return ((((size_t)j * ntiles + id) * 2 + mt) * 4) * 64 + lane;
+#endif
+}
+__device__ __forceinline__ size_t pk_rstride(int ntiles) { return RWKV_PK_ROWMAJOR ? ((size_t)ntiles << 4) : (size_t)64; }
 // value of a GEMM output from its per-slice partials (each already scaled and corrected) and the offset term
 __device__ __forceinline__ float seq_val(const float *pk, int ntiles, int id, int t, int c16, float so)
 {
@@ -687,11 +709,12 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
             if (!tv[i]) continue;
             const int id = id0 + i;
             const double *rl = recl + 2 * ((size_t)vi[i] * SEQ_T + mt * 16 + 4 * (lane >> 4));
-            float *dst = a.pk + ((((size_t)j * ntiles + id) * 2 + mt) * 4) * 64 + lane;
+            float *dst = a.pk + pk_lane_base(ntiles, j, id, mt, lane);
+            const size_t rst = pk_rstride(ntiles);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const double M = (double)acc[i][ms][0][r] + 256.0 * (double)acc[i][ms][1][r] + 65536.0 * (double)acc[i][ms][2][r];
-                dst[r * 64] = (float)(rl[2 * r] * (M + rl[2 * r + 1] + SEQ_CU * (double)rsv[i]));   // scale_o (M + cA_o + CU rowsum_o); rows / columns past the end are never read
+                dst[r * rst] = (float)(rl[2 * r] * (M + rl[2 * r + 1] + SEQ_CU * (double)rsv[i]));   // scale_o (M + cA_o + CU rowsum_o); rows / columns past the end are never read
             }
         }
     };
@@ -983,11 +1006,12 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
                 if (!tv[i]) continue;
                 const int id = id0 + i;
                 const double *rl = recl + 2 * (((size_t)hh * NVS + vi[i]) * SEQ_T + mt * 16 + 4 * (lane >> 4));
-                float *dst = a.pk + hh * a.pk_h + ((((size_t)j * ntiles + id) * 2 + mt) * 4) * 64 + lane;
+                float *dst = a.pk + hh * a.pk_h + pk_lane_base(ntiles, j, id, mt, lane);
+                const size_t rst = pk_rstride(ntiles);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const double M = (double)acc[hh][i][mt][0][r] + 256.0 * (double)acc[hh][i][mt][1][r] + 65536.0 * (double)acc[hh][i][mt][2][r];
-                    dst[r * 64] = (float)(rl[2 * r] * (M + rl[2 * r + 1] + SEQ_CU * (double)rsv[i]));   // scale_o (M + cA_o + CU rowsum_o)
+                    dst[r * rst] = (float)(rl[2 * r] * (M + rl[2 * r + 1] + SEQ_CU * (double)rsv[i]));   // scale_o (M + cA_o + CU rowsum_o)
                 }
             }
     tl_stamp(a.tl, 5);

@@ -220,7 +220,7 @@ def test_pipelined_gemm_is_bit_identical_to_the_up_front_gemm(eng_mod, L, D, T, 
             assert np.array_equal(a, b), pipe
 
 
-@pytest.mark.parametrize("mode,T,L,D", [("gpt", 150, 3, 768), ("gpt", 64, 2, 2048), ("gpt", 47, 2, 1024), ("par", 96, 3, 768), ("par", 70, 2, 2560)])
+@pytest.mark.parametrize("mode,T,L,D", [("gpt", 150, 3, 768), ("gpt", 64, 2, 2048), ("gpt", 47, 2, 1024), ("par", 96, 3, 768), ("par", 70, 2, 2560), ("gpt", 70, 1, 5120), ("gpt", 96, 1, 4096)])
 def test_64_row_passes_are_bit_identical_to_32_row_chunks(eng_mod, oracle, mode, T, L, D, monkeypatch):
     """Round 4: a forward call of more than 32 rows runs in passes of up to 64 rows = TWO halves that share every weight fragment
     (seq.hip.h SEQ_TM; k_seq_gemm_p with NH = 2, the element-wise kernels on a global row index, k_seq_wkv over 64 rows) -- weights
