@@ -131,7 +131,7 @@ int rwkv_set_layer_range(rwkv_ctx *ctx, uint64_t l0, uint64_t l1);
 int rwkv_stage_forward(rwkv_ctx *ctx, uint64_t token, uint32_t slot, uint64_t *pick);
 double *rwkv_x_device(rwkv_ctx *ctx);
 
-/* One prompt chunk (n <= 32 consecutive tokens of one sequence, GPT mode) through THIS stage's layers on the mm8_seq /
+/* One prompt chunk (n <= 64 consecutive tokens of one sequence, GPT mode: one weight pass, two 32-row halves above 32) through THIS stage's layers on the mm8_seq /
  * MFMA path.  The chunk's residual stream [n][n_embed] f64 lives in buffer `buf` (0 or 1) of the context
  * (rwkv_xseq_device): stage 0 fills it from `tokens`, a later stage expects the previous stage's output there and leaves
  * its own in it; the last stage also writes the logits rows [row0, row0 + n).  Asynchronous (rwkv_sync to wait). */
@@ -157,7 +157,7 @@ int rwkv_sync(rwkv_ctx *ctx);
  *   rwkv_pipe_profile / rwkv_pipe_hop_stats   hop timing: event pairs around the per-tick RCCL group of the last
  *                        rwkv_pipe_decode* call; out4 = {ticks measured, mean, min, max microseconds} (min = the hop
  *                        itself, the peer's data was waiting; the mean includes waiting for the peer)
- *   rwkv_pipe_prefill    RWKV::loadContext (rwkv.h:395-413) across the stages: the prompt's 32-token chunks are the
+ *   rwkv_pipe_prefill    RWKV::loadContext (rwkv.h:395-413) across the stages: the prompt's 64-token passes (32 with max_ctx < 64 or RWKV_SEQ_ROWS=32) are the
  *                        micro-batches, stage s works on chunk t - s at tick t; needs max_ctx >= 32; tokens read on rank 0 */
 int rwkv_pipe_unique_id(void *out128);
 int rwkv_pipe_init(rwkv_ctx *ctx, const void *id128, int rank, int world);

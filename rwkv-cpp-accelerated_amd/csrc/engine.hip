@@ -1920,7 +1920,7 @@ int rwkv_stage_chunk(rwkv_ctx *c, const uint64_t *tokens, uint64_t n, uint64_t r
     if (!c) return fail(RWKV_E_ARG, "NULL ctx");
     if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
     if (!c->seq_ok) return fail(RWKV_E_STATE, "chunked path not available (load with max_ctx > 1)");
-    if (n == 0 || n > (uint64_t)SEQ_T || row0 + n > c->maxT || (buf != 0 && buf != 1)) return fail(RWKV_E_ARG, "bad chunk (n %llu, row0 %llu, buf %d)", (unsigned long long)n, (unsigned long long)row0, buf);
+    if (n == 0 || n > (uint64_t)SEQ_TM || row0 + n > c->maxT || (buf != 0 && buf != 1)) return fail(RWKV_E_ARG, "bad chunk (n %llu <= 64, row0 %llu, buf %d)", (unsigned long long)n, (unsigned long long)row0, buf);
     if (c->l0 == 0) {
         if (!tokens) return fail(RWKV_E_ARG, "stage 0 needs the token ids");
         for (uint64_t t = 0; t < n; t++) if (tokens[t] >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
@@ -1940,7 +1940,7 @@ int rwkv_sync(rwkv_ctx *c)
 // several stages per GPU); ordered behind src's work, and dst's later work is ordered behind the copy
 int rwkv_xseq_copy(rwkv_ctx *dst, int dbuf, rwkv_ctx *src, int sbuf, uint64_t rows)
 {
-    if (!dst || !src || !dst->seq_ok || !src->seq_ok || dst->D != src->D || rows > (uint64_t)SEQ_T) return fail(RWKV_E_ARG, "bad copy");
+    if (!dst || !src || !dst->seq_ok || !src->seq_ok || dst->D != src->D || rows > (uint64_t)SEQ_TM) return fail(RWKV_E_ARG, "bad copy");
     HIPCHK(hipSetDevice(src->device));
     // Stream-ordered, no host wait: dst's stream waits for what src's stream has enqueued so far (the chunk that filled the
     // buffer), copies, and src's stream waits for the copy before it may overwrite the buffer -- so two stages on one GPU run
@@ -1986,8 +1986,11 @@ int rwkv_pipe_prefill(rwkv_ctx *c, const uint64_t *tokens, uint64_t n_tokens)
             tokens = clean.data();
         }
     }
-    const uint64_t n_chunks = (n_tokens + SEQ_T - 1) / SEQ_T;
-    auto rows_of = [&](uint64_t ci) { return ci + 1 < n_chunks ? (uint64_t)SEQ_T : n_tokens - ci * SEQ_T; };
+    // micro-batch = one weight pass of the stage: 64 rows (two halves per weight fragment) where the context allows, else 32; every rank
+    // derives it from the same two values (RWKV_SEQ_ROWS, max_ctx), which the ranks of one pipeline share
+    const uint64_t CH = (c->seq_rows > SEQ_T && c->maxT >= (uint64_t)SEQ_TM) ? (uint64_t)SEQ_TM : (uint64_t)SEQ_T;
+    const uint64_t n_chunks = (n_tokens + CH - 1) / CH;
+    auto rows_of = [&](uint64_t ci) { return ci + 1 < n_chunks ? CH : n_tokens - ci * CH; };
     auto has_work = [&](int r, uint64_t t) { return t >= (uint64_t)r && t - r < n_chunks; };
     int rc = 0;
     for (uint64_t tick = 0; tick < n_chunks + S - 1 && !rc; tick++) {
@@ -2000,7 +2003,7 @@ int rwkv_pipe_prefill(rwkv_ctx *c, const uint64_t *tokens, uint64_t n_tokens)
             const int r2 = p->GroupEnd();
             if (r || r2) { rc = pipe_fail(p, r ? r : r2, "RCCL hop"); break; }
         }
-        if (work) rc = enqueue_chunk(c, rank == 0 ? tokens + ci * SEQ_T : nullptr, (int)rows_of(ci), 0, false, (int)(ci & 1));
+        if (work) rc = enqueue_chunk(c, rank == 0 ? tokens + ci * CH : nullptr, (int)rows_of(ci), 0, false, (int)(ci & 1));
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (!rc && e != hipSuccess) rc = fail(RWKV_E_DEVICE, "pipeline prefill: %s", hipGetErrorString(e));

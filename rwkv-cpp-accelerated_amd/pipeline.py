@@ -51,7 +51,7 @@ class EngineStage:
         self.torch = torch
         self.m = engine.RWKV(device=device, resident=True)
         self.m.set_layer_range(l0, l1)
-        self.m.loadTensors(n_layers, n_embed, tensors, maxGPT=max(n_slots, 32) if prefill else n_slots)
+        self.m.loadTensors(n_layers, n_embed, tensors, maxGPT=max(n_slots, 64) if prefill else n_slots)     # 64: micro-batches of one 64-row weight pass
         self.first, self.last = l0 == 0, l1 == n_layers
 
         class _X:   # alias the engine's residual buffer as a torch tensor (no copy)
