@@ -162,6 +162,8 @@ struct rwkv_ctx {
     uint64_t l0 = 0, l1 = UINT64_MAX;   // pipeline stage: this context owns layers [l0, l1) (whole model by default)
     int S = 0;               // ceil(D / 1024): 1 KiB row pieces per lane
     int seq_rows = SEQ_TM;   // chunk path: rows per weight pass, 64 (two halves, round 4) or 32 (env RWKV_SEQ_ROWS)
+    int seq_small = 8;       // chunk path, passes of <= 32 rows (default: ffn_v only, 3.36 -> 3.30 ms per 7B chunk; K/V/R loses, att_out and ffn k/r +-0: profiles/r04/seq_small_ab.txt): GEMM kinds whose activation image is staged per 2 (ffn_v: 4) k-blocks into alternating LDS
+                             // buffers instead of per slice, so that the first MFMA does not wait for the whole slice's image (env RWKV_SEQ_SMALL)
     int seq_pipe = 15;       // chunk path: GEMM kinds (bit 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v) that run as k_seq_gemm_p (env RWKV_SEQ_PIPE)
     int carry_kib = -1;      // ring kernels: KiB of the NEXT ring kernel's rows a workgroup's loader leaves in LDS (kernels.hip.h "CARRY"; env RWKV_CARRY, 0 = off;
                              // default: where it pays -- 32 at 4 KiB rows (7B: +1.3 %), 20 at 3 KiB rows (3B: +3.3 %; 32: -0.7 %) -- else 0 (14B: -2.2 %;
@@ -637,6 +639,7 @@ int seq_smem_limits()
     SEQ_ALLOW_P(1, 1, 8, 1, 8, false); SEQ_ALLOW_P(1, 1, 10, 1, 10, false);
     SEQ_ALLOW_P(2, 5, 8, 2, RWKV_SEQ_DEPTH2, false); SEQ_ALLOW_P(2, 4, 10, 2, 2, false);
     SEQ_ALLOW_P(3, 1, 8, 1, 8, true); SEQ_ALLOW_P(3, 1, 10, 1, 10, true);
+    SEQ_ALLOW_P(0, 3, 2, 3, 2, true); SEQ_ALLOW_P(1, 1, 2, 1, 2, true); SEQ_ALLOW_P(2, 5, 2, 2, 2, true); SEQ_ALLOW_P(2, 4, 2, 2, 2, true); SEQ_ALLOW_P(3, 1, 4, 1, 4, true);
 #undef SEQ_ALLOW_P
 #define SEQ_ALLOW_P2(TAG, NTW, NKB, NVS, DEPTH, MULTI) if (!rc) rc = allow_smem(k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI, 2>, seq_gemm_p_smem(NKB, NVS, MULTI, 2))
     SEQ_ALLOW_P2(0, 3, 2, 3, 2, true); SEQ_ALLOW_P2(1, 1, 8, 1, 8, false); SEQ_ALLOW_P2(1, 1, 10, 1, 10, false);
@@ -985,6 +988,13 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
             return;
         }
 #undef SEQ_LAUNCH_P2
+        if (c->seq_small & (1 << kind)) {
+            if (kind == 0) SEQ_LAUNCH_P(0, 3, 2, 3, 2, true);
+            else if (kind == 1) SEQ_LAUNCH_P(1, 1, 2, 1, 2, true);
+            else if (kind == 2) { if (big) SEQ_LAUNCH_P(2, 4, 2, 2, 2, true); else SEQ_LAUNCH_P(2, 5, 2, 2, 2, true); }
+            else SEQ_LAUNCH_P(3, 1, 4, 1, 4, true);
+            return;
+        }
         if (c->seq_pipe & (1 << kind)) {       // the GEMM as a software pipeline over k-blocks (seq.hip.h k_seq_gemm_p; RWKV_SEQ_PIPE bit per kind)
             if (kind == 0) { if (big) SEQ_LAUNCH_P(0, 3, 10, 2, 2, false); else SEQ_LAUNCH_P(0, 3, 8, 3, RWKV_SEQ_DEPTH0, false); }
             else if (kind == 1) { if (big) SEQ_LAUNCH_P(1, 1, 10, 1, 10, false); else SEQ_LAUNCH_P(1, 1, 8, 1, 8, false); }
@@ -1197,6 +1207,7 @@ int rwkv_create(rwkv_ctx **out, int device)
     { const char *e = getenv("RWKV_RING"); if (e) c->ring = atoi(e); }
     { const char *e = getenv("RWKV_CARRY"); if (e) c->carry_kib = atoi(e); }
     { const char *e = getenv("RWKV_SEQ_PIPE"); if (e) c->seq_pipe = atoi(e); }
+    { const char *e = getenv("RWKV_SEQ_SMALL"); if (e) c->seq_small = atoi(e); }
     { const char *e = getenv("RWKV_SEQ_ROWS"); if (e) c->seq_rows = atoi(e) > SEQ_T ? SEQ_TM : SEQ_T; }
     { const char *e = getenv("RWKV_CARRY_EDGES"); if (e) c->carry_edges = atoi(e); }
     {
