@@ -452,7 +452,7 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     parity = par_box[0]
     prefill = None
     if native and args.prefill_chunks > 0:
-        n_tok = 32 * max(args.prefill_chunks, 2 * world)
+        n_tok = 64 * max(args.prefill_chunks, 2 * world)
         prompt = [int(x) for x in rng.integers(2, mf.VOCAB, n_tok)]
         pipeline.run_prefill_native(stage, rank, prompt, n_tok)
         dist.barrier(); torch.cuda.synchronize()
@@ -462,7 +462,7 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
         tp = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         dist.all_reduce(tp, op=dist.ReduceOp.MAX)
         prefill = dict(prompt_tokens=n_tok, tokens_per_s=round(n_tok / float(tp.item()), 1),
-                       note="pipelined RWKV::loadContext: 32-token chunks as micro-batches, stage s on chunk t - s (rwkv_pipe_prefill)")
+                       note="pipelined RWKV::loadContext: 64-token passes (one weight pass per stage) as micro-batches, stage s on pass t - s (rwkv_pipe_prefill)")
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         import rwkv_cpp_accelerated_amd as pkg

@@ -34,7 +34,7 @@
 namespace {
 
 constexpr int SLOTS = 4;
-constexpr size_t SLOT_BYTES = 2u << 20;       // largest message: a 32-row chunk of the residual stream at D = 5120 (1.25 MiB)
+constexpr size_t SLOT_BYTES = 3u << 20;       // largest message: a 64-row pass of the residual stream at D = 5120 (2.5 MiB)
 constexpr int MAX_RANKS = 8;
 constexpr int WAIT_MS = 30000;
 
