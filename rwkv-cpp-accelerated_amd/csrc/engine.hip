@@ -164,6 +164,9 @@ struct rwkv_ctx {
     int seq_rows = SEQ_TM;   // chunk path: rows per weight pass, 64 (two halves, round 4) or 32 (env RWKV_SEQ_ROWS)
     int seq_small = 8;       // chunk path, passes of <= 32 rows (default: ffn_v only, 3.36 -> 3.30 ms per 7B chunk; K/V/R loses, att_out and ffn k/r +-0: profiles/r04/seq_small_ab.txt): GEMM kinds whose activation image is staged per 2 (ffn_v: 4) k-blocks into alternating LDS
                              // buffers instead of per slice, so that the first MFMA does not wait for the whole slice's image (env RWKV_SEQ_SMALL)
+    int seq_b = -1;          // 64-row passes: GEMM kinds (bit 0 K/V/R, bit 2 ffn k/r) that run as k_seq_gemm_b -- one vector's image of the whole slice resident,
+                             // a wave's tiles in batches, one round of workgroups (env RWKV_SEQ_B; 0: k_seq_gemm_p<.., true, 2>; -1: ffn k/r always, K/V/R at D >= 4096:
+                             // +1-2 % there, -1.5 % at D = 2048, profiles/r04/gemm_b_ab2.txt)
     int seq_pipe = 15;       // chunk path: GEMM kinds (bit 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v) that run as k_seq_gemm_p (env RWKV_SEQ_PIPE)
     int carry_kib = -1;      // ring kernels: KiB of the NEXT ring kernel's rows a workgroup's loader leaves in LDS (kernels.hip.h "CARRY"; env RWKV_CARRY, 0 = off;
                              // default: where it pays -- 32 at 4 KiB rows (7B: +1.3 %), 20 at 3 KiB rows (3B: +3.3 %; 32: -0.7 %) -- else 0 (14B: -2.2 %;
@@ -645,6 +648,8 @@ int seq_smem_limits()
     SEQ_ALLOW_P2(0, 3, 2, 3, 2, true); SEQ_ALLOW_P2(1, 1, 8, 1, 8, false); SEQ_ALLOW_P2(1, 1, 10, 1, 10, false);
     SEQ_ALLOW_P2(2, 3, 2, 2, 2, true); SEQ_ALLOW_P2(3, 1, 4, 1, 4, true);
 #undef SEQ_ALLOW_P2
+    if (!rc) rc = allow_smem(k_seq_gemm_b<0, 3, RWKV_SEQ_BDEPTH, 2>, seq_gemm_b_smem(SEQ_B_NKB_MAX, 2));
+    if (!rc) rc = allow_smem(k_seq_gemm_b<2, 3, RWKV_SEQ_BDEPTH, 2>, seq_gemm_b_smem(SEQ_B_NKB_MAX, 2));
     if (!rc) rc = allow_smem(k_seq_gemm_ks, SEQ_KS_SMEM);
     return rc;
 }
@@ -980,6 +985,57 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
         const dim3 grid(SEQ_O * RB), blk(SEQ_NT);
 #define SEQ_LAUNCH_P(TAG, NTW, NKB, NVS, DEPTH, MULTI) k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI><<<grid, blk, seq_gemm_p_smem(NKB, NVS, MULTI), st>>>(g)
 #define SEQ_LAUNCH_P2(TAG, NTW, NKB, NVS, DEPTH, MULTI) k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI, 2><<<grid, blk, seq_gemm_p_smem(NKB, NVS, MULTI, 2), st>>>(g)
+        if (two && (kind == 0 || kind == 2) && ((c->seq_b >= 0 ? c->seq_b : (4 | (D >= 4096 ? 1 : 0))) & (1 << kind))) {
+            // k_seq_gemm_b: one vector's image of the slice resident, a wave's tiles in batches of <= 3.  The 32 workgroups of a slice are
+            // shared out to the matrix's VECTOR GROUPS (runs of row classes on the same vector) so that no workgroup straddles one and the
+            // largest tile count of a wave is as small as it gets.  Its conditions: slices of DEPTH .. SEQ_B_NKB_MAX k-blocks (the
+            // resident image; row sums prefetched one batch ahead), at most three batches per wave, at most three groups
+            const int KB = K >> 6, nkb_min = KB / SEQ_O, nkb_max = (KB + SEQ_O - 1) / SEQ_O, CBt = (nch + 15) / 16;
+            SeqGemmBArgs b{};
+            int ngrp = 0, gq[4] = {0, 0, 0, 0};
+            for (int q = 0; q < Q && ngrp < 4; q++)
+                if (q == 0 || voq[q] != voq[q - 1]) gq[ngrp++] = q;
+            bool okb = ngrp <= 3 && nkb_min >= RWKV_SEQ_BDEPTH && nkb_max <= SEQ_B_NKB_MAX;
+            if (okb) {
+                int T[3] = {0, 0, 0}, best[3] = {0, 0, 0};
+                for (int i = 0; i < ngrp; i++) { b.grp_tile[i] = gq[i] * CBt; T[i] = ((i + 1 < ngrp ? gq[i + 1] : Q) - gq[i]) * CBt; }
+                b.grp_tile[ngrp] = ntiles;
+                const int WG = 32;                 // workgroups per slice: 8 slices x 32 = one per CU
+                double best_cost = 1e30;
+                for (int w0 = 1; w0 <= WG; w0++)
+                    for (int w1 = (ngrp > 1 ? 1 : 0); w0 + w1 <= WG; w1 += 1) {
+                        const int w2 = ngrp > 2 ? WG - w0 - w1 : 0;
+                        if (ngrp == 1 && (w1 || w0 != WG)) continue;
+                        if (ngrp == 2 && w0 + w1 != WG) continue;
+                        if (ngrp == 3 && w2 < 1) continue;
+                        const int w[3] = {w0, w1, w2};
+                        double cost = 0;
+                        for (int i = 0; i < ngrp; i++) {
+                            const int per_wave = (T[i] + SEQ_NW * w[i] - 1) / (SEQ_NW * w[i]);
+                            const double c2 = per_wave * 1000.0 + (double)T[i] / (SEQ_NW * w[i]);
+                            if (c2 > cost) cost = c2;
+                        }
+                        if (cost < best_cost) { best_cost = cost; for (int i = 0; i < 3; i++) best[i] = w[i]; }
+                        if (ngrp == 1) break;
+                    }
+                int rb0 = 0, per_wave_max = 0;
+                for (int i = 0; i < ngrp; i++) {
+                    b.grp_rb[i] = rb0; rb0 += best[i];
+                    const int pw = (T[i] + SEQ_NW * best[i] - 1) / (SEQ_NW * best[i]);
+                    if (pw > per_wave_max) per_wave_max = pw;
+                }
+                b.grp_rb[ngrp] = rb0; b.ngrp = ngrp;
+                okb = per_wave_max <= 9 && rb0 >= 1;
+                if (okb) {
+                    b.g = g; b.g.ntw = per_wave_max;
+                    const dim3 gridb(SEQ_O * rb0);
+                    const size_t smem = seq_gemm_b_smem(nkb_max, 2);
+                    if (kind == 0) k_seq_gemm_b<0, 3, RWKV_SEQ_BDEPTH, 2><<<gridb, blk, smem, st>>>(b);
+                    else k_seq_gemm_b<2, 3, RWKV_SEQ_BDEPTH, 2><<<gridb, blk, smem, st>>>(b);
+                    return;
+                }
+            }
+        }
         if (two) {      // both halves per weight fragment: short k-block groups re-staged into the other LDS buffer (the image of two halves is twice as large)
             if (kind == 0) SEQ_LAUNCH_P2(0, 3, 2, 3, 2, true);
             else if (kind == 1) { if (big) SEQ_LAUNCH_P2(1, 1, 10, 1, 10, false); else SEQ_LAUNCH_P2(1, 1, 8, 1, 8, false); }
@@ -1208,6 +1264,7 @@ int rwkv_create(rwkv_ctx **out, int device)
     { const char *e = getenv("RWKV_CARRY"); if (e) c->carry_kib = atoi(e); }
     { const char *e = getenv("RWKV_SEQ_PIPE"); if (e) c->seq_pipe = atoi(e); }
     { const char *e = getenv("RWKV_SEQ_SMALL"); if (e) c->seq_small = atoi(e); }
+    { const char *e = getenv("RWKV_SEQ_B"); if (e) c->seq_b = atoi(e); }
     { const char *e = getenv("RWKV_SEQ_ROWS"); if (e) c->seq_rows = atoi(e) > SEQ_T ? SEQ_TM : SEQ_T; }
     { const char *e = getenv("RWKV_CARRY_EDGES"); if (e) c->carry_edges = atoi(e); }
     {
@@ -1651,7 +1708,7 @@ int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, ui
 {
     if (!c || !out) return fail(RWKV_E_ARG, "NULL argument");
     if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
-    const size_t n = (size_t)c->grid * NW * 8;
+    const size_t n = (size_t)(c->grid > 512 ? c->grid : 512) * NW * 8;      // (a chunk GEMM may launch more workgroups than the decode grid)
     if (cap < n) return fail(RWKV_E_ARG, "need room for %zu stamps", n);
     HIPCHK(hipSetDevice(c->device));
     { const int rcp = begin_call(c); if (rcp) return rcp; }
@@ -1664,9 +1721,11 @@ int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, ui
     int rc;
     if (c->tl_cls >= 10) {          // a GEMM of the chunk path: one 32-row GPT chunk of this token
         if (!c->seq_ok) { c->tl_on = false; return fail(RWKV_E_STATE, "the chunk path is not loaded (max_ctx 1)"); }
-        uint64_t toks[SEQ_T];
-        for (int t = 0; t < SEQ_T; t++) toks[t] = token;
-        rc = enqueue_chunk(c, toks, SEQ_T, 0, false);
+        uint64_t toks[SEQ_TM];
+        for (int t = 0; t < SEQ_TM; t++) toks[t] = token;
+        int rows = SEQ_T;                // RWKV_TL_ROWS=64: a 64-row pass (the two-half GEMMs)
+        { const char *e = getenv("RWKV_TL_ROWS"); if (e && atoi(e) > SEQ_T && c->seq_rows > SEQ_T && c->maxT >= (uint64_t)SEQ_TM) rows = SEQ_TM; }
+        rc = enqueue_chunk(c, toks, rows, 0, false);
     } else rc = enqueue_token(c, false, nullptr);
     c->tl_on = false;
     if (rc) return rc;

@@ -1018,6 +1018,226 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// k_seq_gemm_b (round 4): a 64-row pass's GEMM with ONE vector's activation image of the whole slice resident in LDS, staged once per
+// workgroup, and a wave's row tiles multiplied in BATCHES of at most NTW (the accumulators of two halves).
+// k_seq_gemm_p<.., MULTI, 2> holds three tiles per wave at 64 rows: ffn k/r then needs 432 workgroups on 256 CUs -- two rounds, 33 us --
+// and re-stages the image per two k-blocks.  What a workgroup of these GEMMs takes is launch + the image's first touch (4.6 us during
+// which HBM idles), its weights at the CU's share of the stream (22.8 KB/us), an epilogue (2.3 us, idle again): one round of longer
+// workgroups beats two rounds (tools/gemm_timeline.py, profiles/r04/gemm_b_timeline.txt).
+//  * Workgroup ranges are aligned to the VECTOR GROUPS of the matrix (runs of row classes that multiply the same vector: k|r for ffn
+//    k/r) -- a first version with plain ranges ran the two workgroups per slice that straddle a group as one pass per vector, each as long
+//    as a whole workgroup's (a wave's stream goes at the loaded memory system's latency whoever else is idle): 26 us where the others took 16.
+//    The host gives every group its share of the 32 workgroups of a slice (grp_rb); within a group the tiles are spread evenly over the
+//    waves (5 or 6 each for ffn k/r at D = 4096).
+//  * The k-blocks of all batches are one stream through the rolling register buffer: the next batch's first blocks (and its row sums)
+//    are in flight under the epilogue of the previous one.  Requests per slot are counted at run time, the waits go through wait_vm_dyn.
+// Same arithmetic in the same order per output as k_seq_gemm_p: bit-identical partial values.
+__device__ __forceinline__ unsigned load_u32_asm(const unsigned *p)
+{
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int MAXN> __device__ __forceinline__ void wait_vm_dyn(int n)
+{
+    if constexpr (MAXN == 0) wait_vm<0>();
+    else { if (n >= MAXN) wait_vm<MAXN>(); else wait_vm_dyn<MAXN - 1>(n); }
+}
+#ifndef RWKV_SEQ_BDEPTH
+#define RWKV_SEQ_BDEPTH 3
+#endif
+constexpr int SEQ_B_NKB_MAX = 10;        // longest slice whose two-half image fits: 2 x 10 x 6 KiB = 120 KiB (D = 5120)
+constexpr size_t seq_gemm_b_smem(int nkbm, int nh) { return (size_t)nh * nkbm * 384 * 16 + (size_t)nh * SEQ_T * 16; }
+struct SeqGemmBArgs {
+    SeqGemmArgs g;
+    int grp_tile[4];             // first tile of vector group i (i < ngrp), ntiles behind the last
+    int grp_rb[4];               // first workgroup (per slice) of group i, the slice's workgroup count behind the last
+    int ngrp;
+};
+template <int TAG, int NTW, int DEPTH, int NH>
+__global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_b(SeqGemmBArgs ba)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert((DEPTH - 1) * 2 * NTW <= 40, "k_seq_gemm_b: the wait dispatch covers 40 requests");
+    const SeqGemmArgs &a = ba.g;
+    const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
+    const int nkbm = (KB + SEQ_O - 1) / SEQ_O;                    // longest slice
+    carry_kill_stamps(smem, (unsigned)seq_gemm_b_smem(nkbm, NH));
+    __syncthreads();      // (in front of this kernel's own copies into the same places)
+    u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
+    double *recl = reinterpret_cast<double *>(smem + (size_t)NH * nkbm * 384 * 16);   // [NH][SEQ_T]{scale, cA} of this slice
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    tl_stamp(a.tl, 0);
+    const int nch = (N + Q - 1) / Q, CB = (nch + 15) >> 4, ntiles = Q * CB;
+    const int j = blockIdx.x % SEQ_O, rb = blockIdx.x / SEQ_O;
+    const int kb0 = (int)(((long long)j * KB) / SEQ_O), kb1 = (int)(((long long)(j + 1) * KB) / SEQ_O);
+    const int nkb = kb1 - kb0;
+    if (blockIdx.x == gridDim.x - 1)
+        for (int q = threadIdx.x; q < a.cp_n; q += SEQ_NT) a.cp_dst[q] = a.cp_src[q];
+    // this workgroup's vector group, this wave's tiles id0 .. id0 + tpw - 1 of it
+    int gi = 0;
+    while (gi + 1 < ba.ngrp && rb >= ba.grp_rb[gi + 1]) gi++;
+    const int gt0 = ba.grp_tile[gi], gT = ba.grp_tile[gi + 1] - gt0;
+    const int gw = (ba.grp_rb[gi + 1] - ba.grp_rb[gi]) * SEQ_NW, widx = (rb - ba.grp_rb[gi]) * SEQ_NW + wave;
+    const int id0 = gt0 + (int)(((long long)widx * gT) / gw), tpw = gt0 + (int)(((long long)(widx + 1) * gT) / gw) - id0;
+    const int v = a.vec_of_q[min(gt0, ntiles - 1) / CB];
+    const int nb = (tpw + NTW - 1) / NTW, bs = nb ? (tpw + nb - 1) / nb : 0;     // batches (the host keeps them <= 3), tiles per batch (<= NTW)
+    SeqPart rc;
+    {
+        const int tr = threadIdx.x < NH * SEQ_T ? (int)threadIdx.x : 0;
+        const int hh = tr / SEQ_T, t = tr % SEQ_T;
+        rc = a.part[hh * a.part_h + ((size_t)v * SEQ_T + t) * SEQ_O + j];
+    }
+    const unsigned abuf_lds = lds_addr(abuf);
+    const u32x4 *const wbase = a.bimg + lane;
+    auto batch_mask = [&](int b) {       // bit i <-> tile id0 + b * bs + i
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < NTW; i++)
+            if (i < bs && b * bs + i < tpw) m |= 1 << i;
+        return m;
+    };
+    u32x4 bwr[DEPTH][NTW];
+    unsigned rsn[NTW], rsv[NTW];          // row sums (this octant) of the rows this lane finishes: of the batch being requested / multiplied
+    int cnt[DEPTH];                       // requests issued into slot s (weights + row sums): what is "newer" than a slot's block
+    i32x4 acc[NH][NTW][2][3];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int hh = 0; hh < NH; hh++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++)
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) acc[hh][i][mt][b] = i32x4{0, 0, 0, 0};
+    };
+    // the slice's image of vector v, both halves: 1 KiB pieces round-robin over the waves
+    {
+        const int np = nkb * 6;
+        for (int hh = 0; hh < NH; hh++)
+            for (int pc = wave; pc < np; pc += SEQ_NW) {
+                const uint8_t *src = reinterpret_cast<const uint8_t *>(a.img[v] + hh * a.img_h + (size_t)kb0 * 384) + lane * 16 + (size_t)pc * 1024;
+                const unsigned dst = abuf_lds + (unsigned)(hh * nkbm * 384 * 16) + (unsigned)pc * 1024u;
+                dma_piece_shared(src, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+            }
+    }
+    // this wave's stream of (batch, k-block) steps
+    const int total = nb * nkb;
+    int lb = 0, lf = 0;                                           // request cursor: batch, k-block
+    auto request = [&](int slot) {                                // the next step's weights (and, at a batch's first block, its row sums) into `slot`
+        int n = 0;
+        if (lb < nb) {
+            const int m = batch_mask(lb);
+            if (lf == 0) {
+#pragma unroll
+                for (int i = 0; i < NTW; i++)
+                    if (m >> i & 1) {
+                        const int id = id0 + lb * bs + i;
+                        const int q = id / CB, ch = 16 * (id % CB) + (lane & 15), row = Q * ch + q;
+                        rsn[i] = load_u32_asm(a.rs8 + (size_t)j * N + ((ch < nch && row < N) ? row : 0));
+                        n++;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; i++)
+                if (m >> i & 1) {
+                    const int id = id0 + lb * bs + i;
+                    bwr[slot][i] = load_b_asm(wbase + ((size_t)id * KB + (kb0 + lf)) * 64);
+                    n++;
+                }
+            if (++lf == nkb) { lf = 0; lb++; }
+        }
+        return n;
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH; s++) cnt[s] = 0;
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; s++) cnt[s] = request(s);
+    tl_stamp(a.tl, 1);
+    {   // this wave's share of the image is older than its weights
+        int newer = 0;
+#pragma unroll
+        for (int s = 0; s < DEPTH - 1; s++) newer += cnt[s];
+        wait_vm_dyn<(DEPTH - 1) * 2 * NTW>(newer);
+    }
+    if (threadIdx.x < NH * SEQ_T) { recl[2 * threadIdx.x] = scale_of(rc.amax); recl[2 * threadIdx.x + 1] = rc.cA; }
+    __syncthreads();
+    tl_stamp(a.tl, 2);
+    zero_acc();
+    int cb = 0, cf = 0;                                           // compute cursor: batch, k-block
+    for (int g0 = 0; g0 < total; g0 += DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; s++) {
+            if (g0 + s >= total) break;                           // (wave-uniform)
+            cnt[(s + DEPTH - 1) % DEPTH] = request((s + DEPTH - 1) % DEPTH);
+            {
+                int newer = 0;
+#pragma unroll
+                for (int t = 0; t < DEPTH; t++) if (t != s) newer += cnt[t];
+                wait_vm_dyn<(DEPTH - 1) * 2 * NTW>(newer);
+            }
+            // load_b_asm / load_u32_asm hand out their destinations before the data is there: the registers CHANGE here
+#pragma unroll
+            for (int i = 0; i < NTW; i++) asm volatile("" : "+v"(bwr[s][i]));
+            const int m = batch_mask(cb);
+            if (cf == 0) {
+#pragma unroll
+                for (int i = 0; i < NTW; i++) { asm volatile("" : "+v"(rsn[i])); rsv[i] = rsn[i]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 *ab = abuf + lane + (size_t)cf * 384;
+#pragma unroll
+            for (int hh = 0; hh < NH; hh++) {
+                u32x4 av[2][3];
+#pragma unroll
+                for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) av[ms][b] = ab[(size_t)hh * nkbm * 384 + (ms * 3 + b) * 64];
+#pragma unroll
+                for (int i = 0; i < NTW; i++) {
+                    if (!(m >> i & 1)) continue;
+                    const u32x4 w = bwr[s][i];
+                    const i32x4 bf = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+#pragma unroll
+                    for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+                        for (int b = 0; b < 3; b++) {
+                            const i32x4 af = i32x4{(int)av[ms][b][0], (int)av[ms][b][1], (int)av[ms][b][2], (int)av[ms][b][3]};
+                            acc[hh][i][ms][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[hh][i][ms][b], 0, 0, 0);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (++cf == nkb) {                                    // the batch's last block: its partial values out (the next batch's blocks are in flight)
+                if (cb == 0) tl_stamp(a.tl, 6);
+#pragma unroll
+                for (int hh = 0; hh < NH; hh++)
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                        for (int i = 0; i < NTW; i++) {
+                            if (!(m >> i & 1)) continue;
+                            const int id = id0 + cb * bs + i;
+                            const double *rl = recl + 2 * ((size_t)hh * SEQ_T + mt * 16 + 4 * (lane >> 4));
+                            float *dst = a.pk + hh * a.pk_h + pk_lane_base(ntiles, j, id, mt, lane);
+                            const size_t rst = pk_rstride(ntiles);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const double M = (double)acc[hh][i][mt][0][r] + 256.0 * (double)acc[hh][i][mt][1][r] + 65536.0 * (double)acc[hh][i][mt][2][r];
+                                dst[r * rst] = (float)(rl[2 * r] * (M + rl[2 * r + 1] + SEQ_CU * (double)rsv[i]));   // scale_o (M + cA_o + CU rowsum_o)
+                            }
+                        }
+                zero_acc();
+                cf = 0; cb++;
+                if (cb == 1) tl_stamp(a.tl, 3);
+            }
+        }
+    }
+    tl_stamp(a.tl, 4);
+    tl_stamp(a.tl, 5);
+}
+
+// ------------------------------------------------------------------------------------------
 // operands of one k-block: B fragments of NTL tiles and the A fragments of the pass's vector
 template <int NTL> struct SeqFrag { u32x4 bw[NTL]; u32x4 af[2][3]; };
 template <int NTL>

@@ -250,3 +250,28 @@ def test_64_row_passes_are_bit_identical_to_32_row_chunks(eng_mod, oracle, mode,
     for i in sorted({0, 31, 32, 33, 46, 63, T - 1} & set(range(T))):
         parity.check_logits(outs["64"][0][i], ref[i], f"{mode} row {i}")
     om.close()
+
+
+@pytest.mark.parametrize("T,L,D", [(70, 2, 2560), (96, 1, 4096)])
+def test_64_row_gemm_forms_agree(eng_mod, T, L, D, monkeypatch):
+    """The 64-row pass has two forms of its K/V/R and ffn k/r GEMMs: k_seq_gemm_p<.., true, 2> (image re-staged per two k-blocks, plain
+    workgroup ranges; RWKV_SEQ_B=0) and k_seq_gemm_b (one vector's image resident, workgroup ranges aligned to the vector groups, a wave's
+    tiles in batches; RWKV_SEQ_B=5 forces both kinds, the default picks by width).  Same arithmetic per output: identical logits and state."""
+    t = mf.synthetic_tensors(L, D, seed=77 + T)
+    toks = _toks(T, 3 * T)
+    outs = {}
+    for b in ("0", "5", None):
+        if b is None:
+            monkeypatch.delenv("RWKV_SEQ_B", raising=False)
+        else:
+            monkeypatch.setenv("RWKV_SEQ_B", b)
+        m = eng_mod.RWKV(resident=True)
+        m.loadTensors(L, D, t, maxGPT=T)
+        lg = m.forward(toks, eng_mod.MODE_GPT)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+        m.pull_state(1)
+        outs[b] = (lg, [a.copy() for a in m.state.arrays()])
+        m.close()
+    for b in ("5", None):
+        assert np.array_equal(outs["0"][0], outs[b][0]), b
+        for x, y in zip(outs["0"][1], outs[b][1]):
+            assert np.array_equal(x, y), b

@@ -1,4 +1,4 @@
-"""phase timeline of one GEMM of the chunk path (k_seq_gemm; kind 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v): python tools/gemm_timeline.py [kind] [model]"""
+"""phase timeline of one GEMM of the chunk path (kind 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v): python tools/gemm_timeline.py [kind] [model] [rows 32|64]"""
 import os
 import sys
 
@@ -10,18 +10,20 @@ import numpy as np, torch                                                 # noqa
 from rwkv_cpp_accelerated_amd import engine, modelfile as mf              # noqa: E402
 
 model = sys.argv[2] if len(sys.argv) > 2 else "7B"
+rows = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+os.environ["RWKV_TL_ROWS"] = str(rows)
 L, D = mf.SHAPES[model]
 L = min(L, 8)
 m = engine.RWKV(resident=True)
-m.loadTensors(L, D, mf.synthetic_tensors_torch(L, D, seed=0), maxGPT=32)
-m.forward([5] * 32, engine.MODE_GPT)
-names = ["entry", "requests issued", "A image staged", "first batch done", "last weights multiplied", "end"]
+m.loadTensors(L, D, mf.synthetic_tensors_torch(L, D, seed=0), maxGPT=rows)
+m.forward([5] * rows, engine.MODE_GPT)
+names = ["entry", "requests issued", "A image staged", "first batch done", "last weights multiplied", "end", "first batch multiplied (k_seq_gemm_b)"]
 for rep in range(3):
-    buf = m.debug_timeline(9).reshape(-1, 8, 8)[:256].astype(np.int64)
+    buf = m.debug_timeline(9).reshape(-1, 8, 8)[:512].astype(np.int64)
     live = buf[:, :, 0] > 0
     t0 = buf[:, :, 0][live].min()
     us = (buf - t0) / 100.0
-    print(f"kind {kind} rep {rep}: workgroups {int(live.any(axis=1).sum())}, span {us[:, :, 5][buf[:, :, 5] > 0].max():.2f} us")
+    print(f"kind {kind} rows {rows} RWKV_SEQ_B={os.environ.get('RWKV_SEQ_B', 'default')} rep {rep}: workgroups {int(live.any(axis=1).sum())}, span {us[:, :, 5][buf[:, :, 5] > 0].max():.2f} us")
     for ph, nm in enumerate(names):
         v = us[:, :, ph][buf[:, :, ph] > 0]
         if v.size:
