@@ -1267,6 +1267,12 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
 #ifdef RWKV_RING_NODOT      // experiment (WRONG results): what the dot products and reductions cost
 #pragma unroll
         for (int r = 0; r < R; r++) T[r] = (unsigned long long)__builtin_amdgcn_readfirstlane((int)w[r][0][0]);
+#elif defined(RWKV_RING_TAILSKIP)   // experiment (WRONG results): an upper bound on what ANY shortening of the last groups' work could buy --
+        // the last RWKV_RING_TAILSKIP groups of the workgroup are taken but not multiplied
+        if (g >= g1 - RWKV_RING_TAILSKIP) {
+#pragma unroll
+            for (int r = 0; r < R; r++) T[r] = (unsigned long long)__builtin_amdgcn_readfirstlane((int)w[r][0][0]);
+        } else group_dot<R, S, PAT, false>(w, xq, lane, T, nullptr, 0, chunks, false);
 #else
         group_dot<R, S, PAT, false>(w, xq, lane, T, nullptr, 0, chunks, false);
 #endif
@@ -1274,7 +1280,9 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
         asm volatile("" : "+s"(T[R - 1]));
         if (rr < 1) tl_stamp(g_tl_groups, 4);
 #endif
-#ifndef RWKV_RING_NOEPI     // experiment (WRONG results): what the epilogues cost
+#if defined(RWKV_RING_TAILSKIP) && RWKV_RING_TAILSKIP_EPI
+        if (g < g1 - RWKV_RING_TAILSKIP) epi(g, T, in);
+#elif !defined(RWKV_RING_NOEPI)     // experiment (WRONG results): what the epilogues cost
         epi(g, T, in);
 #endif
 #ifdef RWKV_TL_GROUPS
