@@ -145,6 +145,10 @@ int rwkv_sync(rwkv_ctx *ctx);
  * (north_star: "layers optionally pipeline across the 8 GPUs of one node via RCCL send/recv over xGMI").  One process
  * per GPU; rank r's context holds layers [l0_r, l1_r) (rwkv_set_layer_range before loading), rank 0 the embedding, the
  * last rank the head.  librccl.so is resolved at run time by the first of these calls, so single-GPU users never load it.
+ *   rwkv_pipe_rccl_path  which RCCL these calls bind in this process (path of the shared object holding ncclSend; loads it if
+ *                        need be, no GPU involved).  Order: RWKV_RCCL_LIB if set; else the copy the process has ALREADY loaded (a
+ *                        PyTorch-ROCm host carries torch/lib/librccl.so, built against the HIP runtime torch brought along --
+ *                        the engine's streams live in that runtime too); else the system's librccl.so.1
  *   rwkv_pipe_unique_id  one rank makes the 128-byte communicator id (ncclGetUniqueId) and distributes it out of band
  *   rwkv_pipe_init       every rank joins (ncclCommInitRank); the rank must match the context's layer range
  *   rwkv_pipe_decode     greedy decode of `world` independent streams (one per stage in flight, state slot = stream),
@@ -159,6 +163,7 @@ int rwkv_sync(rwkv_ctx *ctx);
  *                        itself, the peer's data was waiting; the mean includes waiting for the peer)
  *   rwkv_pipe_prefill    RWKV::loadContext (rwkv.h:395-413) across the stages: the prompt's 64-token passes (32 with max_ctx < 64 or RWKV_SEQ_ROWS=32) are the
  *                        micro-batches, stage s works on chunk t - s at tick t; needs max_ctx >= 32; tokens read on rank 0 */
+int rwkv_pipe_rccl_path(char *out, uint64_t cap);
 int rwkv_pipe_unique_id(void *out128);
 int rwkv_pipe_init(rwkv_ctx *ctx, const void *id128, int rank, int world);
 int rwkv_pipe_decode(rwkv_ctx *ctx, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks);

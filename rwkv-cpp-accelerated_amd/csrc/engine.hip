@@ -1789,13 +1789,22 @@ int pipe_fail(Pipe *p, int rc, const char *what)
 int pipe_open(Pipe *p)
 {
     if (p->lib) return 0;
-    const char *names[] = {getenv("RWKV_RCCL_LIB"), "librccl.so.1", "librccl.so"};
-    for (const char *n : names) {
-        if (!n) continue;
-        p->lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (p->lib) break;
-    }
-    if (!p->lib) return fail(RWKV_E_DEVICE, "cannot load librccl.so (%s)", dlerror());
+    // Which RCCL: (1) RWKV_RCCL_LIB if set; (2) the copy the PROCESS HAS ALREADY LOADED -- a host that imported PyTorch-ROCm carries
+    // torch/lib/librccl.so, built against the HIP runtime torch brought along, and the engine's streams and buffers live in that same
+    // runtime: a second RCCL of another ROCm release beside it is a version mix nobody tests; (3) the system's, for a host without one.
+    const char *env = getenv("RWKV_RCCL_LIB");
+    if (env && env[0]) p->lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+    if (!p->lib && !(env && env[0]))
+        for (const char *n : {"librccl.so", "librccl.so.1"}) {
+            p->lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+            if (p->lib) break;
+        }
+    if (!p->lib && !(env && env[0]))
+        for (const char *n : {"librccl.so.1", "librccl.so"}) {
+            p->lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (p->lib) break;
+        }
+    if (!p->lib) return fail(RWKV_E_DEVICE, "cannot load %s (%s)", (env && env[0]) ? env : "librccl.so", dlerror());
     auto sym = [&](const char *n) { return dlsym(p->lib, n); };
     *(void **)&p->GetUniqueId = sym("ncclGetUniqueId");
     *(void **)&p->CommInitRank = sym("ncclCommInitRank");
@@ -1814,6 +1823,20 @@ constexpr int kNcclUint64 = 5, kNcclFloat64 = 8;
 } // namespace
 
 extern "C" {
+
+// which RCCL the pipeline transport binds in this process (path of the shared object that holds ncclSend); loads it if need be.
+// No GPU involved: a host can check the pairing before it builds a pipeline.
+int rwkv_pipe_rccl_path(char *out, uint64_t cap)
+{
+    if (!out || cap == 0) return fail(RWKV_E_ARG, "NULL argument");
+    static Pipe probe;
+    int rc = pipe_open(&probe);
+    if (rc) return rc;
+    Dl_info info{};
+    if (!dladdr(reinterpret_cast<void *>(probe.Send), &info) || !info.dli_fname) return fail(RWKV_E_DEVICE, "dladdr failed for ncclSend");
+    snprintf(out, (size_t)cap, "%s", info.dli_fname);
+    return 0;
+}
 
 // 128 opaque bytes (ncclUniqueId) made by ONE rank and handed to every rank of the pipeline out of band
 int rwkv_pipe_unique_id(void *out128)

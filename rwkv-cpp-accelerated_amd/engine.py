@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
     "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_debug_carry_hits", "rwkv_debug_carry_stats", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
-    "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode", "rwkv_pipe_decode_streams", "rwkv_pipe_profile", "rwkv_pipe_hop_stats",
+    "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_rccl_path", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode", "rwkv_pipe_decode_streams", "rwkv_pipe_profile", "rwkv_pipe_hop_stats",
     "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device",
 ]
 
@@ -85,6 +85,7 @@ def lib():
     L.rwkv_xseq_device.argtypes = [vp, i32]; L.rwkv_xseq_device.restype = vp
     L.rwkv_xseq_copy.argtypes = [vp, i32, vp, i32, u64]; L.rwkv_xseq_copy.restype = i32
     L.rwkv_sync.argtypes = [vp]; L.rwkv_sync.restype = i32
+    L.rwkv_pipe_rccl_path.argtypes = [C.c_char_p, u64]; L.rwkv_pipe_rccl_path.restype = i32
     L.rwkv_pipe_unique_id.argtypes = [vp]; L.rwkv_pipe_unique_id.restype = i32
     L.rwkv_pipe_init.argtypes = [vp, vp, i32, i32]; L.rwkv_pipe_init.restype = i32
     L.rwkv_pipe_decode.argtypes = [vp, C.POINTER(u64), u64, C.POINTER(u64)]; L.rwkv_pipe_decode.restype = i32
@@ -231,6 +232,13 @@ class RWKV:
         _chk(lib().rwkv_sync(self._h))
 
     # -- native pipeline transport (RCCL inside the engine) ------------------------------------
+    @staticmethod
+    def pipe_rccl_path() -> str:
+        """the RCCL shared object the pipeline transport binds in this process (RWKV_RCCL_LIB, else the one already loaded -- torch's --, else the system's)"""
+        buf = C.create_string_buffer(4096)
+        _chk(lib().rwkv_pipe_rccl_path(buf, len(buf)))
+        return buf.value.decode()
+
     @staticmethod
     def pipe_unique_id() -> bytes:
         buf = C.create_string_buffer(128)
