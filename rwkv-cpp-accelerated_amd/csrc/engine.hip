@@ -1348,6 +1348,8 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
         const uint64_t CH = (T > (uint64_t)SEQ_T && c->seq_rows > SEQ_T) ? (uint64_t)SEQ_TM : (uint64_t)SEQ_T;
         const uint64_t nchunks = (T + CH - 1) / CH;
         int rc = 0;
+        static const bool host_time = getenv("RWKV_SEQ_HOSTTIME") != nullptr;     // diagnostics: is a long call bound by the host's launch rate?
+        const auto h0 = std::chrono::steady_clock::now();
         if (nchunks >= 2 && (rc = split_setup(c)) == 0 && c->n_split >= 2) {
             // Software pipeline over the chunks: stage k = an equal share of the layers (the last one with the head) on its
             // own stream with its own scratch, stage k on chunk i while stage k - 1 is on chunk i + 1.  Every launch of this path
@@ -1388,7 +1390,13 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
                 if (rc) return rc;
             }
         }
+        const auto h1 = std::chrono::steady_clock::now();
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (host_time) {
+            const auto h2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[rwkv] forward T=%llu: host enqueue %.2f ms, waited %.2f ms more for the device\n", (unsigned long long)T,
+                    std::chrono::duration<double, std::milli>(h1 - h0).count(), std::chrono::duration<double, std::milli>(h2 - h1).count());
+        }
         return 0;
     }
     for (uint64_t t = 0; t < T; t++) {
