@@ -19,7 +19,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 using namespace rwkvk;
@@ -223,6 +225,12 @@ struct rwkv_ctx {
     unsigned long long *h_sq_tokens = nullptr;    // pinned, same shape
     hipEvent_t sq_ev[8] = {};                     // slot r of the ring is free once sq_ev[r] has completed
     uint64_t sq_n = 0;                            // chunks enqueued so far
+    // captured passes of the chunk path (GPT mode): one hipGraph per (layer range, residual buffer, rows, logits row of the last part);
+    // a pass is 11 launches per layer -- 2.9 k launches and events for a 512-token 7B prompt, 3.5 us of host time each
+    // (RWKV_SEQ_GRAPH=0: direct launches)
+    struct SeqGraphKey { uint64_t la, lb, row0; int buf, n; bool operator<(const SeqGraphKey &o) const { return std::tie(la, lb, row0, buf, n) < std::tie(o.la, o.lb, o.row0, o.buf, o.n); } };
+    std::map<SeqGraphKey, hipGraphExec_t> sq_graphs;
+    bool seq_graph = true;
     double *sq_x[4] = {nullptr, nullptr, nullptr, nullptr};   // residual stream [SEQ_T][D]; two buffers: a pipeline stage receives chunk c + 1 while chunk c is sent on; [2], [3]: more chunks in flight in rwkv_forward's pipeline
     hipEvent_t xs_ev[2] = {nullptr, nullptr};     // rwkv_xseq_copy: "source chunk done" / "copied"
     // long prompts on one GPU: the chunk path as a two-stage software pipeline (layers [l0, mid) on `stream`, [mid, l1) + head on
@@ -929,7 +937,20 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
 // part: nullptr = the context's whole layer range on its stream with its own scratch; else layers [la, lb) on part->st with
 // scratch part->S (the two-stage software pipeline of rwkv_forward: the embedding belongs to the part that starts at l0, the
 // head to the part that ends at l1)
-struct ChunkPart { uint64_t la, lb; hipStream_t st; const SeqScratch *S; };
+struct ChunkPart { uint64_t la, lb; hipStream_t st; const SeqScratch *S; bool no_upload = false; };
+// a pass's token ids: host -> pinned ring slot -> the device slot of the pass's residual buffer (what k_seq_embed reads; the copy is
+// stream-ordered behind the embedding kernel of the pass that used the buffer before)
+int upload_chunk_tokens(rwkv_ctx *c, const uint64_t *tokens, int n, int buf, hipStream_t st)
+{
+    const int slot = (int)(c->sq_n % SQ_RING);
+    if (c->sq_n >= SQ_RING) HIPCHK(hipEventSynchronize(c->sq_ev[slot]));   // the copy that last used this pinned slot is done
+    unsigned long long *h = c->h_sq_tokens + (size_t)slot * SEQ_TM, *d = c->sq_tokens + (size_t)buf * SEQ_TM;
+    for (int t = 0; t < n; t++) h[t] = tokens[t];
+    HIPCHK(hipMemcpyAsync(d, h, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(c->sq_ev[slot], st));
+    c->sq_n++;
+    return 0;
+}
 int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, bool par, int buf = 0, const ChunkPart *part = nullptr)
 {
     const int D = (int)c->D;
@@ -945,13 +966,9 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
     const SeqScratch &S = part ? *part->S : own;
     double *x = c->sq_x[buf];
     if (first) {
-        const int slot = (int)(c->sq_n % SQ_RING);
-        if (c->sq_n >= SQ_RING) HIPCHK(hipEventSynchronize(c->sq_ev[slot]));   // the copy that last used this pinned slot is done
-        unsigned long long *h = c->h_sq_tokens + (size_t)slot * SEQ_TM, *d = c->sq_tokens + (size_t)slot * SEQ_TM;
-        for (int t = 0; t < n; t++) h[t] = tokens[t];
-        HIPCHK(hipMemcpyAsync(d, h, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, st));
-        HIPCHK(hipEventRecord(c->sq_ev[slot], st));
-        c->sq_n++;
+        if (buf < 0 || buf >= SQ_RING) return fail(RWKV_E_ARG, "residual buffer %d out of range", buf);
+        if (!(part && part->no_upload)) { const int rcu = upload_chunk_tokens(c, tokens, n, buf, st); if (rcu) return rcu; }
+        unsigned long long *d = c->sq_tokens + (size_t)buf * SEQ_TM;
         SeqEmbedArgs ea{c->embed, c->ln, d, x, D};
         k_seq_embed<<<dim3(n), dim3(NT), 0, st>>>(ea);
     }
@@ -1202,6 +1219,39 @@ uint64_t split_point(const rwkv_ctx *c, int k, int n)
     return l;
 }
 
+// one pass of the chunk path (GPT mode) over layers [part.la, part.lb) on part.st: replay of the captured graph of exactly this pass
+// shape, captured at first use.  The token upload stays outside (host memory changes per pass); everything else a pass launches
+// depends only on the key.  A capture that fails turns the graphs off for the context and the pass is launched directly.
+int enqueue_pass(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, int buf, ChunkPart part)
+{
+    const bool first = c->l0 == 0 && part.la == c->l0, last = c->l1 == c->L && part.lb == c->l1;
+    if (!c->seq_graph || c->tl_on) return enqueue_chunk(c, tokens, n, row0, false, buf, &part);
+    if (first) { const int rcu = upload_chunk_tokens(c, tokens, n, buf, part.st); if (rcu) return rcu; }
+    part.no_upload = true;
+    const rwkv_ctx::SeqGraphKey key{part.la, part.lb, last ? row0 : 0, buf, n};
+    auto it = c->sq_graphs.find(key);
+    if (it == c->sq_graphs.end()) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        bool ok = hipStreamBeginCapture(part.st, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            const int rc = enqueue_chunk(c, nullptr, n, row0, false, buf, &part);
+            const hipError_t e = hipStreamEndCapture(part.st, &g);
+            ok = rc == 0 && e == hipSuccess && g != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+        if (!ok) {
+            (void)hipGetLastError();
+            c->seq_graph = false;
+            return enqueue_chunk(c, nullptr, n, row0, false, buf, &part);
+        }
+        it = c->sq_graphs.emplace(key, ge).first;
+    }
+    HIPCHK(hipGraphLaunch(it->second, part.st));
+    return 0;
+}
+
 // Rows carried in LDS across kernel boundaries pay only while THIS context's kernels follow each other on the CUs: with two contexts
 // decoding at once (two models, two streams of one model) nearly every workgroup finds that the other context's kernel has had its
 // CU (hits 1.2 %, profiles/r03/carry.txt) and the rows left for it were streamed for nothing -- 678 -> 656 tokens/s aggregate.  So
@@ -1265,6 +1315,7 @@ int rwkv_create(rwkv_ctx **out, int device)
     { const char *e = getenv("RWKV_SEQ_PIPE"); if (e) c->seq_pipe = atoi(e); }
     { const char *e = getenv("RWKV_SEQ_SMALL"); if (e) c->seq_small = atoi(e); }
     { const char *e = getenv("RWKV_SEQ_B"); if (e) c->seq_b = atoi(e); }
+    { const char *e = getenv("RWKV_SEQ_GRAPH"); if (e) c->seq_graph = atoi(e) != 0; }
     { const char *e = getenv("RWKV_SEQ_ROWS"); if (e) c->seq_rows = atoi(e) > SEQ_T ? SEQ_TM : SEQ_T; }
     { const char *e = getenv("RWKV_CARRY_EDGES"); if (e) c->carry_edges = atoi(e); }
     {
@@ -1373,7 +1424,8 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
                     if (k == 0) { if (i >= (uint64_t)ns) HIPCHK(hipStreamWaitEvent(st, c->sp_done[ns - 1][b], 0)); }   // the last stage is done with this buffer (chunk i - ns)
                     else HIPCHK(hipStreamWaitEvent(st, c->sp_done[k - 1][b], 0));                                        // the stage before has handed chunk i over
                     const ChunkPart part{split_point(c, k, ns), split_point(c, k + 1, ns), st, k == 0 ? &own : c->sp_scratch[k]};
-                    rc = enqueue_chunk(c, k == 0 ? tokens + t0 : nullptr, n, t0, mode == RWKV_MODE_PARRALEL, b, &part);
+                    if (mode == RWKV_MODE_PARRALEL) rc = enqueue_chunk(c, k == 0 ? tokens + t0 : nullptr, n, t0, true, b, &part);
+                    else rc = enqueue_pass(c, k == 0 ? tokens + t0 : nullptr, n, t0, b, part);
                     HIPCHK(hipEventRecord(c->sp_done[k][b], st));
                 }
             }
@@ -1384,9 +1436,15 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
             if (rc) return rc;
         } else {
             if (rc) return rc;
+            SeqScratch own;
+            own.state = c->sq_state; own.y = c->sq_y; own.imgh = c->sq_imgh;
+            for (int k = 0; k < 3; k++) own.img[k] = c->sq_img[k];
+            own.qpart = c->sq_qpart; own.qparta = c->sq_qparta; own.qparth = c->sq_qparth; own.stat = c->sq_stat;
+            own.pk3 = c->sq_pk3; own.pk5 = c->sq_pk5; own.pk1 = c->sq_pk1;
             for (uint64_t t0 = 0; t0 < T; t0 += CH) {
                 const int n = (int)(T - t0 < CH ? T - t0 : CH);
-                rc = enqueue_chunk(c, tokens + t0, n, t0, mode == RWKV_MODE_PARRALEL);
+                if (mode == RWKV_MODE_PARRALEL) rc = enqueue_chunk(c, tokens + t0, n, t0, true);
+                else rc = enqueue_pass(c, tokens + t0, n, t0, 0, ChunkPart{c->l0, c->l1, c->stream, &own});
                 if (rc) return rc;
             }
         }
@@ -1570,6 +1628,8 @@ void rwkv_free(rwkv_ctx *c)
     for (auto &row : c->sp_done) for (auto &e : row) if (e) (void)hipEventDestroy(e);
     if (c->sp_end) (void)hipEventDestroy(c->sp_end);
     for (int k = 1; k < rwkv_ctx::SPLIT_MAX; k++) { if (c->sp_stream[k]) (void)hipStreamDestroy(c->sp_stream[k]); delete c->sp_scratch[k]; }
+    for (auto &kv : c->sq_graphs) (void)hipGraphExecDestroy(kv.second);
+    c->sq_graphs.clear();
     if (c->h_sq_tokens) (void)hipHostFree(c->h_sq_tokens);
     for (int r = 0; r < SQ_RING; r++) if (c->sq_ev[r]) (void)hipEventDestroy(c->sq_ev[r]);
     if (c->stream) (void)hipStreamDestroy(c->stream);

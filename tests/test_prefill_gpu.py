@@ -275,3 +275,31 @@ def test_64_row_gemm_forms_agree(eng_mod, T, L, D, monkeypatch):
         assert np.array_equal(outs["0"][0], outs[b][0]), b
         for x, y in zip(outs["0"][1], outs[b][1]):
             assert np.array_equal(x, y), b
+
+
+@pytest.mark.parametrize("T,L,D", [(150, 3, 768), (64, 2, 2048), (20, 2, 1024)])
+def test_captured_passes_replay_bit_identically(eng_mod, T, L, D, monkeypatch):
+    """GPT-mode passes are captured as hipGraphs at first use (one per layer range, residual buffer, row count and logits row) and
+    replayed afterwards (engine.hip enqueue_pass; RWKV_SEQ_GRAPH=0: direct launches).  First call (capture + launch), second call
+    (replay) and the direct launches must agree bit for bit, logits and state, also when a different prompt goes through the same graphs."""
+    t = mf.synthetic_tensors(L, D, seed=900 + T)
+    toks, toks2 = _toks(T, 7 * T), _toks(T, 11 * T)
+    outs = {}
+    for gr in ("0", "1"):
+        monkeypatch.setenv("RWKV_SEQ_GRAPH", gr)
+        m = eng_mod.RWKV(resident=True)
+        m.loadTensors(L, D, t, maxGPT=T)
+        res = []
+        for tk in (toks, toks, toks2):
+            m.reset_state()
+            lg = m.forward(tk, eng_mod.MODE_GPT)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+            m.pull_state(1)
+            res.append((lg, [a.copy() for a in m.state.arrays()]))
+        outs[gr] = res
+        m.close()
+    for i in range(3):
+        assert np.array_equal(outs["0"][i][0], outs["1"][i][0]), i
+        for x, y in zip(outs["0"][i][1], outs["1"][i][1]):
+            assert np.array_equal(x, y), i
+    assert np.array_equal(outs["1"][0][0], outs["1"][1][0])
+    assert not np.array_equal(outs["1"][0][0], outs["1"][2][0])
