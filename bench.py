@@ -29,6 +29,29 @@ sys.path.insert(0, ROOT)
 
 USABLE_CPUS = None               # (usable CPUs, cgroup quota): read at the top of main()
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290
+I8_MFMA_PEAK_TOPS = 3944.0      # dense v_mfma_i32_16x16x64_i8 peak (MI355X_MICROARCH.md, MFMA table; no sparsity)
+
+
+def seq_roofline(L, D, V, rows, seconds):
+    """Both rooflines of a pass through the chunk path (mm8_seq on the int8 matrix cores), from what the engine really does:
+    every layer matrix is read once per weight pass of up to RWKV_SEQ_ROWS (default 64) rows, the head once per 32-row half;
+    every weight byte is multiplied with 3 activation limbs of every row of the pass (2 ops per MAC).  `bound` names the
+    roofline that is closer to its peak, i.e. the one that would bind first if the path were perfect."""
+    seq_rows = 32 if os.environ.get("RWKV_SEQ_ROWS") == "32" else 64
+    if rows <= 32:
+        seq_rows = 32
+    passes = (rows + seq_rows - 1) // seq_rows
+    halves = (rows + 31) // 32
+    wbytes = passes * 13 * L * D * D + halves * V * D
+    ops = 2 * 3 * (13 * L * D * D + V * D) * rows
+    gbps, tops = wbytes / seconds / 1e9, ops / seconds / 1e12
+    fh, fm = gbps / HBM_PEAK_GBPS, tops / I8_MFMA_PEAK_TOPS
+    return dict(weight_passes=passes, head_passes=halves, weight_bytes=wbytes, weight_GBps=round(gbps, 1), int8_mfma_TOPS=round(tops, 1),
+                roofline=dict(hbm=dict(achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(fh, 4)),
+                              mfma_i8=dict(achieved=round(tops, 1), peak=I8_MFMA_PEAK_TOPS, unit="TOP/s", frac=round(fm, 4)),
+                              bound="hbm" if fh >= fm else "mfma",
+                              method="weight bytes actually streamed (13 L D^2 per weight pass of <= 64 rows + V D per 32-row half) and "
+                                     "2 x 3 limbs x weight bytes x rows int8 operations, over the wall time of the call"))
 
 
 def main():
@@ -46,6 +69,8 @@ def main():
     ap.add_argument("--ref-seconds", type=float, default=150.0, help="wall-time bound of the reference-kernel leg")
     ap.add_argument("--profile-reps", type=int, default=16)
     ap.add_argument("--long-prompt", type=int, default=512, help="tokens of the one-call prompt of the prefill report (0 = skip)")
+    ap.add_argument("--no-long-gate", dest="long_gate", action="store_false", help="skip the reference-kernel gates of the long-prompt and "
+                    "96-stream legs (the reference needs ~20 s for the 512 tokens)")
     ap.add_argument("--prefill-chunks", type=int, default=4, help="32-token prompt chunks timed for the prefill report (0 = skip)")
     ap.add_argument("--config2-steps", type=int, default=256, help="greedy steps of the 1B5 leg (BASELINE config 2) reported beside the 7B headline; 0 = skip")
     ap.add_argument("--parallel", choices=["pipeline", "replicas"], default=os.environ.get("RWKV_BENCH_PARALLEL", "pipeline"),
@@ -174,7 +199,7 @@ def main():
                        "still moves its algorithmic bytes")
     # `traffic`: HBM read bytes per launch of the dominant kernel from the round's own rocprofv3 --pmc FETCH_SIZE pass
     # (tools/gpu_round.sh writes profiles/<round>/hbm_traffic.json together with the sha256 of the kernel source it profiled);
-    # a figure collected for ANOTHER kernels.hip.h is not quoted
+    # a figure collected for ANOTHER kernels.hip.h / engine.hip is not quoted
     roof.update(traffic_lookup(args.model, dom))
     # the north_star's target is stated per mm8_one shape: every weight-streaming kernel of the token with the reference
     # mm8 calls it absorbs (rwkv.cu:267-311 / :58-142), algorithmic uint8 bytes, launch duration, GB/s, fraction of 8 TB/s
@@ -238,9 +263,8 @@ def main():
             m.forward(prompt, engine.MODE_GPT)
         torch.cuda.synchronize()
         dtc = (time.perf_counter() - t0) / args.prefill_chunks
-        wbytes = 13 * L * D * D + mf.VOCAB * D
         line["prefill"] = dict(tokens_per_chunk=len(prompt), ms_per_chunk=round(dtc * 1e3, 3), tokens_per_s=round(len(prompt) / dtc, 1),
-                               weight_GBps=round(wbytes / dtc / 1e9, 1), int8_mfma_TOPS=round(2 * 3 * wbytes * len(prompt) / dtc / 1e12, 1),
+                               **seq_roofline(L, D, mf.VOCAB, len(prompt), dtc),
                                note="GPT-mode chunk (RWKV::loadContext path): v_mfma_i32_16x16x64_i8 over three activation limbs; includes logits for all 32 positions")
         if args.long_prompt >= 64:
             # a prompt of several chunks handed over in ONE call (RWKV::loadContext with maxContext >= the prompt, rwkv.h:395-413):
@@ -260,7 +284,7 @@ def main():
                 run_lp()
             dtl = (time.perf_counter() - t0) / 2
             line["prefill"]["long_prompt"] = dict(prompt_tokens=len(lp), tokens_per_s=round(len(lp) / dtl, 1), ms=round(dtl * 1e3, 2),
-                                                  weight_GBps=round(wbytes * (len(lp) / 32) / dtl / 1e9, 1),
+                                                  **seq_roofline(L, D, mf.VOCAB, len(lp), dtl),
                                                   note="one rwkv_forward call: passes of 64 rows (two halves per weight fragment; RWKV_SEQ_ROWS=32: the 32-row schedule, bit-identical "
                                                        "results) as a software pipeline over RWKV_SEQ_STAGES (default 3) streams on the one GPU (stage k on pass i while "
                                                        "stage k - 1 is on pass i + 1); RWKV_SEQ_STAGES=1 gives the one-stream schedule")
@@ -274,6 +298,7 @@ def main():
         torch.cuda.synchronize()
         dtb = (time.perf_counter() - t0) / args.prefill_chunks
         line["batched_decode"] = dict(streams=len(prompt), ms_per_step=round(dtb * 1e3, 3), aggregate_tokens_per_s=round(len(prompt) / dtb, 1),
+                                      **seq_roofline(L, D, mf.VOCAB, len(prompt), dtb),
                                       note="MODE PARRALEL: one token of each of 32 independent sequences per step, weights read once per step")
         if args.long_prompt >= 96:
             # 96 streams per step = three 32-row passes, pipelined over the stages like the chunks of a long prompt
@@ -290,6 +315,7 @@ def main():
                 run_many()
             dtm = (time.perf_counter() - t0) / args.prefill_chunks
             line["batched_decode"]["streams_96"] = dict(ms_per_step=round(dtm * 1e3, 3), aggregate_tokens_per_s=round(len(many) / dtm, 1),
+                                                        **seq_roofline(L, D, mf.VOCAB, len(many), dtm),
                                                         note="a 64-row and a 32-row pass per step as a software pipeline over the stages (RWKV_SEQ_STAGES)")
 
     # ---- BASELINE config 2 beside the headline: RWKV-4-Raven-1B5 single-stream decode on the same GPU ----
@@ -302,22 +328,53 @@ def main():
         # BASELINE config 5 at its stated size: the 32-token prompt as ONE GPT-mode call of the reference kernel (and one
         # 32-slot PARRALEL step) vs the chunk path that the `prefill` / `batched_decode` legs above timed
         if args.prefill_chunks > 0:
-            g = chunk_gate_leg(mf, tensors, L, D, prompt, m)
+            g = chunk_gate_leg(mf, tensors, L, D, prompt, m, long_prompt=args.long_prompt if args.long_gate else 0)
             if "prefill" in line:
                 line["prefill"]["parity_vs_reference_kernel"] = g.get("gpt_chunk", g)
+                if "long_prompt" in line["prefill"] and "long_prompt" in g:
+                    line["prefill"]["long_prompt"]["parity_vs_reference_kernel"] = g["long_prompt"]
             if "batched_decode" in line:
                 line["batched_decode"]["parity_vs_reference_kernel"] = g.get("parralel_step", g)
+                if "streams_96" in line["batched_decode"] and "streams_96" in g:
+                    line["batched_decode"]["streams_96"]["parity_vs_reference_kernel"] = g["streams_96"]
 
     # ---- CPU baseline: the oracle (CPU restatement of rwkv.cu:493-593) on this box's host cores ----
     if rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(pkg, mf, tensors, L, D, prompt, args.cpu_seconds, engine_model=m)
 
     m.close()
+    bad = parity_failures(line) if rank == 0 else []
     if rank == 0:
+        line["parity_gates_failed"] = bad
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        # the line above is on record; a number whose parity gate tripped must not pass for a result
+        print("[bench] PARITY GATE FAILED: " + "; ".join(bad), file=sys.stderr, flush=True)
+        raise SystemExit(4)
+
+
+def parity_failures(node, path=""):
+    """every `*_outside_tolerance` count > 0 (and every state error above its tolerance) anywhere in the line, as 'path = value'"""
+    out = []
+    if isinstance(node, dict):
+        for k, v in node.items():
+            p = f"{path}.{k}" if path else k
+            if k.endswith("_outside_tolerance") and isinstance(v, (int, float)) and v > 0:
+                out.append(f"{p} = {v}")
+            elif k == "state_max_rel" and isinstance(v, dict):
+                tol = node.get("state_tolerance", 1e-4)
+                out += [f"{p}.{a} = {b} > {tol}" for a, b in v.items() if not (b <= tol)]
+            elif k == "parity_vs_engine" and isinstance(v, dict) and not (v.get("max_rel_logit_err", 0.0) <= v.get("tolerance", 1e-3)):
+                out.append(f"{p}.max_rel_logit_err = {v.get('max_rel_logit_err')}")
+            else:
+                out += parity_failures(v, p)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            out += parity_failures(v, f"{path}[{i}]")
+    return out
 
 
 def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
@@ -369,6 +426,14 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
             native_note = native_note or "another rank could not join the engine-side RCCL communicator"
             if rank == 0:
                 print(f"[bench] native transport unavailable ({native_note}); using torch.distributed P2P", file=sys.stderr, flush=True)
+    # every rank's end of the transport (rwkv_pipe_info: device ordinal, PCI bus id, RCCL version + path, agreed prefill rows) goes into
+    # the line: the first run of the engine-side schedule on real xGMI must be diagnosable from its record
+    tinfo = [None] * world
+    try:
+        mine_info = stage.m.pipe_info() if native else dict(rank=rank, transport="torch.distributed P2P")
+    except Exception as e:          # noqa: BLE001
+        mine_info = dict(rank=rank, error=str(e))
+    dist.all_gather_object(tinfo, mine_info)
     rng = np.random.default_rng(1)
     first = [int(x) for x in rng.integers(2, mf.VOCAB, world)]
 
@@ -496,7 +561,7 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
                             note=f"ONE stream in flight through the {world} stages (rwkv_pipe_decode_streams, n_streams = 1): "
                                  "t_tok(1 GPU) + (N - 1) hops + the fed-back id per token (SURVEY 8e); N - 1 GPUs idle at any time"),
             hop=hop, parity_vs_single_gpu=parity, cpu_baseline=cpu,
-            prefill=prefill, transport_fallback=native_note)), flush=True)
+            prefill=prefill, transport_fallback=native_note, transport_info=tinfo)), flush=True)
     faulthandler.cancel_dump_traceback_later()
     dist.barrier()
     dist.destroy_process_group()
@@ -533,13 +598,20 @@ def ref_kernel_leg(mf, tensors, L, D, prompt, engine_model, steps, budget_s, B_t
                                                              "(max|d| <= 1e-3 max|ref| and |d| <= 1e-3|ref| + 1e-3 rms)"))
 
 
-def traffic_lookup(model, kernel):
-    """HBM bytes per launch of `kernel` from the newest profiles/rNN/hbm_traffic.json whose recorded kernel-source digest matches
-    the kernels.hip.h in the tree (tools/gpu_round.sh records it); {traffic: None, traffic_source: why} otherwise."""
-    import glob
+def decode_src_digest():
+    """sha256 over the sources that decide what a decode launch reads: the kernels AND the engine (grid, ring geometry, carry plan)"""
     import hashlib
-    src = os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", "kernels.hip.h")
-    digest = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    h = hashlib.sha256()
+    for f in ("kernels.hip.h", "engine.hip"):
+        h.update(open(os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def traffic_lookup(model, kernel):
+    """HBM bytes per launch of `kernel` from the newest profiles/rNN/hbm_traffic.json whose recorded source digest matches the
+    kernels.hip.h + engine.hip in the tree (tools/gpu_round.sh records it); {traffic: None, traffic_source: why} otherwise."""
+    import glob
+    digest = decode_src_digest()
     stale = []
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "hbm_traffic.json")), reverse=True):
         try:
@@ -547,13 +619,13 @@ def traffic_lookup(model, kernel):
         except Exception:
             continue
         rel = os.path.relpath(f, ROOT)
-        if d.get("kernels_hip_h_sha256") != digest:
+        if d.get("decode_src_sha256") != digest:
             stale.append(rel)
             continue
         v = d.get(model, {}).get(kernel)
         if v is not None:
-            return dict(traffic=v, traffic_source=f"{rel} (rocprofv3 --pmc FETCH_SIZE x 2, per launch; same kernels.hip.h as this run)")
-    return dict(traffic=None, traffic_source="no PMC pass on record for this kernels.hip.h" + (f" (stale: {', '.join(stale[:2])})" if stale else ""))
+            return dict(traffic=v, traffic_source=f"{rel} (rocprofv3 --pmc FETCH_SIZE x 2, per launch; same kernels.hip.h + engine.hip as this run)")
+    return dict(traffic=None, traffic_source="no PMC pass on record for this kernels.hip.h + engine.hip" + (f" (other sources: {', '.join(stale[:2])})" if stale else ""))
 
 
 def small_model_leg(mf, engine, name, steps, device, dev):
@@ -587,26 +659,38 @@ def small_model_leg(mf, engine, name, steps, device, dev):
                 frac_of_8TBps=round(B * tps / 1e9 / HBM_PEAK_GBPS, 4), kernels=kern)
 
 
-def chunk_gate_leg(mf, tensors, L, D, prompt, engine_model):
+def chunk_gate_leg(mf, tensors, L, D, prompt, engine_model, long_prompt=0):
     """rank 0, N=1: full-depth parity of the CHUNK path (mm8_seq on the int8 matrix cores) against the reference's own kernel
     run with T = 32 tokens in one call -- GPT mode (RWKV::loadContext's shape, rwkv.h:339-376,395-413; in-kernel token loops
     rwkv.cu:227,279): all 32 logits rows, the five state arrays, then 8 greedy decode steps from that state; PARRALEL mode
-    (rwkv.cu:236-240): two 32-slot steps, all rows, all slots of the state.  tests/refgate.run_chunk_gate."""
+    (rwkv.cu:236-240): two 32-slot steps, all rows, all slots of the state.  tests/refgate.run_chunk_gate.
+    long_prompt >= 64: also the legs that run SEVERAL weight passes per call, on the schedule bench.py times (64-row passes, the
+    three-stream software pipeline, captured pass graphs): the same `long_prompt` tokens in one rwkv_forward call against the
+    reference kernel fed them 32 at a time -- every logits row, the state, 4 decode steps (refgate.run_long_prompt_gate) -- and a
+    96-stream PARRALEL step, two rounds, against the reference's 96-slot step (refgate.run_streams_gate)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import oracle_lib
     import refgate
     from rwkv_cpp_accelerated_amd import engine
     if not os.path.exists(oracle_lib.REF_SO):
         return dict(skipped="oracle/_ref/libref.so not built")
     ref = oracle_lib.Ref()
-    rm = refgate.ref_model_from_torch(ref, mf, tensors, L, D, len(prompt))
+    many = long_prompt >= 96 and engine_model.maxContext >= 96
+    rm = refgate.ref_model_from_torch(ref, mf, tensors, L, D, 96 if many else len(prompt))
     was = engine_model.resident
     engine_model.resident = True
     g = refgate.run_chunk_gate(rm, engine_model, mf, engine, prompt, decode_steps=8)
+    if long_prompt >= 64 and engine_model.maxContext >= long_prompt:
+        lp = [int(x) for x in np.random.default_rng(11).integers(2, mf.VOCAB, long_prompt)]      # the tokens the long_prompt leg timed
+        g["long_prompt"] = refgate.run_long_prompt_gate(rm, engine_model, mf, engine, lp, ref_chunk=32, decode_steps=4)
+    if many:
+        first = [int(x) for x in np.random.default_rng(12).integers(2, mf.VOCAB, 96)]
+        g["streams_96"] = refgate.run_streams_gate(rm, engine_model, mf, engine, first, rounds=2)
     engine_model.resident = was
     tol = dict(tolerance=1e-3, state_tolerance=1e-4,
-               note="engine chunk path vs reference include/rwkv/cuda/rwkv.cu (built unmodified for gfx950) called with T=32 tokens; "
-                    "logits: max|d| <= 1e-3 max|ref| and |d| <= 1e-3|ref| + 1e-3 rms per row; state: max|d| / max(1, max|ref|)")
+               note="engine chunk path vs reference include/rwkv/cuda/rwkv.cu (built unmodified for gfx950) called with T=32 tokens "
+                    "(streams_96: T=96 slots); logits: max|d| <= 1e-3 max|ref| and |d| <= 1e-3|ref| + 1e-3 rms per row; state: max|d| / max(1, max|ref|)")
     for k in g:
         for kk, v in list(g[k].items()):
             if isinstance(v, float):

@@ -31,7 +31,7 @@ extern "C" {
  * their check are re-loaded instead of failing the call (no more "arrived damaged" error); the carry counters are on by default
  * (rwkv_debug_carry_stats).  rwkv_abi_version() returns the value the
  * library was built with: a binding compares it with the header it was compiled against. */
-#define RWKV_MI355X_ABI_VERSION 4
+#define RWKV_MI355X_ABI_VERSION 5
 int rwkv_abi_version(void);
 
 #define RWKV_VOCAB 50277u /* hard-wired in the reference: rwkv.h:126, rwkv.cu:471,589 */
@@ -76,9 +76,12 @@ uint64_t rwkv_max_ctx(const rwkv_ctx *ctx);
  * step of n_tokens independent sequences on state slots 0..n_tokens-1.  Logits for every
  * position land in the device logits buffer ([n_tokens][50277] f32); state stays on the device.
  * n_tokens == 1 runs the decode kernels (uint8 x fixed-point dot products on the VALU); n_tokens >= 2
- * on a whole-model context with max_ctx > 1 runs chunks of up to 32 rows through mm8_seq on the int8
- * matrix cores, reading every weight byte once per chunk (env RWKV_SEQ=0 at load time keeps the
- * token-by-token path).  Both agree with the reference within its own tolerance; see DESIGN.md.
+ * on a whole-model context with max_ctx > 1 runs mm8_seq on the int8 matrix cores in weight passes of up
+ * to 64 rows (two 32-row halves that share every weight fragment; a call of <= 32 rows, or env
+ * RWKV_SEQ_ROWS=32: one 32-row chunk per pass), every weight byte read once per pass, the passes of a
+ * longer call pipelined over RWKV_SEQ_STAGES (default 3) streams of the one GPU (env RWKV_SEQ=0 at load
+ * time keeps the token-by-token path).  All schedules give bit-identical results and agree with the
+ * reference within its own tolerance; see DESIGN.md 5.
  * Synchronous on return (the reference ends with cudaDeviceSynchronize, rwkv.cu:590). */
 int rwkv_forward(rwkv_ctx *ctx, const uint64_t *tokens, uint64_t n_tokens, int mode);
 
@@ -150,7 +153,12 @@ int rwkv_sync(rwkv_ctx *ctx);
  *                        PyTorch-ROCm host carries torch/lib/librccl.so, built against the HIP runtime torch brought along --
  *                        the engine's streams live in that runtime too); else the system's librccl.so.1
  *   rwkv_pipe_unique_id  one rank makes the 128-byte communicator id (ncclGetUniqueId) and distributes it out of band
- *   rwkv_pipe_init       every rank joins (ncclCommInitRank); the rank must match the context's layer range
+ *   rwkv_pipe_init       every rank joins (ncclCommInitRank); the rank must match the context's layer range.  The ranks then AGREE,
+ *                        over the communicator, on the prefill micro-batch (64 or 32 rows: RWKV_SEQ_ROWS and max_ctx are per-rank
+ *                        values) and on n_embed / n_layers / world; a mismatch fails every rank with RWKV_E_ARG.  One line describing
+ *                        this rank's end of the transport goes to stderr (RWKV_PIPE_LOG=0: silent)
+ *   rwkv_pipe_info       that description as a JSON object: rank, world, layer range, device ordinal, PCI bus id, arch, RCCL version
+ *                        code + path of the shared object holding ncclSend, HIP runtime version, agreed prefill rows
  *   rwkv_pipe_decode     greedy decode of `world` independent streams (one per stage in flight, state slot = stream),
  *                        n_steps tokens each; first_tokens[world] is read on rank 0, picks[world][n_steps] written on
  *                        the last rank.  The hop (f64[n_embed] forward, the picked id u64 back to rank 0) and the stage
@@ -166,6 +174,7 @@ int rwkv_sync(rwkv_ctx *ctx);
 int rwkv_pipe_rccl_path(char *out, uint64_t cap);
 int rwkv_pipe_unique_id(void *out128);
 int rwkv_pipe_init(rwkv_ctx *ctx, const void *id128, int rank, int world);
+int rwkv_pipe_info(rwkv_ctx *ctx, char *out, uint64_t cap);
 int rwkv_pipe_decode(rwkv_ctx *ctx, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks);
 int rwkv_pipe_decode_streams(rwkv_ctx *ctx, const uint64_t *first_tokens, uint64_t n_steps, uint64_t n_streams, uint64_t *picks);
 int rwkv_pipe_profile(rwkv_ctx *ctx, int on);

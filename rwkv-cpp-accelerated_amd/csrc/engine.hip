@@ -137,6 +137,9 @@ struct Pipe {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+    uint64_t ch = 0;             // rows per prefill micro-batch every rank of this pipeline agreed on (rwkv_pipe_init)
+    std::string info;            // one JSON object describing this rank's end of the transport (rwkv_pipe_info)
 };
 
 // decode kernels that stream through the LDS ring: -1 = by model width (measured on MI355X, profiles/r02/ring_sweep.txt,
@@ -1219,6 +1222,19 @@ uint64_t split_point(const rwkv_ctx *c, int k, int n)
     return l;
 }
 
+// The captured passes are keyed by (layer range, residual buffer, rows, logits row of the last part): a server with many different
+// prompt lengths keeps adding shapes (up to max_ctx / 64 row offsets x 64 remainders for the part that holds the head).  The cache is
+// bounded: beyond SQ_GRAPH_CAP entries everything is dropped and re-captured on demand (a capture costs ~1 ms per pass shape; a 512-token
+// prompt uses 24).  Called at the START of rwkv_forward only (the one entry point that replays them): it is synchronous on return, so none of
+// the executables is in flight here.
+constexpr size_t SQ_GRAPH_CAP = 256;
+void trim_pass_graphs(rwkv_ctx *c)
+{
+    if (c->sq_graphs.size() <= SQ_GRAPH_CAP) return;
+    for (auto &kv : c->sq_graphs) (void)hipGraphExecDestroy(kv.second);
+    c->sq_graphs.clear();
+}
+
 // one pass of the chunk path (GPT mode) over layers [part.la, part.lb) on part.st: replay of the captured graph of exactly this pass
 // shape, captured at first use.  The token upload stays outside (host memory changes per pass); everything else a pass launches
 // depends only on the key.  A capture that fails turns the graphs off for the context and the pass is launched directly.
@@ -1394,6 +1410,7 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
         if (tokens[t] >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id %llu out of range", (unsigned long long)tokens[t]);
     HIPCHK(hipSetDevice(c->device));
     { const int rcp = begin_call(c); if (rcp) return rcp; }
+    trim_pass_graphs(c);
     if (T >= 2 && c->seq_ok && c->l0 == 0 && c->l1 == c->L) {   // prompt chunks (GPT) / batched decode step of T streams (PARRALEL): weights read once per <= 32 rows
         // rows per weight pass: 64 (two halves sharing every weight fragment) for calls of more than 32 rows, else 32
         const uint64_t CH = (T > (uint64_t)SEQ_T && c->seq_rows > SEQ_T) ? (uint64_t)SEQ_TM : (uint64_t)SEQ_T;
@@ -1882,6 +1899,7 @@ int pipe_open(Pipe *p)
     *(void **)&p->GroupStart = sym("ncclGroupStart");
     *(void **)&p->GroupEnd = sym("ncclGroupEnd");
     *(void **)&p->GetErrorString = sym("ncclGetErrorString");
+    *(void **)&p->GetVersion = sym("ncclGetVersion");      // (optional: diagnostics only)
     if (!p->GetUniqueId || !p->CommInitRank || !p->Send || !p->Recv || !p->GroupStart || !p->GroupEnd)
         return fail(RWKV_E_DEVICE, "librccl.so lacks the point-to-point API");
     return 0;
@@ -1954,7 +1972,77 @@ int rwkv_pipe_init(rwkv_ctx *c, const void *id128, int rank, int world)
             return undo(rc);
         }
     }
+    // Every rank must cut a prompt into the SAME micro-batches (rwkv_pipe_prefill: rows per ncclSend / ncclRecv) and speak about the same
+    // model: the values behind that are per-rank (RWKV_SEQ_ROWS in each process's environment, the max_ctx each context was loaded with),
+    // so they are agreed here, once, over the communicator itself -- a ring pass of (min, max) per field, world - 1 hops, after which every
+    // rank holds the same extremes and every rank fails the same way on a mismatch (a pipeline that disagrees would hang in its first
+    // prefill hop, or corrupt the residual stream).
+    {
+        const uint64_t my_ch = !c->seq_ok ? 0 : (c->seq_rows > SEQ_T && c->maxT >= (uint64_t)SEQ_TM) ? (uint64_t)SEQ_TM : (c->maxT >= (uint64_t)SEQ_T ? (uint64_t)SEQ_T : 0);
+        uint64_t mm[8] = {my_ch, my_ch, c->D, c->D, c->L, c->L, (uint64_t)world, (uint64_t)world};      // (min, max) pairs
+        if (world > 1) {
+            uint64_t *d = nullptr;
+            if (hipMalloc(reinterpret_cast<void **>(&d), 16 * sizeof(uint64_t)) != hipSuccess) return undo(fail(RWKV_E_DEVICE, "rwkv_pipe_init: no device memory for the agreement round"));
+            int r = 0;
+            hipError_t e = hipSuccess;
+            for (int hop = 0; hop + 1 < world && !r && e == hipSuccess; hop++) {
+                e = hipMemcpyAsync(d, mm, sizeof(mm), hipMemcpyHostToDevice, c->stream);
+                if (e != hipSuccess) break;
+                r = p->GroupStart();
+                if (!r) r = p->Send(d, 8, kNcclUint64, (rank + 1) % world, p->comm, c->stream);
+                if (!r) r = p->Recv(d + 8, 8, kNcclUint64, (rank + world - 1) % world, p->comm, c->stream);
+                const int r2 = p->GroupEnd();
+                if (!r) r = r2;
+                uint64_t got[8];
+                if (!r) e = hipMemcpyAsync(got, d + 8, sizeof(got), hipMemcpyDeviceToHost, c->stream);
+                if (!r && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (!r && e == hipSuccess)
+                    for (int k = 0; k < 8; k += 2) { mm[k] = std::min(mm[k], got[k]); mm[k + 1] = std::max(mm[k + 1], got[k + 1]); }
+            }
+            (void)hipFree(d);
+            if (r) { rc = pipe_fail(p, r, "agreement round of rwkv_pipe_init"); if (rank > 0) { c->x_in = nullptr; (void)rebuild_graphs(c); } return undo(rc); }
+            if (e != hipSuccess) { rc = fail(RWKV_E_DEVICE, "agreement round of rwkv_pipe_init: %s", hipGetErrorString(e)); if (rank > 0) { c->x_in = nullptr; (void)rebuild_graphs(c); } return undo(rc); }
+        }
+        if (mm[0] != mm[1] || mm[2] != mm[3] || mm[4] != mm[5] || mm[6] != mm[7]) {
+            rc = fail(RWKV_E_ARG, "the ranks of this pipeline disagree: prefill micro-batch rows %llu..%llu (RWKV_SEQ_ROWS / max_ctx differ between ranks; this rank: %llu), "
+                                  "n_embed %llu..%llu, n_layers %llu..%llu, world %llu..%llu", (unsigned long long)mm[0], (unsigned long long)mm[1], (unsigned long long)my_ch,
+                      (unsigned long long)mm[2], (unsigned long long)mm[3], (unsigned long long)mm[4], (unsigned long long)mm[5], (unsigned long long)mm[6], (unsigned long long)mm[7]);
+            if (rank > 0) { c->x_in = nullptr; (void)rebuild_graphs(c); }
+            return undo(rc);
+        }
+        p->ch = my_ch;
+    }
+    {   // what this rank's end of the transport is made of: for the first run on real xGMI to be diagnosable from its log / bench line
+        int ver = -1;
+        if (p->GetVersion) (void)p->GetVersion(&ver);
+        Dl_info di{};
+        const char *path = (dladdr(reinterpret_cast<void *>(p->Send), &di) && di.dli_fname) ? di.dli_fname : "?";
+        char bus[64] = "?";
+        (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), c->device);
+        hipDeviceProp_t prop{};
+        (void)hipGetDeviceProperties(&prop, c->device);
+        int rt = 0;
+        (void)hipRuntimeGetVersion(&rt);
+        char buf[1024];
+        snprintf(buf, sizeof(buf), "{\"rank\": %d, \"world\": %d, \"layers\": [%llu, %llu], \"device\": %d, \"pci_bus_id\": \"%s\", \"arch\": \"%s\", \"cus\": %d, "
+                                   "\"rccl_version\": %d, \"rccl_path\": \"%s\", \"hip_runtime\": %d, \"prefill_rows\": %llu, \"HSA_ENABLE_IPC_MODE_LEGACY\": \"%s\"}",
+                 rank, world, (unsigned long long)c->l0, (unsigned long long)c->l1, c->device, bus, prop.gcnArchName, prop.multiProcessorCount, ver, path, rt,
+                 (unsigned long long)p->ch, getenv("HSA_ENABLE_IPC_MODE_LEGACY") ? getenv("HSA_ENABLE_IPC_MODE_LEGACY") : "");
+        p->info = buf;
+        const char *lg = getenv("RWKV_PIPE_LOG");
+        if (!(lg && lg[0] == '0')) fprintf(stderr, "[rwkv_mi355x] pipeline transport up: %s\n", buf);
+    }
     c->pipe = p;
+    return 0;
+}
+
+// this rank's end of the pipeline transport as one JSON object (rank, world, layer range, device ordinal, PCI bus id, arch, RCCL
+// version code and the path of the shared object that holds ncclSend, HIP runtime version, agreed prefill micro-batch rows)
+int rwkv_pipe_info(rwkv_ctx *c, char *out, uint64_t cap)
+{
+    if (!c || !out || cap == 0) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->pipe) return fail(RWKV_E_STATE, "needs rwkv_pipe_init done");
+    snprintf(out, (size_t)cap, "%s", c->pipe->info.c_str());
     return 0;
 }
 
@@ -2147,9 +2235,9 @@ int rwkv_pipe_prefill(rwkv_ctx *c, const uint64_t *tokens, uint64_t n_tokens)
             tokens = clean.data();
         }
     }
-    // micro-batch = one weight pass of the stage: 64 rows (two halves per weight fragment) where the context allows, else 32; every rank
-    // derives it from the same two values (RWKV_SEQ_ROWS, max_ctx), which the ranks of one pipeline share
-    const uint64_t CH = (c->seq_rows > SEQ_T && c->maxT >= (uint64_t)SEQ_TM) ? (uint64_t)SEQ_TM : (uint64_t)SEQ_T;
+    // micro-batch = one weight pass of the stage: 64 rows (two halves per weight fragment) where the contexts allow, else 32
+    const uint64_t CH = p->ch;       // agreed by all ranks in rwkv_pipe_init (a per-rank value here could differ between ranks: hang or corruption)
+    if (CH == 0) return fail(RWKV_E_STATE, "chunked path not available on every rank (load with max_ctx >= 32)");
     const uint64_t n_chunks = (n_tokens + CH - 1) / CH;
     auto rows_of = [&](uint64_t ci) { return ci + 1 < n_chunks ? CH : n_tokens - ci * CH; };
     auto has_work = [&](int r, uint64_t t) { return t >= (uint64_t)r && t - r < n_chunks; };

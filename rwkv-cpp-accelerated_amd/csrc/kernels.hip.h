@@ -1236,7 +1236,11 @@ __device__ __forceinline__ void carry_verify(const CarryCheck &ck, GldsCtl *ctl,
 template <int S> __device__ __forceinline__ constexpr bool early_take() { return RWKV_EARLY_TAKE == 1 || (RWKV_EARLY_TAKE == 2 && S >= 5); }
 // the consumer waves' streaming loop (wave < NC): same pre / epi contract as stream_groups; ready() = wait until the vectors are staged
 // and fetch the scalars the epilogues need (called once, by every wave)
-template <int R, int S, int PAT, class Pre, class Epi, class Ready>
+// CARRIED = the kernel's carry instance: its first groups may have been sitting in LDS since the previous kernel and are only to be used
+// once carry_verify has checked (and repaired) them -- which the staging waves learn in ready(), BEHIND an early take.  The two are
+// never combined by the defaults (carry at 3-4 KiB rows, early take from 5 KiB), and a build that forces both (-DRWKV_EARLY_TAKE=1
+// with RWKV_CARRY > 0) gets the early take switched off in the carry instances instead of unverified rows.
+template <int R, int S, int PAT, bool CARRIED = false, class Pre, class Epi, class Ready>
 __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
                                             int chunks, Pre pre, Epi epi, Ready ready, unsigned &fail, unsigned long long *g_tl_groups = nullptr, int pos0 = 0)
 {
@@ -1246,7 +1250,7 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
     int rr = 0;
 #endif
     constexpr int NWP = NT / 2 / 64;
-    constexpr bool ET = early_take<S>();
+    constexpr bool ET = early_take<S>() && !CARRIED;
     bool first = true;
     if (!ET) { ready(); first = false; }
     const bool late_pre = ET && wave >= NWP;       // the waves that take their first group before the vectors are staged
@@ -1562,7 +1566,7 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
             constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 3 : 0;
             ring_site<3, S, RC>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, 3, a.w, a.cy.hits});
             auto ready = [&]() { SiteRed<3> sr; ring_site_ready<3, RC>(red, gc, sr, fail, a.tl); scalars(sr); };
-            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
+            ring_groups<3, S, PAT_PER_ROW, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[3][S], wB[3][S];
@@ -1670,7 +1674,7 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
             constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? R : 0;
             ring_vec<1, S, RC>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, R, a.w, a.cy.hits});
             auto ready = [&]() { ring_vec_ready<RC>(red, gc, Sf, amax, fail, a.tl); sc = scale_of(amax); };
-            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, nullptr, CARRY ? a.cy.pos0 : 0);
+            ring_groups<R, S, PAT_SHARED, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, nullptr, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[R][S], wB[R][S];
@@ -1769,7 +1773,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
             constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 5 : 0;
             ring_site<2, S, RC>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, 5, a.w, a.cy.hits});
             auto ready = [&]() { SiteRed<2> sr; ring_site_ready<2, RC>(red, gc, sr, fail, a.tl); scalars(sr); };
-            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
+            ring_groups<5, S, PAT_FFN_RK, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[5][S], wB[5][S];
@@ -1867,7 +1871,7 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
             constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 4 : 0;
             ring_vec<4, S, RC>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, 1, a.w, a.cy.hits});
             auto ready = [&]() { ring_vec_ready<RC>(red, gc, Sf, amax, fail, a.tl); sc = scale_of(amax); };
-            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
+            ring_groups<4, S, PAT_PER_ROW, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
         }
     } else {
         u32x4 wA[4][S], wB[4][S];

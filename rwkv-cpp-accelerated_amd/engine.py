@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("RWKV_LIB") or os.path.join(_HERE, "csrc", "librwkv_mi
 MODE_PARRALEL, MODE_GPT = 0, 1   # reference enums/enum.h:2-5
 SAMPLE_BAN0, SAMPLE_RECIPE = 1, 2   # include/rwkv_mi355x.h
 N_KCLASS = 7
-ABI_VERSION = 4                   # RWKV_MI355X_ABI_VERSION of include/rwkv_mi355x.h
+ABI_VERSION = 5                   # RWKV_MI355X_ABI_VERSION of include/rwkv_mi355x.h
 KCLASS_NAMES = ["first", "att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head", "argmax"]
 
 # every entry point declared in include/rwkv_mi355x.h (tests check the library exports all of them)
@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
     "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_debug_carry_hits", "rwkv_debug_carry_stats", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
     "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_rccl_path", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode", "rwkv_pipe_decode_streams", "rwkv_pipe_profile", "rwkv_pipe_hop_stats",
-    "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device",
+    "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device", "rwkv_pipe_info",
 ]
 
 _lib = None
@@ -94,6 +94,7 @@ def lib():
     L.rwkv_pipe_hop_stats.argtypes = [vp, C.POINTER(C.c_double)]; L.rwkv_pipe_hop_stats.restype = i32
     L.rwkv_pipe_prefill.argtypes = [vp, C.POINTER(u64), u64]; L.rwkv_pipe_prefill.restype = i32
     L.rwkv_pipe_free.argtypes = [vp]; L.rwkv_pipe_free.restype = None
+    L.rwkv_pipe_info.argtypes = [vp, C.c_char_p, u64]; L.rwkv_pipe_info.restype = i32
     L.rwkv_tensor_device.argtypes = [vp, i32]; L.rwkv_tensor_device.restype = vp
     _lib = L
     return L
@@ -248,6 +249,13 @@ class RWKV:
     def pipe_init(self, unique_id: bytes, rank: int, world: int):
         assert len(unique_id) == 128
         _chk(lib().rwkv_pipe_init(self._h, C.create_string_buffer(unique_id, 128), rank, world))
+
+    def pipe_info(self) -> dict:
+        """this rank's end of the transport (rwkv_pipe_info): rank, world, layers, device, PCI bus id, arch, RCCL version + path, prefill rows"""
+        import json
+        buf = C.create_string_buffer(2048)
+        _chk(lib().rwkv_pipe_info(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     def pipe_decode(self, first_tokens, n_steps: int, world: int, last: bool, n_streams: int | None = None):
         """greedy decode of n_streams (default: world) streams over the stages; [world][n_steps] ids on the last rank"""

@@ -190,6 +190,7 @@ int ncclCommDestroy(void *comm)
 
 int ncclSend(const void *buf, size_t count, int type, int peer, void *comm, hipStream_t st) { return submit(true, const_cast<void *>(buf), count, type, peer, comm, st); }
 int ncclRecv(void *buf, size_t count, int type, int peer, void *comm, hipStream_t st) { return submit(false, buf, count, type, peer, comm, st); }
+int ncclGetVersion(int *v) { if (v) *v = 1; return 0; }      // (1 = this stand-in; real RCCL reports e.g. 22204)
 int ncclGroupStart() { g_depth++; return 0; }
 int ncclGroupEnd()
 {

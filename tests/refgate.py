@@ -3,8 +3,8 @@
 SAME device-resident synthetic tensors, the engine teacher-forced with the reference's greedy ids, and compare the
 logits of every step with BASELINE.json's tolerance (parity.py) plus the greedy id of every step.
 
-Used by bench.py (7B, 1024 steps: `ref_kernel_baseline` + `parity_vs_reference_kernel`) and by
-tests/test_ref_parity_gpu.py (1B5 and 14B at full depth).  Nothing here reads /root/reference at run time."""
+Used by bench.py (7B, 1024 steps: `ref_kernel_baseline` + `parity_vs_reference_kernel`; the chunk, long-prompt and 96-stream
+gates beside the legs that time those paths) and by tests/test_ref_parity_gpu.py (1B5, 7B and 14B at full depth).  Nothing here reads /root/reference at run time."""
 import time
 
 import numpy as np
@@ -137,14 +137,28 @@ def run_chunk_gate(rm, em, mf, engine_mod, prompt, decode_steps=8, strict=False,
                             decode_steps_after=decode_steps, decode_max_rel=dworst, decode_steps_outside_tolerance=dbad,
                             decode_ids_identical=ddiff == 0, ref_chunk_seconds=ref_s)
     # ---- (b) PARRALEL step ----
+    res["parralel_step"] = run_streams_gate(rm, em, mf, engine_mod, prompt, rounds=2, strict=strict, what=what, state_tol=state_tol)
+    return res
+
+
+def run_streams_gate(rm, em, mf, engine_mod, first, rounds=2, strict=False, what="", state_tol=1e-4):
+    """PARRALEL mode (rwkv.cu:236-240) with T = len(first) independent sequences per step: `rounds` steps of the reference's kernel
+    against the engine's batched step, so the per-slot state carries over -- every logits row of every round and all T slots of the
+    five state arrays.  T > 64 makes the engine run SEVERAL weight passes per step (a 64-row and a 32-row pass at T = 96) as a
+    software pipeline over its streams: the `batched_decode.streams_96` leg of bench.py.  rm / em need maxGPT >= T."""
+    T = len(first)
+    LD = rm.L_ * rm.D
     em.reset_state()
     for s in range(5):
         rm.state(s)[:] = 0.0
     rng = np.random.default_rng(4321)
     worst, bad, diff = 0.0, 0, 0
-    for rnd in range(2):
-        toks = prompt if rnd == 0 else [int(x) for x in rng.integers(2, mf.VOCAB, T)]
+    ref_s = 0.0
+    for rnd in range(rounds):
+        toks = list(first) if rnd == 0 else [int(x) for x in rng.integers(2, mf.VOCAB, T)]
+        t0 = time.perf_counter()
         lr = rm.forward(toks, oracle_lib.MODE_PARRALEL)
+        ref_s += time.perf_counter() - t0
         le = em.forward(toks, engine_mod.MODE_PARRALEL)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
         w, b, d = _rows(le, lr, strict, f"{what} PARRALEL round {rnd}")
         worst = max(worst, w); bad += b; diff += d
@@ -152,6 +166,46 @@ def run_chunk_gate(rm, em, mf, engine_mod, prompt, decode_steps=8, strict=False,
     serr = _state_err(em, rm, T * LD)
     if strict:
         assert max(serr.values()) <= state_tol, serr
-    res["parralel_step"] = dict(slots=T, rounds=2, max_rel=worst, rows_outside_tolerance=bad, rows_greedy_id_differs=diff, state_max_rel=serr)
     em.reset_state()
-    return res
+    return dict(slots=T, rounds=rounds, max_rel=worst, rows_outside_tolerance=bad, rows_greedy_id_differs=diff, state_max_rel=serr,
+                ref_seconds=ref_s)
+
+
+def run_long_prompt_gate(rm, em, mf, engine_mod, tokens, ref_chunk=32, decode_steps=4, strict=False, what="", state_tol=1e-4):
+    """A prompt of SEVERAL weight passes handed to the engine in ONE call (RWKV::loadContext with maxContext >= the prompt,
+    rwkv.h:395-413: 64-row passes, the three-stream software pipeline, the captured pass graphs -- what bench.py's `long_prompt`
+    leg times) against the reference's own kernel fed the same tokens in GPT-mode calls of `ref_chunk` tokens (its in-kernel token
+    loops, rwkv.cu:227,279; the state carries from call to call on its side): EVERY logits row, the five state arrays after the
+    last token, then `decode_steps` greedy single-token steps from that state.  rm needs maxGPT >= ref_chunk, em maxGPT >= len(tokens)."""
+    T = len(tokens)
+    LD = rm.L_ * rm.D
+    em.reset_state()
+    for s in range(5):
+        rm.state(s)[:] = 0.0
+    le = em.forward(tokens, engine_mod.MODE_GPT)[: T * mf.VOCAB].reshape(T, mf.VOCAB).copy()
+    worst, bad, diff, ref_s = 0.0, 0, 0, 0.0
+    last = None
+    for c0 in range(0, T, ref_chunk):
+        part = tokens[c0:c0 + ref_chunk]
+        t0 = time.perf_counter()
+        lr = rm.forward(part, oracle_lib.MODE_GPT)
+        ref_s += time.perf_counter() - t0
+        w, b, d = _rows(le[c0:c0 + len(part)], lr, strict, f"{what} prompt rows {c0}..")
+        worst = max(worst, w); bad += b; diff += d
+        last = lr[len(part) - 1].copy()
+    em.pull_state(1)
+    serr = _state_err(em, rm, LD)
+    if strict:
+        assert max(serr.values()) <= state_tol, serr
+    tk = parity.argmax_ban0(last)
+    dworst, dbad, ddiff = 0.0, 0, 0
+    for step in range(decode_steps):
+        l1 = rm.forward([tk])
+        e1 = em.forward(int(tk))[: mf.VOCAB].reshape(1, mf.VOCAB)
+        w, b, d = _rows(e1, l1, strict, f"{what} decode after the prompt, step {step}")
+        dworst = max(dworst, w); dbad += b; ddiff += d
+        tk = parity.argmax_ban0(l1[0])
+    em.reset_state()
+    return dict(rows=T, reference_calls=f"{(T + ref_chunk - 1) // ref_chunk} GPT-mode calls of {ref_chunk} tokens", max_rel=worst,
+                rows_outside_tolerance=bad, rows_greedy_id_differs=diff, state_max_rel=serr, decode_steps_after=decode_steps,
+                decode_max_rel=dworst, decode_steps_outside_tolerance=dbad, decode_ids_identical=ddiff == 0, ref_seconds=ref_s)

@@ -138,6 +138,7 @@ def _native_worker(rank, world, port, first_tokens, L, D, seed, steps, prompt, q
         l0, l1 = pipeline.partition_layers(L, world, D)[rank]
         st = pipeline.EngineStage(mf.synthetic_tensors(L, D, seed=seed), L, D, l0, l1, n_slots=world, device=0, prefill=True)
         pipeline.pipe_connect(st, dist, rank, world)
+        info = st.m.pipe_info()
         pipeline.run_prefill_native(st, rank, prompt, len(prompt))
         lg = st.m.logits(32)[: mf.VOCAB * ((len(prompt) - 1) % 32 + 1)].reshape(-1, mf.VOCAB)[-1].copy() if rank == world - 1 else None
         picks = pipeline.run_pipeline_native(st, rank, world, first_tokens, steps)
@@ -158,7 +159,7 @@ def _native_worker(rank, world, port, first_tokens, L, D, seed, steps, prompt, q
         if rank == 0:
             q.put(("rank0", bad))
         if rank == world - 1:
-            q.put(("ok", picks, lg, picks1, hop))
+            q.put(("ok", picks, lg, picks1, hop, info))
         dist.barrier()
         st.m.close()
         dist.destroy_process_group()
@@ -200,7 +201,10 @@ def test_native_transport_with_several_ranks_on_one_gpu(eng_mod, world):
                 p.kill()
     assert "error" not in res, res["error"]
     assert "out of range" in (res["rank0"][1] or ""), res["rank0"]
-    _, picks, lg, picks1, hop = res["ok"]
+    _, picks, lg, picks1, hop, info = res["ok"]
+    # rwkv_pipe_info: what the first run on real xGMI will be diagnosed from (here: the stand-in's version code 1 and its path)
+    assert info["rank"] == world - 1 and info["world"] == world and info["prefill_rows"] == 64 and info["rccl_version"] == 1, info
+    assert info["rccl_path"].endswith("libfake_rccl.so") and info["device"] == 0 and info["arch"].startswith("gfx"), info
     t = mf.synthetic_tensors(L, D, seed=seed)
     m = eng_mod.RWKV(resident=True); m.loadTensors(L, D, t, maxGPT=32)
     for i in range(0, len(prompt), 32):
@@ -223,3 +227,59 @@ def test_native_transport_with_several_ranks_on_one_gpu(eng_mod, world):
     assert list(picks1[0]) == ids and not picks1[1:].any(), picks1
     assert hop["n"] == steps and 0.0 < hop["min_us"] <= hop["mean_us"] <= hop["max_us"], hop
     m.close()
+
+
+
+def _mismatch_worker(rank, world, port, L, D, q, rccl_lib):
+    try:
+        os.environ["RWKV_RCCL_LIB"] = rccl_lib
+        os.environ["RWKV_PIPE_LOG"] = "0"
+        if rank == 1:
+            os.environ["RWKV_SEQ_ROWS"] = "32"           # a per-rank environment difference: this rank would cut prompts into 32-row micro-batches
+        import torch.distributed as dist
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from rwkv_cpp_accelerated_amd import pipeline
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        l0, l1 = pipeline.partition_layers(L, world, D)[rank]
+        st = pipeline.EngineStage(mf.synthetic_tensors(L, D, seed=7), L, D, l0, l1, n_slots=world, device=0, prefill=True)
+        err = None
+        try:
+            pipeline.pipe_connect(st, dist, rank, world)
+        except Exception as e:                           # noqa: BLE001
+            err = str(e)
+        q.put(("rank", rank, err))
+        dist.barrier()
+        st.m.close()
+        dist.destroy_process_group()
+    except Exception as e:                               # pragma: no cover
+        q.put(("error", rank, repr(e)))
+
+
+def test_pipe_init_refuses_ranks_that_disagree_on_the_micro_batch(eng_mod):
+    """rwkv_pipe_prefill's micro-batch (64 or 32 rows) comes from per-rank values (RWKV_SEQ_ROWS, max_ctx): ranks that differ would
+    exchange differently sized messages and hang or corrupt the residual stream.  rwkv_pipe_init agrees on it over the communicator
+    (ADVICE r04): with RWKV_SEQ_ROWS=32 on rank 1 only, EVERY rank must fail the init with the same diagnosis."""
+    import torch.multiprocessing as mp
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/_build/libfake_rccl.so is missing: run __graft_entry__.build()")
+    world, L, D = 2, 4, 768
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, world, port, L, D, q, FAKE_RCCL)) for r in range(world)]
+    [p.start() for p in procs]
+    got = {}
+    try:
+        for _ in range(world):
+            r = q.get(timeout=300)
+            assert r[0] != "error", r
+            got[r[1]] = r[2]
+    finally:
+        [p.join(timeout=60) for p in procs]
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    for r in range(world):
+        assert got[r] and "disagree" in got[r] and "32..64" in got[r], got

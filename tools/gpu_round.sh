@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU-box session that produces everything profiles/rNN/ holds: GPU tests, the full bench line (reference-kernel
 # gate + CPU baseline legs included), rocprofv3 kernel-trace stats of the bench command, a separate PMC pass (FETCH_SIZE
-# only, no trace domains), the prefill report with per-kernel statistics, the other model sizes, the N = 2 dry runs of the multi-GPU bench line.  usage: tools/gpu_round.sh [r04]
+# only, no trace domains), the prefill report with per-kernel statistics, the other model sizes, the N = 2 dry runs of the multi-GPU bench line.  usage: tools/gpu_round.sh [r05]
 cd "$(dirname "$0")/.."
-R=$PWD; TAG=${1:-r04}; O=$R/gpurun_out/$TAG
+R=$PWD; TAG=${1:-r05}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 export PYTHONUNBUFFERED=1
 if [ -z "$SKIP_TESTS" ]; then
@@ -60,7 +60,9 @@ with open(O + "/bench7b_pmc_fetch_size_summary.csv", "w") as fo:
         fo.write(f"{k},{len(v)},{mean:.1f},{b},{a},{b / a:.4f}\n")
 print(open(O + "/bench7b_pmc_fetch_size_summary.csv").read())
 import hashlib
-json.dump({"7B": traffic, "kernels_hip_h_sha256": hashlib.sha256(open("rwkv-cpp-accelerated_amd/csrc/kernels.hip.h", "rb").read()).hexdigest(), "_note": "HBM read bytes per launch = mean FETCH_SIZE [KB] x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section); "
+sys.path.insert(0, os.getcwd())
+import bench
+json.dump({"7B": traffic, "decode_src_sha256": bench.decode_src_digest(), "_note": "HBM read bytes per launch = mean FETCH_SIZE [KB] x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section); "
            "own rocprofv3 --pmc FETCH_SIZE pass of `bench.py --steps 8 --warmup 2` (tools/gpu_round.sh)"}, open(O + "/hbm_traffic.json", "w"), indent=1)
 PY
 rm -rf $O/kt $O/pmc
