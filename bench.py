@@ -213,7 +213,7 @@ def main():
         metric="tokens/sec single-stream RWKV-4 uint8 greedy decode",
         value=round(tok_s, 2), unit="tokens/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
         ms_per_step=round(1e3 * dt / args.steps, 5), higher_is_better=True, scaling="weak",
-        vs_baseline=None, dtype="u8 weights x 23-bit fixed-point activations, exact u32 accumulate (v_dot4_u32_u8); f32/f64 epilogues, f64 state", data="synthetic",
+        vs_baseline=None, dtype="u8 weights x 23-bit fixed-point activations, exact 32-bit integer accumulate (v_dot4 on the VALU: i32_i8 on signed limbs in tile form, u32_u8 in row form); f32/f64 epilogues, f64 state", data="synthetic",
         config=dict(workload=f"RWKV-4-Raven-{args.model} uint8 single-stream greedy decode "
                              f"(L={L}, D={D}, V={mf.VOCAB}), 32-token prompt then {args.steps}-token continuation, "
                              "device-resident state",
@@ -234,10 +234,12 @@ def main():
                         "(DESIGN.md 4.5).  timed_region = workgroup launches of the TIMED decode that found / did not find their rows "
                         "(one counter word per workgroup, counted inside the timed region itself).  The carry changes no result "
                         "(bit-identical logits with RWKV_CARRY=0, tests/test_engine_gpu.py) and is worth +1.3 % at 7B"),
-        hbm_resident_bytes=dict(total=m.resident_bytes(),
-                                note="device bytes of this context: decode-layout weights + embedding + state + scratch"
-                                     + (", plus the SECOND copy of the matrices in the MFMA B-operand image of the chunk path "
-                                        f"(13*L*D^2 + V*D = {13 * L * D * D + mf.VOCAB * D} bytes; loaded because max_ctx > 1)" if args.prefill_chunks > 0 else "")),
+        hbm_resident_bytes=dict(total=m.resident_bytes(), weight_bytes_one_copy=13 * L * D * D + mf.VOCAB * D,
+                                note="device bytes of this context: weights + row-sum tables + embedding + state + scratch.  A 4096-wide model on 256 CUs "
+                                     "decodes in TILE form (csrc/tile.hip.h) and holds ONE image of the per-layer matrices -- the MFMA B-operand image the "
+                                     "chunk path multiplies -- plus the head in row form (and the head's tile image when max_ctx > 1); other widths (and "
+                                     "RWKV_TILE=0) keep the row-form matrices and, when max_ctx > 1, the tile image as a second copy (DESIGN.md 3)"),
+        decode_form=("tile" if os.environ.get("RWKV_TILE", "-1") not in ("0",) and D == 4096 and torch.cuda.get_device_properties(local_rank).multi_processor_count == 256 else "row"),
     )
 
     if drop_in is not None:
@@ -544,7 +546,7 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
             value=round(tok_s, 2), unit="tokens/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 5),
             higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype="u8 weights x 23-bit fixed-point activations, exact u32 accumulate (v_dot4_u32_u8); f32/f64 epilogues, f64 state",
+            dtype="u8 weights x 23-bit fixed-point activations, exact 32-bit integer accumulate (v_dot4 on the VALU: i32_i8 on signed limbs in tile form, u32_u8 in row form); f32/f64 epilogues, f64 state",
             data="synthetic",
             config=dict(workload=f"RWKV-4-Raven-{args.model} uint8 greedy decode (L={L}, D={D}), layers pipelined over {world} GPUs, "
                                  f"{world} independent streams in flight (one per stage), {args.steps} tokens per stream",

@@ -5,6 +5,7 @@
 // engine: weights are re-tiled once at load, state and the embedding table stay resident on the
 // device, and one token is a replay of a captured hipGraph (4 launches per layer + 2).
 #include "kernels.hip.h"
+#include "tile.hip.h"
 #include "seq.hip.h"
 #include "sampler.hip.h"
 #include "../../include/rwkv_mi355x.h"
@@ -181,6 +182,9 @@ struct rwkv_ctx {
     bool carry_active = true;       //   this context is the only one of the process on its device (carry_policy)
     unsigned carry_epoch = 0u;      //   g_ctx_epoch when that was last looked at
     unsigned *carry_hits = nullptr; //   debug counters (env RWKV_CARRY_COUNT=1; rwkv_debug_carry_hits)
+    int tile = -1;           // decode kernel classes that run in TILE form (tile.hip.h; bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv; env RWKV_TILE; -1 = auto: 15 where a
+                             // workgroup owns exactly one 16-channel block -- D = 4096 on 256 CUs --, else 0).  15: the context holds ONLY the tile image of the per-layer
+                             // matrices; a partial mask keeps both layouts (tuning); tile form turns the row-form loaders' carry off
     int ring = RWKV_RING;    // decode kernels that stream their weights through the LDS ring (bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv, 4 k_head; env RWKV_RING)
 
     // weights (device)
@@ -297,6 +301,19 @@ int ring_units(int nv, int S, bool common) { return (int)((LDS_BYTES - RED_BYTES
 int ring_xq_bytes(int nv, int S, bool common) { return (common ? 4 : nv) * S * 3072; }
 size_t smem_ring3(int nv, int S, bool common) { return RED_BYTES + (size_t)ring_xq_bytes(nv, S, common) + sizeof(GldsCtl) + (size_t)ring_units(nv, S, common) * S * 1024; }
 
+// tile-form decode kernels (tile.hip.h; classes 1 att, 2 att_out, 3 ffn_rk, 4 ffn_v): ring of 4 KiB units behind each kernel's fixed LDS
+constexpr int TILE_SU = 4;
+size_t tile_fixed(int cls, int D) { return cls == 1 ? tile_fixed_att(D) : cls == 2 ? tile_fixed_attout(D) : cls == 3 ? tile_fixed_frk(D) : tile_fixed_fv(D); }
+int tile_units(int cls, int D)
+{
+    const int nu = (cls == 1 ? 3 : cls == 3 ? 5 : cls == 4 ? 4 : 1) * (D / 64) / TILE_SU;          // units a workgroup streams
+    const int fit = (int)((LDS_BYTES - tile_fixed(cls, D)) / ((size_t)TILE_SU * 1024)) & ~1;         // (even: the loader moves pairs of units)
+    return std::min(fit, nu);
+}
+size_t tile_smem(int cls, int D) { return tile_fixed(cls, D) + (size_t)tile_units(cls, D) * TILE_SU * 1024; }
+// a class runs in tile form when asked to (RWKV_TILE bit cls - 1), the chunk path's image is loaded, and a workgroup owns exactly one 16-channel block
+bool tile_ok(const rwkv_ctx *c, int cls) { return c->tile > 0 && ((c->tile >> (cls - 1)) & 1) && c->b_frk != nullptr; }
+
 // k-blocks a wave of k_seq_gemm_p keeps in flight (K/V/R, ffn k/r at up to 4 KiB rows; a divisor of 8)
 #ifndef RWKV_SEQ_DEPTH0
 #define RWKV_SEQ_DEPTH0 2
@@ -383,7 +400,14 @@ struct ArgMaker {
         n = std::max(n, 1);
         n = std::min(n, std::min(G / 2, units() / (2 * rows_of(cls))));
         n = std::min(n, GLDS_FQ / 2);            // RingLoader::adopt books them in gend[] / freeq[] (GLDS_FQ entries)
+        n = std::min(n, 64 / nrs_of(cls));       // their expected sums travel in GldsCtl::csum (64 words)
         return std::max(n, 0);
+    }
+    static int nrs_of(int cls) { return cls == 1 ? 3 : cls == 2 ? ATTOUT_R : cls == 3 ? 5 : 1; }      // words of the position-weighted sum table per group
+    const unsigned *sums_of(int cls, uint64_t l) const
+    {
+        const size_t lr = (size_t)(l - c->l0);
+        return cls == 1 ? c->rw_kvr + lr * 3 * D : cls == 2 ? c->rw_att + lr * D : cls == 3 ? c->rw_frk + lr * 5 * D : c->rw_fv + lr * D;
     }
     const uint8_t *weights_of(int cls, uint64_t l) const
     {
@@ -406,6 +430,7 @@ struct ArgMaker {
         if (next_of(cls, l, chain, c2, l2) && carry_groups(c2) > 0) {
             cy.w_next = weights_of(c2, l2); cy.rows_next = rows_of(c2); cy.n_out = carry_groups(c2); cy.groups_next = groups_of(c2);
             cy.tag_out[0] = c->nonce[0]; cy.tag_out[1] = c->nonce[1] ^ (unsigned)(l2 * 8 + (uint64_t)c2);
+            cy.rw_next = sums_of(c2, l2); cy.nrs_next = nrs_of(c2);
         }
         if (prev_of(cls, l, chain, c2, l2) && carry_groups(cls) > 0) {
             cy.n_in = carry_groups(cls);
@@ -441,7 +466,7 @@ struct ArgMaker {
         const size_t lo = (size_t)l * D;
         AttArgs aa;
         aa.x = c->x; aa.st = site_static(0, l); aa.dy = site_dyn(0, l == c->l0 ? n_first : grid);
-        aa.w = c->w_kvr + (size_t)(l - c->l0) * 3 * D * D; aa.rs = c->rs_kvr + (size_t)(l - c->l0) * D * 3; aa.rw = c->rw_kvr + (size_t)(l - c->l0) * D * 3;
+        aa.w = c->w_kvr ? c->w_kvr + (size_t)(l - c->l0) * 3 * D * D : nullptr; aa.rs = c->rs_kvr + (size_t)(l - c->l0) * D * 3; aa.rw = c->rw_kvr ? c->rw_kvr + (size_t)(l - c->l0) * D * 3 : nullptr;
         aa.uw = c->uw + lo; aa.ew = c->ew + lo;
         aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
         aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
@@ -453,7 +478,7 @@ struct ArgMaker {
     {
         const size_t lo = (size_t)l * D;
         AttOutArgs ao;
-        ao.w = c->w_att + (size_t)(l - c->l0) * D * D; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.rw = c->rw_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
+        ao.w = c->w_att ? c->w_att + (size_t)(l - c->l0) * D * D : nullptr; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.rw = c->rw_att ? c->rw_att + (size_t)(l - c->l0) * D : nullptr; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
         ao.x = c->x; ao.lnw = c->ln + (4 * l + 2) * D; ao.lnb = c->ln + (4 * l + 3) * D; ao.lnstat = c->lnstat + 0;
         ao.sxy = c->state[0] + lo; ao.st = site_static(1, l); ao.dy = site_dyn(1, grid); ao.sdd = c->state[4] + lo;
         ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.ns = 0; ao.tl = tl_of(2, l); ao.herr = c->d_herr; ao.cy = carry(2, l);
@@ -464,7 +489,7 @@ struct ArgMaker {
         const size_t lo = (size_t)l * D;
         FfnRKArgs fa;
         fa.x = c->x; fa.st = site_static(1, l); fa.dy = site_dyn(1, grid);
-        fa.w = c->w_frk + (size_t)(l - c->l0) * 5 * D * D; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5; fa.rw = c->rw_frk + (size_t)(l - c->l0) * D * 5;
+        fa.w = c->w_frk ? c->w_frk + (size_t)(l - c->l0) * 5 * D * D : nullptr; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5; fa.rw = c->rw_frk ? c->rw_frk + (size_t)(l - c->l0) * D * 5 : nullptr;
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.partM = c->partMF; fa.ctl = c->ctl; fa.D = D;
         fa.ns = 0; fa.tl = tl_of(3, l); fa.herr = c->d_herr; fa.cy = carry(3, l);
@@ -477,7 +502,7 @@ struct ArgMaker {
     {
         const size_t lo = (size_t)l * D;
         FfnVArgs fv;
-        fv.w = c->w_fv + (size_t)(l - c->l0) * 4 * D * D; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.rw = c->rw_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
+        fv.w = c->w_fv ? c->w_fv + (size_t)(l - c->l0) * 4 * D * D : nullptr; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.rw = c->rw_fv ? c->rw_fv + (size_t)(l - c->l0) * D : nullptr; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
         fv.rgate = c->rgate; fv.x = c->x; fv.lnw = c->ln + (4 * l + 4) * D; fv.lnb = c->ln + (4 * l + 5) * D; fv.lnstat = c->lnstat + 2;
         fv.sdd = c->state[4] + lo; fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D; fv.tl = tl_of(4, l);
         fv.ns = 0; fv.herr = c->d_herr; fv.cy = carry(4, l);
@@ -506,7 +531,13 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
     } break;
     case 1: {
         AttArgs aa = mk.att(l);
-        if (c->ring & 1) {
+        if (tile_ok(c, 1)) {
+            AttTArgs ta;
+            ta.a = aa; ta.a.ns = tile_units(1, mk.D); ta.a.cy = RingCarry{};
+            ta.im.CB = mk.D / 16; ta.im.bimg = c->b_kvr + (size_t)(l - c->l0) * 3 * (size_t)ta.im.CB * 16 * mk.D;
+            k_att_t<4, TILE_SU, 64><<<dim3(grid), dim3(NT), tile_smem(1, mk.D), c->stream>>>(ta);
+        }
+        else if (c->ring & 1) {
             aa.ns = ring_units(3, S, mk.common);
             if (mk.common) DISPATCH_S(S, k_att<S_, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(3, S, true), c->stream>>>(aa))
             else DISPATCH_S(S, k_att<S_, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(3, S, false), c->stream>>>(aa));
@@ -515,7 +546,13 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
     } break;
     case 2: {
         AttOutArgs ao = mk.attout(l);
-        if ((c->ring & 2) && mk.common && mk.ring_cls(2)) {
+        if (tile_ok(c, 2)) {
+            AttOutTArgs ta;
+            ta.a = ao; ta.a.ns = tile_units(2, mk.D); ta.a.cy = RingCarry{};
+            ta.im.CB = mk.D / 16; ta.im.bimg = c->b_att + (size_t)(l - c->l0) * (size_t)ta.im.CB * 16 * mk.D;
+            k_attout_t<4, TILE_SU, 64><<<dim3(grid), dim3(NT), tile_smem(2, mk.D), c->stream>>>(ta);
+        }
+        else if ((c->ring & 2) && mk.common && mk.ring_cls(2)) {
             ao.ns = ring_units(1, S, true);
             DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(1, S, true), c->stream>>>(ao));
         }
@@ -524,7 +561,13 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
     } break;
     case 3: {
         FfnRKArgs fa = mk.frk(l);
-        if (c->ring & 4) {
+        if (tile_ok(c, 3)) {
+            FfnRKTArgs ta;
+            ta.a = fa; ta.a.ns = tile_units(3, mk.D); ta.a.cy = RingCarry{};
+            ta.im.CB = mk.D / 16; ta.im.bimg = c->b_frk + (size_t)(l - c->l0) * 5 * (size_t)ta.im.CB * 16 * mk.D;
+            k_ffn_rk_t<4, TILE_SU, 64><<<dim3(grid), dim3(NT), tile_smem(3, mk.D), c->stream>>>(ta);
+        }
+        else if (c->ring & 4) {
             fa.ns = ring_units(2, S, mk.common);
             if (mk.common) DISPATCH_S(S, k_ffn_rk<S_, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(2, S, true), c->stream>>>(fa))
             else DISPATCH_S(S, k_ffn_rk<S_, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(2, S, false), c->stream>>>(fa));
@@ -534,7 +577,14 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
     case 4: {
         FfnVArgs fv = mk.fv(l);
         fv.ns = ring_units(4, S, mk.common);
-        if (mk.fv_next_att(l)) {
+        if (tile_ok(c, 4)) {
+            FfnVTArgs ta;
+            ta.a = fv; ta.a.ns = tile_units(4, mk.D); ta.a.cy = RingCarry{};
+            ta.im.CB = mk.D / 16; ta.im.bimg = c->b_fv + (size_t)(l - c->l0) * (size_t)ta.im.CB * 16 * 4 * mk.D;
+            if (mk.fv_next_att(l)) k_ffnv_t<4, TILE_SU, 256, 3><<<dim3(grid), dim3(NT), tile_smem(4, mk.D), c->stream>>>(ta);
+            else k_ffnv_t<4, TILE_SU, 256, 1><<<dim3(grid), dim3(NT), tile_smem(4, mk.D), c->stream>>>(ta);
+        }
+        else if (mk.fv_next_att(l)) {
             if (c->ring & 8) {
                 if (mk.common) DISPATCH_S(S, k_ffnv<S_, 3, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(4, S, true), c->stream>>>(fv))
                 else DISPATCH_S(S, k_ffnv<S_, 3, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(4, S, false), c->stream>>>(fv));
@@ -686,6 +736,13 @@ int set_smem_limits(rwkv_ctx *c)
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, 1>, smem_ring3(4, S, false))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, 2>, smem_ring3(4, S, true))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_head<S_, 1, 1>, smem_ring(smem_head(S), RWKV_HEAD_RR, S))); if (rc) return rc;
+    if (c->D == 4096) {
+        if ((rc = allow_smem(k_att_t<4, TILE_SU, 64>, tile_smem(1, 4096)))) return rc;
+        if ((rc = allow_smem(k_attout_t<4, TILE_SU, 64>, tile_smem(2, 4096)))) return rc;
+        if ((rc = allow_smem(k_ffn_rk_t<4, TILE_SU, 64>, tile_smem(3, 4096)))) return rc;
+        if ((rc = allow_smem(k_ffnv_t<4, TILE_SU, 256, 3>, tile_smem(4, 4096)))) return rc;
+        if ((rc = allow_smem(k_ffnv_t<4, TILE_SU, 256, 1>, tile_smem(4, 4096)))) return rc;
+    }
     return 0;
 }
 
@@ -778,47 +835,106 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         HIPCHK(hipGetLastError());
     }
 
-    // uint8 matrices: re-tile to row-per-output
-    if ((rc = dalloc(c, &c->w_kvr, nl * 3 * D * D))) return rc;
-    if ((rc = dalloc(c, &c->w_att, nl * D * D))) return rc;
-    if ((rc = dalloc(c, &c->w_frk, nl * 5 * D * D))) return rc;
-    if ((rc = dalloc(c, &c->w_fv, nl * 4 * D * D))) return rc;
-    if (last && (rc = dalloc(c, &c->w_head, V * D))) return rc;
-    uint8_t *staging = nullptr;
-    if (!src.on_device) HIPCHK(hipMalloc(reinterpret_cast<void **>(&staging), std::max<uint64_t>(4 * D * D, V * D)));
-    for (uint64_t l = l0; l < l1 && !rc; l++) {
-        uint8_t *kvr = c->w_kvr + (l - l0) * 3 * D * D, *frk = c->w_frk + (l - l0) * 5 * D * D;
-        if (!rc) rc = retile(c, src, KM, l, D, D, kvr, 1, 3, 0, staging);
-        if (!rc) rc = retile(c, src, VM, l, D, D, kvr, 1, 3, 1, staging);
-        if (!rc) rc = retile(c, src, RM, l, D, D, kvr, 1, 3, 2, staging);
-        if (!rc) rc = retile(c, src, ATTOUT, l, D, D, c->w_att + (l - l0) * D * D, 1, 1, 0, staging);
-        if (!rc) rc = retile(c, src, FFNK, l, D, 4 * D, frk, 4, 5, 0, staging);
-        if (!rc) rc = retile(c, src, FFNR, l, D, D, frk, 1, 5, 4, staging);
-        if (!rc) rc = retile(c, src, FFNV, l, 4 * D, D, c->w_fv + (l - l0) * 4 * D * D, 1, 1, 0, staging);
+    // uint8 matrices.  Two device layouts exist: ROW form -- re-tiled to row-per-output, what the row-form decode kernels
+    // stream -- and the TILE image -- [16-row tile][k-block of 64][lane][16 B], signed: the MFMA B operand of the chunk path AND what the
+    // tile-form decode kernels stream (tile.hip.h).  A context whose four per-layer decode classes all run in tile form (7B-wide models on
+    // 256 CUs: c->tile == 15) keeps ONLY the tile image: every matrix goes file layout -> row form in a scratch buffer -> row sums,
+    // octant row sums, tile image, layer by layer.  Otherwise the row form is resident and the tile image is the second copy the chunk
+    // path (max_ctx > 1) needs.  The head stays in row form (k_head) either way (+ its tile image for the chunk path).
+    const bool want_seq = [&] { const char *e = getenv("RWKV_SEQ"); return max_ctx > 1 && D % 64 == 0 && !(e && e[0] == '0'); }();
+    if (c->tile < 0) c->tile = (D == 4096 && c->grid * 16 == (int)D) ? 15 : 0;       // (auto: where a workgroup owns exactly one 16-channel block)
+    if (!(D % 64 == 0 && c->grid * 16 == (int)D && D == 4096)) c->tile = 0;
+    if (c->tile) c->carry_kib = 0;      // (the row-form loaders' carry has no tile-form counterpart yet)
+    const bool tile_only = c->tile == 15;
+    const bool need_b = want_seq || c->tile != 0;
+    if (!tile_only) {
+        if ((rc = dalloc(c, &c->w_kvr, nl * 3 * D * D))) return rc;
+        if ((rc = dalloc(c, &c->w_att, nl * D * D))) return rc;
+        if ((rc = dalloc(c, &c->w_frk, nl * 5 * D * D))) return rc;
+        if ((rc = dalloc(c, &c->w_fv, nl * 4 * D * D))) return rc;
     }
-    if (!rc && last) rc = retile(c, src, HEAD, 0, D, V, c->w_head, 1, 1, 0, staging);
-    // row sums of the re-tiled matrices (the 2^22 offset of the activation limbs is removed with them)
+    if (last && (rc = dalloc(c, &c->w_head, V * D))) return rc;
     if (!rc) rc = dalloc(c, &c->rs_kvr, nl * 3 * D);
     if (!rc) rc = dalloc(c, &c->rs_att, nl * D);
     if (!rc) rc = dalloc(c, &c->rs_frk, nl * 5 * D);
     if (!rc) rc = dalloc(c, &c->rs_fv, nl * D);
     if (!rc) rc = dalloc(c, &c->rs_head, V);
-    if (!rc) rc = dalloc(c, &c->rw_kvr, nl * 3 * D);
-    if (!rc) rc = dalloc(c, &c->rw_att, nl * D);
-    if (!rc) rc = dalloc(c, &c->rw_frk, nl * 5 * D);
-    if (!rc) rc = dalloc(c, &c->rw_fv, nl * D);
-    if (!rc) {
-        auto rowsum = [&](const uint8_t *w, unsigned *rs, unsigned *rw, uint64_t rows, uint64_t N) {
-            k_rowsum<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream>>>(w, rs, rw, (size_t)rows, (int)N, (int)D);
-        };
-        rowsum(c->w_kvr, c->rs_kvr, c->rw_kvr, nl * 3 * D, D);
-        rowsum(c->w_att, c->rs_att, c->rw_att, nl * D, D);
-        rowsum(c->w_frk, c->rs_frk, c->rw_frk, nl * 5 * D, D);
-        rowsum(c->w_fv, c->rs_fv, c->rw_fv, nl * D, 4 * D);
-        if (last) rowsum(c->w_head, c->rs_head, nullptr, V, D);
+    if (!rc && !tile_only) {
+        rc = dalloc(c, &c->rw_kvr, nl * 3 * D);
+        if (!rc) rc = dalloc(c, &c->rw_att, nl * D);
+        if (!rc) rc = dalloc(c, &c->rw_frk, nl * 5 * D);
+        if (!rc) rc = dalloc(c, &c->rw_fv, nl * D);
+    }
+    if (rc) return rc;
+    // tile images (+ octant row sums for the chunk path): per = bytes of one layer's image
+    const uint64_t cbD = (D + 15) / 16;
+    const uint64_t per_kvr = 3 * cbD * 16 * D, per_att = cbD * 16 * D, per_frk = 5 * cbD * 16 * D, per_fv = cbD * 16 * 4 * D;
+    if (need_b) {
+        if ((rc = dalloc(c, &c->b_kvr, nl * per_kvr))) return rc;
+        if ((rc = dalloc(c, &c->b_att, nl * per_att))) return rc;
+        if ((rc = dalloc(c, &c->b_frk, nl * per_frk))) return rc;
+        if ((rc = dalloc(c, &c->b_fv, nl * per_fv))) return rc;
+        if (want_seq) {
+            if ((rc = dalloc(c, &c->r8_kvr, nl * SEQ_O * 3 * D))) return rc;
+            if ((rc = dalloc(c, &c->r8_att, nl * SEQ_O * D))) return rc;
+            if ((rc = dalloc(c, &c->r8_frk, nl * SEQ_O * 5 * D))) return rc;
+            if ((rc = dalloc(c, &c->r8_fv, nl * SEQ_O * D))) return rc;
+        }
+    }
+    auto rowsum = [&](const uint8_t *w, unsigned *rs, unsigned *rw, uint64_t rows, uint64_t N) {
+        k_rowsum<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream>>>(w, rs, rw, (size_t)rows, (int)N, (int)D);
+    };
+    // one layer's matrix in row form (w_t[N][K]) -> its tile image (and octant row sums)
+    auto image = [&](const uint8_t *w_t, uint8_t *bdst, unsigned *r8dst, uint64_t N, uint64_t K, int Q, uint64_t per) {
+        k_bimage<<<dim3((unsigned)((per / 16 + 255) / 256)), dim3(256), 0, c->stream>>>(w_t, bdst, (int)N, (int)K, Q, (int)((((N + Q - 1) / Q) + 15) / 16));
+        if (r8dst) k_rowsum8<<<dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream>>>(w_t, r8dst, (int)N, (int)K);
+    };
+    uint8_t *staging = nullptr, *rowtmp = nullptr;
+    if (!src.on_device) HIPCHK(hipMalloc(reinterpret_cast<void **>(&staging), std::max<uint64_t>(4 * D * D, V * D)));
+    if (tile_only) HIPCHK(hipMalloc(reinterpret_cast<void **>(&rowtmp), 5 * D * D));
+    for (uint64_t l = l0; l < l1 && !rc; l++) {
+        const uint64_t lr = l - l0;
+        uint8_t *kvr = tile_only ? rowtmp : c->w_kvr + lr * 3 * D * D;
+        if (!rc) rc = retile(c, src, KM, l, D, D, kvr, 1, 3, 0, staging);
+        if (!rc) rc = retile(c, src, VM, l, D, D, kvr, 1, 3, 1, staging);
+        if (!rc) rc = retile(c, src, RM, l, D, D, kvr, 1, 3, 2, staging);
+        if (!rc) {
+            rowsum(kvr, c->rs_kvr + lr * 3 * D, tile_only ? nullptr : c->rw_kvr + lr * 3 * D, 3 * D, D);
+            if (need_b) image(kvr, c->b_kvr + lr * per_kvr, want_seq ? c->r8_kvr + lr * SEQ_O * 3 * D : nullptr, 3 * D, D, 3, per_kvr);
+        }
+        uint8_t *att = tile_only ? rowtmp : c->w_att + lr * D * D;
+        if (!rc) rc = retile(c, src, ATTOUT, l, D, D, att, 1, 1, 0, staging);
+        if (!rc) {
+            rowsum(att, c->rs_att + lr * D, tile_only ? nullptr : c->rw_att + lr * D, D, D);
+            if (need_b) image(att, c->b_att + lr * per_att, want_seq ? c->r8_att + lr * SEQ_O * D : nullptr, D, D, 1, per_att);
+        }
+        uint8_t *frk = tile_only ? rowtmp : c->w_frk + lr * 5 * D * D;
+        if (!rc) rc = retile(c, src, FFNK, l, D, 4 * D, frk, 4, 5, 0, staging);
+        if (!rc) rc = retile(c, src, FFNR, l, D, D, frk, 1, 5, 4, staging);
+        if (!rc) {
+            rowsum(frk, c->rs_frk + lr * 5 * D, tile_only ? nullptr : c->rw_frk + lr * 5 * D, 5 * D, D);
+            if (need_b) image(frk, c->b_frk + lr * per_frk, want_seq ? c->r8_frk + lr * SEQ_O * 5 * D : nullptr, 5 * D, D, 5, per_frk);
+        }
+        uint8_t *fvm = tile_only ? rowtmp : c->w_fv + lr * 4 * D * D;
+        if (!rc) rc = retile(c, src, FFNV, l, 4 * D, D, fvm, 1, 1, 0, staging);
+        if (!rc) {
+            rowsum(fvm, c->rs_fv + lr * D, tile_only ? nullptr : c->rw_fv + lr * D, D, 4 * D);
+            if (need_b) image(fvm, c->b_fv + lr * per_fv, want_seq ? c->r8_fv + lr * SEQ_O * D : nullptr, D, 4 * D, 1, per_fv);
+        }
+    }
+    if (!rc && last) {
+        rc = retile(c, src, HEAD, 0, D, V, c->w_head, 1, 1, 0, staging);
+        if (!rc) rowsum(c->w_head, c->rs_head, nullptr, V, D);
+        if (!rc && want_seq) {
+            const uint64_t cbV = (V + 15) / 16, per_head = cbV * 16 * D;
+            rc = dalloc(c, &c->b_head, per_head);
+            if (!rc) rc = dalloc(c, &c->r8_head, SEQ_O * V);
+            if (!rc) image(c->w_head, c->b_head, c->r8_head, V, D, 1, per_head);
+        }
     }
     hipError_t se = hipStreamSynchronize(c->stream);
     if (staging) (void)hipFree(staging);
+    if (rowtmp) (void)hipFree(rowtmp);
     if (rc) return rc;
     HIPCHK(se);
     HIPCHK(hipGetLastError());
@@ -862,8 +978,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
 
     // chunked path scratch
     {
-        const char *e = getenv("RWKV_SEQ");
-        if (max_ctx > 1 && D % 64 == 0 && !(e && e[0] == '0')) {
+        if (want_seq) {
             if ((rc = dalloc(c, &c->sq_tokens, (size_t)SQ_RING * SEQ_TM))) return rc;
             HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_sq_tokens), sizeof(unsigned long long) * SQ_RING * SEQ_TM, hipHostMallocDefault));
             for (int r = 0; r < SQ_RING; r++) HIPCHK(hipEventCreateWithFlags(&c->sq_ev[r], hipEventDisableTiming));
@@ -891,27 +1006,6 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
                 if ((rc = dalloc(c, &c->sq_pk3, (size_t)2 * SEQ_O * 3 * cbd * 512))) return rc;
                 if ((rc = dalloc(c, &c->sq_pk5, (size_t)2 * SEQ_O * 5 * cbd * 512))) return rc;
                 if ((rc = dalloc(c, &c->sq_pk1, (size_t)2 * SEQ_O * cbd * 512))) return rc;
-            }
-            // second resident copy of the matrices: MFMA B-operand images (seq.hip.h k_bimage) + row sums per octant of K
-            {
-                auto second = [&](const uint8_t *w_t, uint8_t **bdst, unsigned **rdst, uint64_t layers, uint64_t N, uint64_t K, int Q) -> int {
-                    const uint64_t nch = (N + Q - 1) / Q, cb = (nch + 15) / 16, per = (uint64_t)Q * cb * 16 * K;
-                    int r2 = dalloc(c, bdst, layers * per);
-                    if (!r2) r2 = dalloc(c, rdst, layers * SEQ_O * N);
-                    if (r2) return r2;
-                    for (uint64_t l = 0; l < layers; l++) {
-                        const uint64_t units = per / 16;
-                        k_bimage<<<dim3((unsigned)((units + 255) / 256)), dim3(256), 0, c->stream>>>(w_t + l * N * K, *bdst + l * per, (int)N, (int)K, Q, (int)cb);
-                        k_rowsum8<<<dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream>>>(w_t + l * N * K, *rdst + l * SEQ_O * N, (int)N, (int)K);
-                    }
-                    return 0;
-                };
-                if ((rc = second(c->w_kvr, &c->b_kvr, &c->r8_kvr, nl, 3 * D, D, 3))) return rc;
-                if ((rc = second(c->w_att, &c->b_att, &c->r8_att, nl, D, D, 1))) return rc;
-                if ((rc = second(c->w_frk, &c->b_frk, &c->r8_frk, nl, 5 * D, D, 5))) return rc;
-                if ((rc = second(c->w_fv, &c->b_fv, &c->r8_fv, nl, D, 4 * D, 1))) return rc;
-                if (last && (rc = second(c->w_head, &c->b_head, &c->r8_head, 1, V, D, 1))) return rc;
-                HIPCHK(hipGetLastError());
             }
             c->seq_ok = true;
         }
@@ -1334,6 +1428,7 @@ int rwkv_create(rwkv_ctx **out, int device)
     { const char *e = getenv("RWKV_SEQ_GRAPH"); if (e) c->seq_graph = atoi(e) != 0; }
     { const char *e = getenv("RWKV_SEQ_ROWS"); if (e) c->seq_rows = atoi(e) > SEQ_T ? SEQ_TM : SEQ_T; }
     { const char *e = getenv("RWKV_CARRY_EDGES"); if (e) c->carry_edges = atoi(e); }
+    { const char *e = getenv("RWKV_TILE"); if (e) c->tile = atoi(e); }
     {
         static std::atomic<unsigned> serial{0u};
         const unsigned long long t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((unsigned long long)(uintptr_t)c << 17);

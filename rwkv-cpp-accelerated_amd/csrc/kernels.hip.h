@@ -58,6 +58,11 @@ constexpr int RED_BYTES = 1024;  // LDS scratch for workgroup reductions
 #define RWKV_A6(a, ...) "s"(a), RWKV_A5(__VA_ARGS__)
 #define RWKV_A7(a, ...) "s"(a), RWKV_A6(__VA_ARGS__)
 #define RWKV_A8(a, ...) "s"(a), RWKV_A7(__VA_ARGS__)
+// the wave's index in its workgroup as a wave-UNIFORM value.  (threadIdx.x >> 6 is uniform in fact but "divergent" to the compiler: a role
+// branch on it -- loader / prologue / consumer -- is then compiled as exec-masked straight-line code, every wave walks through every
+// role's blocks, and hipcc's path-insensitive s_waitcnt insertion lets one role's pending loads tax another's: round 5 found an
+// s_waitcnt vmcnt(0) in k_att's LOADER loop -- draining its DMA queue -- that guarded a register a consumer-side load had been given.)
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ int block_lo(int n) { return (int)(((unsigned)blockIdx.x * (unsigned)n) / gridDim.x); }
 __device__ __forceinline__ int block_hi(int n) { return (int)((((unsigned)blockIdx.x + 1u) * (unsigned)n) / gridDim.x); }
 constexpr unsigned VOCAB = 50277u;
@@ -664,7 +669,7 @@ __device__ __forceinline__ void site_open(const SiteStatic &st, const SiteDyn &d
                                           u32x4 (&w)[R][S], u32x4 (&w2)[R][S], const uint8_t *wb, const uint8_t *wb2, size_t stride,
                                           SiteRed<NV> &sr, bool publish_stats, unsigned long long *tl)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int chunks = D >> 4, nqd = D >> 2;
     constexpr int NTP = SPLIT ? NT / 2 : NT, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
     float *bc = reinterpret_cast<float *>(red + RED_BC);
@@ -733,7 +738,7 @@ __device__ __forceinline__ void vec_open(const float *vec, const double *partS, 
                                          float &Sf, float &amax, unsigned long long *tl)
 {
     constexpr int XVD = xvd<S>();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int chunks = D >> 4, nqd = D >> 2;
     constexpr int NTP = SPLIT ? NT / 2 : NT, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
     float *bc = reinterpret_cast<float *>(red + RED_BC);
@@ -854,6 +859,12 @@ template <> __device__ __forceinline__ void dma_unit<5>(const uint8_t *src, unsi
 }
 #undef RWKV_DMA_L
 #undef RWKV_DMA_UNIT
+// First statement of every loader wave.  hipcc does not see the loader's DMA (inline asm), but it does remember every vector memory
+// operation the wave issued BEFORE the role branch -- the debug timeline's store, a kernel-entry load -- and guards the registers those
+// were given with s_waitcnt vmcnt(0) wherever the loader's code first reuses them: by the luck of register allocation that was inside
+// the loader's loop in one round-5 build of k_att (12.3 -> 16.8 us: a drain of the DMA queue per group).  A wait the compiler DOES see
+// (the builtin, not asm), placed where nothing of the DMA is in flight yet, settles its books: nothing is pending behind it.
+__device__ __forceinline__ void loader_clean_slate() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0) expcnt(7) lgkmcnt(15)
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 constexpr int GLDS_SPIN = 1 << 18;    // bound of every wait loop (a lost hand-off must end the kernel, not hang the GPU)
 // A wait that ran into its bound is RECORDED in a wave-uniform REGISTER (`fail`: no memory operation on any path that rejoins the
@@ -900,7 +911,7 @@ constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
 // TEST build only (-DRWKV_TEST_CORRUPT_CARRY=1): the loader flips one bit of the rows it carries for the next kernel, whose consumers
 // must notice (code 5) and fail the call
 #ifndef RWKV_CARRY_VERIFY
-#define RWKV_CARRY_VERIFY 1      // A/B knob: check carried rows against their row sums
+#define RWKV_CARRY_VERIFY 1      // A/B knob: check carried rows against their row sums (0: no check; 2: checked, but nobody waits for the verdict -- timing experiment only)
 #endif
 #ifndef RWKV_TEST_CORRUPT_CARRY
 #define RWKV_TEST_CORRUPT_CARRY 0
@@ -920,7 +931,11 @@ struct GldsCtl {            // LDS control block of the ring (80 dwords)
     unsigned gend[GLDS_FQ];    // the loader's own: end unit of group k
     unsigned stamp[4];         // carry (below): what the previous ring kernel left in the ring for this workgroup
     unsigned pad2[8];
+    unsigned csum[64];         // carry: the expected position-weighted sums of the carried groups (nrs per group), left by the PREVIOUS kernel beside
+                               // its stamp; NOT zeroed at entry (GLDS_CTL_ZERO words are): read by this kernel's verifying waves, rewritten at the
+                               // end of this kernel's consumer loop for the next one
 };
+constexpr int GLDS_CTL_ZERO = (int)(offsetof(GldsCtl, csum) / 4);
 // CARRY: the weight stream does not stop at the kernel boundary.  Weights do not depend on activations, a CU's LDS keeps its content
 // from one kernel to the next, and with one whole-LDS workgroup per CU block b of launch N + 1 lands on the CU block b of launch N
 // ran on (tools/ldskeep.hip, profiles/r03/ldskeep.txt: 256 / 256 blocks, every word intact, launch after launch and inside a
@@ -955,6 +970,8 @@ struct RingCarry {
     int pos0;                   // ring position of this kernel's first unit
     unsigned *hits;             // counters per workgroup, [block][4]: launches that found their rows / did not / carried groups re-loaded after a failed check
     int xq_bytes;               // LDS reserved for the staged vectors in front of the control block (the same for all kernels that carry)
+    const unsigned *rw_next;    // the next ring kernel's table of position-weighted sums: nrs_next words per group, its group g at rw_next[g * nrs_next]
+    int nrs_next;               //   (this kernel leaves the sums of the n_out groups it carries in GldsCtl::csum: n_out * nrs_next <= 64)
 };
 constexpr int NC = NW - 1;              // consumer waves of a ring kernel
 // LDS of k_att / k_ffn_rk / k_ffnv in ring form: [reduction scratch RED_BYTES][staged vectors: cy.xq_bytes][GldsCtl][ring: ns units of S KiB]
@@ -1100,6 +1117,7 @@ template <int R, int S, bool CARRY = false, class Base>
 __device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int nu, unsigned ring, GldsCtl *ctl, int lane,
                                                 const RingCarry &cy = RingCarry{})
 {
+    loader_clean_slate();
 #if RWKV_LOADER_PRIO
     __builtin_amdgcn_s_setprio(RWKV_LOADER_PRIO);     // the loader's instruction issue IS the stream's ceiling: let it win the SIMD's arbitration
 #endif
@@ -1112,7 +1130,7 @@ __device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_
         have = (int)have <= g1 - g0 ? have : 0u;
     }
     // the control block is this wave's to zero: nobody else touches it before the order barrier
-    for (int i = lane; i < (int)(sizeof(GldsCtl) / 4); i += 64) reinterpret_cast<unsigned *>(ctl)[i] = 0u;
+    for (int i = lane; i < GLDS_CTL_ZERO; i += 64) reinterpret_cast<unsigned *>(ctl)[i] = 0u;
     RingLoader<S> ld(ctl, ring, nu, chunks, lane, CARRY ? cy.pos0 : 0);
     if (CARRY && have) ld.template adopt<R>(have);
     int g = g0 + (int)have;
@@ -1164,15 +1182,27 @@ __device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, cons
     if (lane == 0) __hip_atomic_store(&ctl->freeq[kl % GLDS_FQ], (unsigned)kl + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // Rows that were CARRIED into this kernel (the first ctl->carried groups of the workgroup: they have been sitting in LDS since the
-// previous kernel, across a boundary at which another process's kernel may have had the CU) are checked before anybody is handed
-// them, and RE-LOADED where the check fails (round 4; round 3 failed the call): LDS content across a kernel boundary is not something
-// the programming model promises, so a damaged row must cost a reload, not the token.  The check is a POSITION-WEIGHTED sum of the
-// row's bytes -- sum over 16-byte pieces c of (c + 1) * sum_i (1 + i) u[16 c + i], modulo 2^32 -- against the table the engine builds
-// at load next to the row sums (`rw`, k_rowsum: nrs entries per group, the group's first at rw[g * nrs]); a plain byte sum (round 3)
-// passes any permutation and any pair of compensating changes.  Run by the consumer waves that have nothing to do while waves 0..3
-// stage the vector (widx of nw), straight from the ring, off the streaming loop; every consumer waits for `verified` behind the
-// "staged" wait (it has long been reached by then).  The repair is a plain copy global -> registers -> ring by the wave that found
-// the damage: cold path, compiler-visible loads, nothing of it in the streaming loop.
+// previous kernel, across a boundary at which another process's kernel may have had the CU) are checked before they are used, and
+// RE-LOADED where the check fails (round 4; round 3 failed the call): LDS content across a kernel boundary is not something the
+// programming model promises, so a damaged row must cost a reload, not the token.  The check is a POSITION-WEIGHTED sum of the row's
+// bytes -- sum over 16-byte pieces c of (c + 1) * sum_i (1 + i) u[16 c + i], modulo 2^32 -- against the table the engine builds at load
+// next to the row sums (`rw`, k_rowsum: nrs entries per group); a plain byte sum (round 3) passes any permutation and any pair of
+// compensating changes.
+//
+// WHO checks, WHEN, against WHAT decides whether the check is free (round 5; profiles/r05/r04_regression_bisect.txt, carry_verify_timeline*.txt).
+// Round 4 had the idle consumer waves check the carried groups in the ring while waves 0..3 staged the vector, and every consumer waited
+// for their verdict behind "staged".  Measured, that wait cost exactly what the carry gains (7B: 567 tokens/s with it, 568 with the carry
+// off, 581 with the check compiled out): the verdict on a 20 KiB group came in 2-2.4 us behind the order barrier -- AFTER the vectors were
+// staged -- (a) because its expected sum was a cold 4-byte load from the table, queued behind the DMA stream and the prologue's 100 KB
+// (requested at kernel entry or behind the barrier alike, it returned at 3.9-4.4 us), and (b) because twenty LDS round trips under the
+// loader's stream are slow whoever makes them.  So:
+//   * the expected sums travel WITH the rows: a consumer wave of the PRODUCING kernel fetches the next kernel's sums from the table while
+//     it has nothing to wait for (carry_next_sums) and leaves them in GldsCtl::csum behind the kernel's closing barrier; the check compares
+//     LDS against LDS.  What it defends against is unchanged: rows damaged while they sat in LDS do not match the table's sums (a copy our
+//     own kernel made, under the same stamp); a damaged copy of the sums fails the check too and costs a reload, never a wrong row;
+//   * the wave that TAKES a carried group checks it, in the registers glds_take has just filled (the reads are the take's own): 6 VALU
+//     instructions per 16 weight bytes on the first group of at most `carried` waves, no pass over the ring, no verdict anybody waits for;
+//     a group that fails is loaded again from memory straight into those registers (cold path, compiler-visible loads).
 constexpr unsigned CK_PAT0 = 0x04030201u, CK_PAT1 = 0x08070605u, CK_PAT2 = 0x0c0b0a09u, CK_PAT3 = 0x100f0e0du;
 __device__ __forceinline__ unsigned ck_piece(const u32x4 &w, int c)
 {
@@ -1182,44 +1212,45 @@ __device__ __forceinline__ unsigned ck_piece(const u32x4 &w, int c)
     t = __builtin_amdgcn_udot4(w[3], CK_PAT3, t, false);
     return t * (unsigned)(c + 1);
 }
-struct CarryCheck { unsigned char *ring; int nu, pos0, chunks, g0; const unsigned *rw; int nrs; const uint8_t *w; unsigned *hits; };
+struct CarryCheck { int chunks, g0, nrs; const uint8_t *w; unsigned *hits; };
+// k = the group's index in the workgroup (< ctl->carried); w = its rows as glds_take left them
 template <int R, int S>
-__device__ __forceinline__ void carry_verify(const CarryCheck &ck, GldsCtl *ctl, int lane, int widx, int nw)
+__device__ __forceinline__ void carry_check_taken(u32x4 (&w)[R][S], int k, const CarryCheck &ck, const GldsCtl *ctl, int lane)
 {
-    const int ncar = (int)ctl->carried;
-    for (int k = widx; k < ncar; k += nw) {
-        unsigned want = 0u;
-        if (lane < ck.nrs) want = ck.rw[(size_t)(ck.g0 + k) * ck.nrs + lane];
-        unsigned t = 0u;
-        unsigned p0 = ((unsigned)ck.pos0 + (unsigned)k * R) % (unsigned)ck.nu;
+    const unsigned want = lane < ck.nrs ? ctl->csum[(k * ck.nrs + lane) & 63] : 0u;
+    unsigned t = 0u;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const u32x4 *p = reinterpret_cast<const u32x4 *>(ck.ring + (size_t)p0 * (S * 1024)) + lane;
+    for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int s = 0; s < S; s++)
-                if (lane + 64 * s < ck.chunks) t += ck_piece(p[s * 64], lane + 64 * s);
-            p0 = p0 + 1 == (unsigned)ck.nu ? 0u : p0 + 1;
-        }
-        if (wave_sum_dpp(t) != wave_sum_dpp(want)) {
-            // damaged: this group's rows once more, from memory into the ring (the layout the DMA writes: piece s of a unit holds
-            // the row's 16-byte chunk min(lane + 64 s, chunks - 1) at lane * 16)
-            const uint8_t *src = ck.w + (size_t)(ck.g0 + k) * R * ((size_t)ck.chunks << 4);
-            unsigned q0 = ((unsigned)ck.pos0 + (unsigned)k * R) % (unsigned)ck.nu;
-            for (int r = 0; r < R; r++) {
-                u32x4 *p = reinterpret_cast<u32x4 *>(ck.ring + (size_t)q0 * (S * 1024)) + lane;
+        for (int s = 0; s < S; s++)
+            if (lane + 64 * s < ck.chunks) t += ck_piece(w[r][s], lane + 64 * s);
+    if (wave_sum_dpp(t) != wave_sum_dpp(want)) {
+        const uint8_t *src = ck.w + (size_t)(ck.g0 + k) * R * ((size_t)ck.chunks << 4);
 #pragma unroll
-                for (int s = 0; s < S; s++) {
-                    int c = lane + 64 * s;
-                    c = c < ck.chunks ? c : ck.chunks - 1;
-                    p[s * 64] = *reinterpret_cast<const u32x4 *>(src + (size_t)r * ((size_t)ck.chunks << 4) + ((size_t)c << 4));
-                }
-                q0 = q0 + 1 == (unsigned)ck.nu ? 0u : q0 + 1;
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                int c = lane + 64 * s;
+                c = c < ck.chunks ? c : ck.chunks - 1;
+                w[r][s] = *reinterpret_cast<const u32x4 *>(src + (size_t)r * ((size_t)ck.chunks << 4) + ((size_t)c << 4));
             }
-            if (ck.hits != nullptr && lane == 0) __hip_atomic_fetch_add(ck.hits + (size_t)blockIdx.x * 4 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (ck.hits != nullptr && lane == 0) __hip_atomic_fetch_add(ck.hits + (size_t)blockIdx.x * 4 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane == 0) __hip_atomic_fetch_add(&ctl->verified, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// the producing side of the sums: requested by ONE consumer wave once the vectors are staged (nothing waits for them), stored behind the
+// kernel's closing barrier (every wave of this kernel is past the check of the sums IT was left)
+__device__ __forceinline__ unsigned carry_next_sums(const RingCarry &cy, int lane)
+{
+    unsigned v = 0u;
+    if (cy.n_out > 0 && lane < cy.n_out * cy.nrs_next) v = cy.rw_next[(size_t)block_lo(cy.groups_next) * cy.nrs_next + lane];
+    return v;
+}
+__device__ __forceinline__ void carry_leave_sums(const RingCarry &cy, GldsCtl *ctl, int lane, unsigned v)
+{
+    if (cy.n_out > 0 && lane < cy.n_out * cy.nrs_next) ctl->csum[lane] = v;
+}
+constexpr int CARRY_SUMS_WAVE = NT / 2 / 64 + 2;      // wave 6: the verifying wave with the fewest groups
+
 // EARLY TAKE (round 4).  The ring holds what HBM delivers while waves 0..3 run the prologue; when the prologue outlasts the ring --
 // 14B: vectors staged at 6.5 us, the ring (110-125 KiB) full at 4.4-5 us, the loader idle for ~2 us of every k_att / k_ffn_rk launch
 // (profiles/r04/timelines_14B_1B5.txt) -- the stream waits for the consumers.  The consumer waves that do NOT stage (4..6) therefore take
@@ -1242,7 +1273,8 @@ template <int S> __device__ __forceinline__ constexpr bool early_take() { return
 // with RWKV_CARRY > 0) gets the early take switched off in the carry instances instead of unverified rows.
 template <int R, int S, int PAT, bool CARRIED = false, class Pre, class Epi, class Ready>
 __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
-                                            int chunks, Pre pre, Epi epi, Ready ready, unsigned &fail, unsigned long long *g_tl_groups = nullptr, int pos0 = 0)
+                                            int chunks, Pre pre, Epi epi, Ready ready, unsigned &fail, unsigned long long *g_tl_groups = nullptr, int pos0 = 0,
+                                            const CarryCheck &ck = CarryCheck{})
 {
 #ifdef RWKV_TL_GROUPS
     // debug build (tools/timeline.py): where a consumer wave's time goes.  Stamps of the wave: 1 inputs of its first group requested,
@@ -1263,6 +1295,10 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
         u32x4 w[R][S];
         glds_take<R, S>(w, g - g0, nu, ring, ctl, lane, fail, pos0);
         if (first) { ready(); if (late_pre) in = pre(g); first = false; }
+        if constexpr (CARRIED && RWKV_CARRY_VERIFY == 1) {
+            // (`carried` was set by the loader in front of the order barrier; only a wave's first group can be a carried one: carried <= NC)
+            if (g - g0 < __builtin_amdgcn_readfirstlane((int)ctl->carried)) carry_check_taken<R, S>(w, g - g0, ck, ctl, lane);
+        }
 #ifdef RWKV_TL_GROUPS
         asm volatile("" : "+v"(w[R - 1][S - 1]));
         if (rr < 1) tl_stamp(g_tl_groups, 2);
@@ -1299,20 +1335,19 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
 // ring kernels: the control block is zeroed before the order barrier
 __device__ __forceinline__ void ring_init(GldsCtl *gc)
 {
-    if (threadIdx.x < sizeof(GldsCtl) / 4) reinterpret_cast<unsigned *>(gc)[threadIdx.x] = 0u;
+    if (threadIdx.x < (unsigned)GLDS_CTL_ZERO) reinterpret_cast<unsigned *>(gc)[threadIdx.x] = 0u;
 }
 // LayerNorm-site prologue of a ring kernel, called by the consumer waves (wave < NC): waves 0..3 stage the NV vectors and
 // publish the scalars, the others wait; contains the workgroup's order barrier, which the loader executes once as well
 template <int NV, int S, int RC = 0>
 __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &dy, const double *x, int D, double *red, unsigned *xq,
-                                          bool publish_stats, GldsCtl *gc, unsigned long long *tl, unsigned &fail,
-                                          const CarryCheck &ck = CarryCheck{})
+                                          bool publish_stats, GldsCtl *gc, unsigned long long *tl, unsigned &fail)
 {
     constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
     const int nqd = D >> 2;
     float *bc = reinterpret_cast<float *>(red + RED_BC);
     unsigned *spin = reinterpret_cast<unsigned *>(bc + 8);
-    if ((int)(threadIdx.x >> 6) < NWP) {
+    if (wave_id() < NWP) {
         double tc[NV];
         float mc[NV];
 #pragma unroll
@@ -1346,10 +1381,6 @@ __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &d
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&gc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         __syncthreads();   // order
-        if constexpr (RC > 0) {
-            carry_verify<RC, S>(ck, gc, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6) - NWP, NC - NWP);
-            wait_count(&gc->verified, NC - NWP, fail);      // these waves take the first (= the carried) groups next: all of them checked
-        }
     }
 }
 // ... and its second half, run by every consumer wave inside its first group (ring_groups' ready()): the vectors are staged, the
@@ -1360,7 +1391,6 @@ __device__ __forceinline__ void ring_site_ready(double *red, GldsCtl *gc, SiteRe
     constexpr int NWP = NT / 2 / 64;
     float *bc = reinterpret_cast<float *>(red + RED_BC);
     wait_count(&gc->staged, NWP, fail);
-    if constexpr (RC > 0) wait_count(&gc->verified, NC - NWP, fail);
 #pragma unroll
     for (int m = 0; m < NV; m++) { sr.S[m] = (double)bc[m]; sr.amax[m] = bc[4 + m]; }
     sr.mean = sr.rstd = 0.0;
@@ -1369,11 +1399,11 @@ __device__ __forceinline__ void ring_site_ready(double *red, GldsCtl *gc, SiteRe
 // plain-vector prologue of a ring kernel (k_attout, k_ffnv), same roles
 template <int NVEC, int S, int RC = 0>
 __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, const float *partM, int n_part, int D, double *red, unsigned *xq,
-                                         GldsCtl *gc, unsigned long long *tl, unsigned &fail, const CarryCheck &ck = CarryCheck{})
+                                         GldsCtl *gc, unsigned long long *tl, unsigned &fail)
 {
     constexpr int XVD = xvd<S>();
     constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (S * 256 + NTP - 1) / NTP;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nqd = D >> 2;
+    const int lane = threadIdx.x & 63, wave = wave_id(), nqd = D >> 2;
     float *bc = reinterpret_cast<float *>(red + RED_BC);
     unsigned *spin = reinterpret_cast<unsigned *>(bc + 8);
     if (wave < NWP) {
@@ -1414,10 +1444,6 @@ __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, 
         if (lane == 0) __hip_atomic_fetch_add(&gc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         __syncthreads();   // order
-        if constexpr (RC > 0) {
-            carry_verify<RC, S>(ck, gc, lane, wave - NWP, NC - NWP);
-            wait_count(&gc->verified, NC - NWP, fail);
-        }
     }
 }
 template <int RC>
@@ -1426,7 +1452,6 @@ __device__ __forceinline__ void ring_vec_ready(double *red, GldsCtl *gc, float &
     constexpr int NWP = NT / 2 / 64;
     float *bc = reinterpret_cast<float *>(red + RED_BC);
     wait_count(&gc->staged, NWP, fail);
-    if constexpr (RC > 0) wait_count(&gc->verified, NC - NWP, fail);
     Sf = bc[0]; amax = bc[4];
     tl_stamp(tl, 5);
 }
@@ -1507,12 +1532,15 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
     const int chunks = D >> 4;
     if constexpr (RING) RWKV_ARGS_NOW(a.x, a.st.C, a.st.TC, a.st.maxC, a.dy.B, a.dy.pd, a.dy.pf, a.dy.n_part);
     const int g0 = block_lo(D);
     const int g1 = block_hi(D);
-    const size_t so = (size_t)a.ctl->slot * a.slot_stride;
+    // (not on the loader wave: a compiler-visible load pending there makes hipcc guard the register it was given with s_waitcnt vmcnt(0)
+    // wherever the loader's code happens to reuse it -- in round 5 that was inside the loader's loop, i.e. a drain of its DMA queue per group)
+    size_t so = 0;
+    if (!RING || wave != NC) so = (size_t)a.ctl->slot * a.slot_stride;
 
     tl_stamp(a.tl, 0);
     // every wave requests its first groups, even one without work (it re-reads a neighbour's rows): a
@@ -1555,6 +1583,8 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
         }
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
+    GldsCtl *gcc = nullptr;    // carry instances: the ring's control block and the next ring kernel's expected sums (carry_next_sums), left there
+    unsigned nx = 0u;          // behind the closing barrier
     if constexpr (RING) {
         constexpr bool CARRY = RING == 2;      // the stream crosses the kernel boundaries (kernels.hip.h "CARRY"): common ring geometry
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : 3 * S * 3072));
@@ -1564,9 +1594,12 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
             tl_stamp(a.tl, 2);
         } else {
             constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 3 : 0;
-            ring_site<3, S, RC>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, 3, a.w, a.cy.hits});
+            ring_site<3, S, RC>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail);
+            const CarryCheck ck{chunks, g0, 3, a.w, a.cy.hits};
+            gcc = gc;
+            if (CARRY && wave == CARRY_SUMS_WAVE) nx = carry_next_sums(a.cy, lane);      // the next ring kernel's expected sums: nothing waits for them
             auto ready = [&]() { SiteRed<3> sr; ring_site_ready<3, RC>(red, gc, sr, fail, a.tl); scalars(sr); };
-            ring_groups<3, S, PAT_PER_ROW, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
+            ring_groups<3, S, PAT_PER_ROW, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0, ck);
         }
     } else {
         u32x4 wA[3][S], wB[3][S];
@@ -1580,6 +1613,7 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     }
     tl_stamp(a.tl, 6);
     __syncthreads();   // every wave is past its last read of the reduction scratch
+    if constexpr (RING == 2) { if (wave == CARRY_SUMS_WAVE) carry_leave_sums(a.cy, gcc, lane, nx); }
     block_sum_max(part, pmax, red + RED_PART);
     if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
     if constexpr (RING) ring_report(fail, a.herr);
@@ -1620,7 +1654,7 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
     const int chunks = D >> 4;
     tl_stamp(a.tl, 0);
     if constexpr (RING) RWKV_ARGS_NOW(a.ybuf, a.partS, a.partM, a.n_part);
@@ -1628,8 +1662,9 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
     const int g0 = block_lo(G);
     const int g1 = block_hi(G);
 
-    const double mean1 = a.lnstat[0], rstd1 = a.lnstat[1];
-    const size_t so = (size_t)a.ctl->slot * a.slot_stride;
+    double mean1 = 0.0, rstd1 = 1.0;
+    size_t so = 0;
+    if (!RING || wave != NC) { mean1 = a.lnstat[0]; rstd1 = a.lnstat[1]; so = (size_t)a.ctl->slot * a.slot_stride; }      // (not on the loader wave: see k_att)
     auto base = [&](int gg) {
         int row = (gg < g1 ? gg : (g1 > g0 ? g1 - 1 : 0)) * R;
         if (row > D - R) row = D - R;          // the last group may overlap the previous one
@@ -1663,6 +1698,8 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
         }
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
+    GldsCtl *gcc = nullptr;    // carry instances: the ring's control block and the next ring kernel's expected sums (carry_next_sums), left there
+    unsigned nx = 0u;          // behind the closing barrier
     if constexpr (RING) {
         constexpr bool CARRY = RING == 2;      // (needs D % R == 0: no overlapping last group)
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : S * 3072));
@@ -1672,9 +1709,12 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
             tl_stamp(a.tl, 2);
         } else {
             constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? R : 0;
-            ring_vec<1, S, RC>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, R, a.w, a.cy.hits});
+            ring_vec<1, S, RC>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail);
+            const CarryCheck ck{chunks, g0, R, a.w, a.cy.hits};
+            gcc = gc;
+            if (CARRY && wave == CARRY_SUMS_WAVE) nx = carry_next_sums(a.cy, lane);      // the next ring kernel's expected sums: nothing waits for them
             auto ready = [&]() { ring_vec_ready<RC>(red, gc, Sf, amax, fail, a.tl); sc = scale_of(amax); };
-            ring_groups<R, S, PAT_SHARED, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, nullptr, CARRY ? a.cy.pos0 : 0);
+            ring_groups<R, S, PAT_SHARED, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, nullptr, CARRY ? a.cy.pos0 : 0, ck);
         }
     } else {
         u32x4 wA[R][S], wB[R][S];
@@ -1686,6 +1726,7 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
         stream_groups<R, S, PAT_SHARED, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base, pre, epi);
     }
     __syncthreads();   // every wave is past its last read of the reduction scratch (and of the staged vector / the ring)
+    if constexpr (RING == 2) { if (wave == CARRY_SUMS_WAVE) carry_leave_sums(a.cy, gcc, lane, nx); }
     tl_stamp(a.tl, 6);
     site_publish<2, R>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
     if constexpr (RING) ring_report(fail, a.herr);
@@ -1721,7 +1762,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
     const int chunks = D >> 4;
     if constexpr (RING) RWKV_ARGS_NOW(a.x, a.st.C, a.st.TC, a.st.maxC, a.dy.B, a.dy.pd, a.dy.pf, a.dy.n_part);
     const int g0 = block_lo(D);
@@ -1762,6 +1803,8 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
         }
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
+    GldsCtl *gcc = nullptr;    // carry instances: the ring's control block and the next ring kernel's expected sums (carry_next_sums), left there
+    unsigned nx = 0u;          // behind the closing barrier
     if constexpr (RING) {
         constexpr bool CARRY = RING == 2;      // the stream crosses the kernel boundaries (kernels.hip.h "CARRY"): common ring geometry
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : 2 * S * 3072));
@@ -1771,9 +1814,12 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
             tl_stamp(a.tl, 2);
         } else {
             constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 5 : 0;
-            ring_site<2, S, RC>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, 5, a.w, a.cy.hits});
+            ring_site<2, S, RC>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail);
+            const CarryCheck ck{chunks, g0, 5, a.w, a.cy.hits};
+            gcc = gc;
+            if (CARRY && wave == CARRY_SUMS_WAVE) nx = carry_next_sums(a.cy, lane);      // the next ring kernel's expected sums: nothing waits for them
             auto ready = [&]() { SiteRed<2> sr; ring_site_ready<2, RC>(red, gc, sr, fail, a.tl); scalars(sr); };
-            ring_groups<5, S, PAT_FFN_RK, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
+            ring_groups<5, S, PAT_FFN_RK, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0, ck);
         }
     } else {
         u32x4 wA[5][S], wB[5][S];
@@ -1787,6 +1833,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     }
     tl_stamp(a.tl, 6);
     __syncthreads();   // every wave is past its last read of the reduction scratch
+    if constexpr (RING == 2) { if (wave == CARRY_SUMS_WAVE) carry_leave_sums(a.cy, gcc, lane, nx); }
     block_sum_max(part, pmax, red + RED_PART);
     if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
     if constexpr (RING) ring_report(fail, a.herr);
@@ -1827,15 +1874,16 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
     const int chunks = D >> 4;
     if constexpr (RING) RWKV_ARGS_NOW(a.hbuf, a.partS, a.partM, a.n_part);
     tl_stamp(a.tl, 0);
     const int g0 = block_lo(D);
     const int g1 = block_hi(D);
 
-    const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
-    const size_t so = (size_t)a.ctl->slot * a.slot_stride;
+    double mean2 = 0.0, rstd2 = 1.0;
+    size_t so = 0;
+    if (!RING || wave != NC) { mean2 = a.lnstat[0]; rstd2 = a.lnstat[1]; so = (size_t)a.ctl->slot * a.slot_stride; }      // (not on the loader wave: see k_att)
     auto base = [&](int g) { return a.w + (size_t)(g < g1 ? g : (g1 > g0 ? g1 - 1 : 0)) * 4 * D; };
     float Sf, amax;   // one scale for the whole 4D hidden vector
     double sc;
@@ -1860,6 +1908,8 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
         }
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
+    GldsCtl *gcc = nullptr;    // carry instances: the ring's control block and the next ring kernel's expected sums (carry_next_sums), left there
+    unsigned nx = 0u;          // behind the closing barrier
     if constexpr (RING) {
         constexpr bool CARRY = RING == 2;      // the stream crosses the kernel boundaries (kernels.hip.h "CARRY"): common ring geometry
         GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : 4 * S * 3072));
@@ -1869,9 +1919,12 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
             tl_stamp(a.tl, 2);
         } else {
             constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 4 : 0;
-            ring_vec<4, S, RC>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail, CarryCheck{ring, a.ns, a.cy.pos0, chunks, g0, a.rw, 1, a.w, a.cy.hits});
+            ring_vec<4, S, RC>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail);
+            const CarryCheck ck{chunks, g0, 1, a.w, a.cy.hits};
+            gcc = gc;
+            if (CARRY && wave == CARRY_SUMS_WAVE) nx = carry_next_sums(a.cy, lane);      // the next ring kernel's expected sums: nothing waits for them
             auto ready = [&]() { ring_vec_ready<RC>(red, gc, Sf, amax, fail, a.tl); sc = scale_of(amax); };
-            ring_groups<4, S, PAT_PER_ROW, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0);
+            ring_groups<4, S, PAT_PER_ROW, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0, ck);
         }
     } else {
         u32x4 wA[4][S], wB[4][S];
@@ -1883,6 +1936,7 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
         stream_groups<4, S, PAT_PER_ROW, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base, pre, epi);
     }
     __syncthreads();   // every wave is past its last read of the reduction scratch
+    if constexpr (RING == 2) { if (wave == CARRY_SUMS_WAVE) carry_leave_sums(a.cy, gcc, lane, nx); }
     tl_stamp(a.tl, 6);
     site_publish<NVN, 1>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
     if constexpr (RING) ring_report(fail, a.herr);
@@ -1916,13 +1970,14 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
     float *bval = reinterpret_cast<float *>(xq + XVD);
     unsigned *bidx = reinterpret_cast<unsigned *>(bval + NW);
-    const int D = a.D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
     const int chunks = D >> 4;
     const int V = (int)VOCAB;
     const int G = (V + R - 1) / R;
     const int g0 = block_lo(G);
     const int g1 = block_hi(G);
-    float *lg = a.logits + (size_t)a.ctl->out_row * V;   // read at entry: behind the prologue's barriers it is a cold scalar load
+    float *lg = a.logits;                                  // read at entry: behind the prologue's barriers it is a cold load (not on the loader wave: see k_att)
+    if (!RING || wave != NC) lg = a.logits + (size_t)a.ctl->out_row * V;
 
     auto base = [&](int gg) {
         int row = (gg < g1 ? gg : (g1 > g0 ? g1 - 1 : 0)) * R;
@@ -2033,7 +2088,7 @@ __global__ __launch_bounds__(NT) void k_mm8(Mm8Args a)
     constexpr int NVQ = QUARTERS ? 4 : 1;
     double *red = reinterpret_cast<double *>(smem);
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int Dq = QUARTERS ? a.N / 4 : a.N;
     const int chunks = Dq >> 4, nqd = Dq >> 2;
     const int M = a.M;

@@ -1,0 +1,751 @@
+// tile.hip.h -- TILE-FORM decode kernel for ffn k/r (round 5; the gate the round-4 review set for "decode on the MFMA B-operand image":
+// built for k_ffn_rk first, measured against the row-form ring kernel on one box; see DESIGN.md 4.7 for the outcome and for why the tile
+// image cannot serve every model width).
+//
+// The row-form decode kernels (kernels.hip.h) stream a matrix re-tiled to row-per-output order: a wave owns whole rows, a lane 16 bytes of
+// a row per step, every row ends in three 6-step DPP reductions and an epilogue on one lane.  This kernel consumes the image the chunk
+// path already holds (seq.hip.h k_bimage): [16-row tile][k-block of 64][lane][16 B], lane = 16 * (k-quarter) + row, bytes SIGNED (u - 128).
+//   * a wave instruction's 1 KiB is 64 inputs of 16 rows: lane l accumulates row l % 16 over quarter l / 16 of every k-block it meets --
+//     no cross-lane reduction per row at all; the four quarters of a row and the k-ranges of different waves meet as exact integer adds
+//     in LDS (ds_add_u32: the sums are integers, so the order they arrive in changes nothing);
+//   * the ring unit is S KiB = S k-blocks of ONE tile (contiguous in the image: one dma_unit), units go round-robin to the 7 consumer
+//     waves, every unit is freed as soon as its S ds_read_b128 are in the LDS queue: fine-grained turnover, all waves busy from the
+//     first unit on (row form: 5 groups of 20 KiB in the ring for 7 waves);
+//   * the wave whose add completes a tile runs that tile's 16 epilogues side by side on 16 lanes;
+//   * activations: the same 23-bit fixed point, limbs stored SIGNED (limb - 128) so that v_dot4_i32_i8 multiplies the image's bytes as
+//     they are: sum u l = dot + 128 rowsum(u) + 128 sum(l) - 16384 N, folded into one constant per vector (cA) and the row-sum
+//     coefficient 4227200 the chunk path uses (seq.hip.h SEQ_CU).  Every row value is the SAME exact integer as in row form: the
+//     kernel's hbuf / rgate are bit-identical to k_ffn_rk's.
+//   * staged vector layout [k-block][quarter][limb][16 B]: a lane's operand is one ds_read_b128, 16 lanes share an address (broadcast).
+// Integer contraction on the VALU, like row form; MFMA stays where the north_star puts it (the batched mm8_seq case).
+#pragma once
+#include "kernels.hip.h"
+
+namespace rwkvk {
+
+constexpr double TILE_CU = 4227200.0;          // 128 * (1 + 256 + 65536) - 2^22: coefficient of the unsigned row sum (= seq.hip.h SEQ_CU)
+constexpr double TILE_CN = -1077952512.0;      // -16384 * 65793: coefficient of N (elements of the vector) beside 128 * sum_j (q_j + 2^22)
+
+struct TileCtl {                 // LDS control block of a tile-form ring
+    unsigned staged;             // prologue waves that have staged their part of the vectors
+    unsigned landed;             // ring units whose DMA has completed (loader -> consumers, monotonic)
+    unsigned freed[8];           // freed[w]: units consumer wave w has copied out of the ring (its units are w, w + 7, w + 14, ...)
+    unsigned tcnt[8];            // per tile of the workgroup: units already added into tsum
+    unsigned pad[2];
+    unsigned long long sq[4];    // per staged vector: sum of (q_j + 2^22) over its elements (one ds_add_u64 per staging wave)
+    unsigned dump[64];           // where lanes 1..63 of the loader put their copy of `landed` (a store by ALL lanes needs no exec juggling: two instructions)
+};
+static_assert(sizeof(TileCtl) % 16 == 0, "ring behind the control block stays 16-byte aligned");
+
+// stage 4 consecutive elements (quad qd) of a vector in TILE layout: dword dw of (k-block kb, quarter qq, limb b) at
+// xq[kb * 48 + qq * 12 + b * 4 + dw], bytes = limb - 128.  Returns the sum of the four 23-bit values (q + 2^22) for the cA constant.
+__device__ __forceinline__ unsigned stage_quad_t(unsigned *xq, int qd, const float (&xr)[4], float inv_s)
+{
+    unsigned t[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) t[e] = __float_as_uint(fmaf(xr[e], inv_s, QMAGIC));
+    const unsigned p01 = __builtin_amdgcn_perm(t[1], t[0], 0x05010400u);
+    const unsigned p23 = __builtin_amdgcn_perm(t[3], t[2], 0x05010400u);
+    const unsigned h01 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u);
+    const unsigned h23 = __builtin_amdgcn_perm(t[3], t[2], 0x0c0c0602u);
+    const unsigned d0 = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+    const unsigned d1 = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+    const unsigned d2 = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
+    unsigned *p = xq + (qd >> 4) * 48 + ((qd >> 2) & 3) * 12 + (qd & 3);
+    p[0] = d0 ^ 0x80808080u;
+    p[4] = d1 ^ 0x80808080u;
+    p[8] = d2 ^ 0x80808080u;
+    return (t[0] & 0x7fffffu) + (t[1] & 0x7fffffu) + (t[2] & 0x7fffffu) + (t[3] & 0x7fffffu);
+}
+
+// LayerNorm-site prologue of a tile-form kernel, run by waves 0..3 (the other consumer waves and the loader meet them at the order
+// barrier inside); same ownership split as ring_site (kernels.hip.h).  SD = ceil(D / 1024).
+template <int NV, int SD>
+__device__ __forceinline__ void tile_site(const SiteStatic &st, const SiteDyn &dy, const double *x, int D, double *red, unsigned *xq, int xvd_t,
+                                          bool publish_stats, TileCtl *tc, unsigned long long *tl)
+{
+    constexpr int NTP = NT / 2, NWP = NTP / 64, NQP = (SD * 256 + NTP - 1) / NTP;
+    const int nqd = D >> 2;
+    float *bc = reinterpret_cast<float *>(red + RED_BC);
+    unsigned *spin = reinterpret_cast<unsigned *>(bc + 8);
+    double tcs[NV];
+    float mc[NV];
+#pragma unroll
+    for (int m = 0; m < NV; m++) { tcs[m] = st.TC[m]; mc[m] = st.maxC[m]; }
+    SiteTuple tup;
+    site_tuple_load(dy, tup);
+    double xl[NQP][4];
+    f32x4 Cq[NQP][NV], Bq[NQP][NV];
+#pragma unroll
+    for (int i = 0; i < NQP; i++) {
+        const int qd = threadIdx.x + i * NTP, qc = qd < nqd ? qd : nqd - 1;
+        load_quad_f64(x, qc, xl[i]);
+#pragma unroll
+        for (int m = 0; m < NV; m++) {
+            Cq[i][m] = reinterpret_cast<const f32x4 *>(st.C + (size_t)m * D)[qc];
+            Bq[i][m] = reinterpret_cast<const f32x4 *>(dy.B + (size_t)m * D)[qc];
+        }
+    }
+    tl_stamp(tl, 1);
+    if (threadIdx.x == 0) *spin = 0u;
+    __syncthreads();   // order
+    SiteRed<NV> r;
+    site_reduce<NV, NWP>(st, dy, tup, D, red, r, tcs, mc, tl, spin);
+    if (publish_stats && blockIdx.x == 0 && threadIdx.x == 0) { dy.lnstat[0] = r.mean; dy.lnstat[1] = r.rstd; }
+    tl_stamp(tl, 4);
+    const float rstdf = (float)r.rstd;
+    unsigned long long sq[NV];
+#pragma unroll
+    for (int m = 0; m < NV; m++) sq[m] = 0ull;
+#pragma unroll
+    for (int i = 0; i < NQP; i++) {
+        const int qd = threadIdx.x + i * NTP;
+        if (qd < nqd) {
+            float xh[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) xh[e] = (float)(xl[i][e] - r.mean) * rstdf;
+#pragma unroll
+            for (int m = 0; m < NV; m++) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaf(Cq[i][m][e], xh[e], Bq[i][m][e]);
+                sq[m] += stage_quad_t(xq + m * xvd_t, qd, v, inv_scale(r.amax[m]));
+            }
+        }
+    }
+    // one LDS atomic per wave and vector (64 lanes on one address would serialise in the LDS pipe under the DMA stream): the thread sums
+    // (< 2^27 each) are folded on the DPP network in two 32-bit halves that cannot overflow
+#pragma unroll
+    for (int m = 0; m < NV; m++) {
+        const unsigned lo = wave_sum_dpp((unsigned)sq[m] & 0xffffu), hi = wave_sum_dpp((unsigned)(sq[m] >> 16));
+        if ((threadIdx.x & 63) == 0)
+            __hip_atomic_fetch_add(&tc->sq[m], (unsigned long long)lo + ((unsigned long long)hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int m = 0; m < NV; m++) { bc[m] = (float)r.S[m]; bc[4 + m] = r.amax[m]; }
+    }
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&tc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// S KiB from ONE wave-uniform address (SGPR pair) + this lane's 32-bit offset: the per-unit address update is two scalar adds
+template <int S> __device__ __forceinline__ void dma_unit_s(const uint8_t *src, unsigned voff, unsigned lds_dst);
+#define RWKV_DMA_UNIT_S(S_, BODY)                                                                                                      \
+    template <> __device__ __forceinline__ void dma_unit_s<S_>(const uint8_t *src, unsigned voff, unsigned lds_dst)                    \
+    {                                                                                                                                  \
+        unsigned keep;                                                                                                                 \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" BODY "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(src), "s"(lds_dst) : "memory"); \
+    }
+#define RWKV_DMA_LS(OFF) "global_load_lds_dwordx4 %1, %2 offset:" #OFF " nt\n\t"
+RWKV_DMA_UNIT_S(2, RWKV_DMA_LS(0) RWKV_DMA_LS(1024))
+RWKV_DMA_UNIT_S(4, RWKV_DMA_LS(0) RWKV_DMA_LS(1024) RWKV_DMA_LS(2048) RWKV_DMA_LS(3072))
+#undef RWKV_DMA_LS
+#undef RWKV_DMA_UNIT_S
+
+// The loader wave of a tile-form kernel: units of S KiB (S k-blocks of one tile), in order.  Same rules as RingLoader (kernels.hip.h):
+// one asm statement per unit, vmcnt READ instead of waited on, every wait bounded -- and, because one wave's instruction issue IS the
+// stream's ceiling (the first version of this loader spent 50 instructions per unit and streamed at 23 KB/us per CU where the row
+// form's reaches 26: profiles/r05/tile_check.txt), ALL state scalar: the unit's address is an SGPR pair advanced by two scalar adds,
+// `landed` is stored by all lanes at once (lane 0 into the control block, the others into dump slots).  Consumers free units by
+// per-wave counters (unit u belongs to wave u % NC, which takes its units in order), so the first unit still in use is
+// min_w (NC * freed[w] + w): looked at only when the cached value says the ring is full.
+template <int S> struct TileLoader {
+    TileCtl *tc;
+    unsigned ring, nu;
+    unsigned issued = 0, pub = 0, tailu = 0, pos = 0;
+    unsigned voff;               // lane * 16
+    unsigned landed_lds;         // LDS byte address this lane stores `landed` to: lane 0 the control block's word, lane l dump[l]
+    int lane;
+    bool dead = false;
+    unsigned fail = 0;
+    __device__ __forceinline__ TileLoader(TileCtl *tc_, unsigned ring_, int nu_, int lane_)
+        : tc(tc_), ring((unsigned)__builtin_amdgcn_readfirstlane((int)ring_)), nu((unsigned)nu_), voff((unsigned)lane_ << 4),
+          landed_lds(lane_ == 0 ? lds_addr(&tc_->landed) : lds_addr(&tc_->dump[lane_])), lane(lane_)
+    {
+        asm volatile("" : "+s"(ring));
+    }
+    __device__ __forceinline__ unsigned in_flight() const
+    {
+        const unsigned v = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 7);
+        return (v & 0xfu) | ((v >> 18) & 0x30u);
+    }
+    // (asm: a store the compiler sees through a generic pointer becomes a FLAT store + s_waitcnt vmcnt(0) -- it would sit in this wave's
+    // vmcnt, which IS the landing count, and drain the DMA queue at every announcement)
+    __device__ __forceinline__ void store_landed(unsigned units) { asm volatile("ds_write_b32 %0, %1" ::"v"(landed_lds), "v"(units) : "memory"); }
+    // (this wave issues no vector memory operation but its DMA pieces: issued * S >= in_flight, always)
+    __device__ __forceinline__ void poll_landed()
+    {
+        const unsigned units = (issued * (unsigned)S - in_flight()) / (unsigned)S;
+        if (units != pub) { pub = units; store_landed(units); }
+    }
+    __device__ __forceinline__ void refresh_tail()
+    {
+        const unsigned f = __hip_atomic_load(&tc->freed[lane & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        const unsigned v = f * (unsigned)NC + (unsigned)(lane & 7);
+        unsigned m = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+#pragma unroll
+        for (int w = 1; w < NC; w++) { const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)v, w); m = o < m ? o : m; }
+        tailu = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+    }
+    __device__ __forceinline__ bool room2() const { return issued + 2u - tailu <= nu; }
+    // TWO units (2 S KiB, contiguous in the image and -- nu is even, pairs are aligned -- in the ring) per round of bookkeeping
+    template <int DEPTH> __device__ __forceinline__ void pair(const uint8_t *src)
+    {
+        if (!room2()) {
+            for (int it = 0; !dead; it++) {
+                refresh_tail();
+                if (room2()) break;
+                poll_landed();
+                if (it >= GLDS_SPIN) { dead = true; fail = 1u; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        wait_vm<(DEPTH > 2 * S ? DEPTH : 2 * S) - 2 * S>();
+        const unsigned dst = ring + pos * (unsigned)(S * 1024);
+        dma_unit_s<S>(src, voff, dst);
+        dma_unit_s<S>(src + S * 1024, voff, dst + (unsigned)(S * 1024));
+        pos = pos + 2 == nu ? 0u : pos + 2;
+        issued += 2;
+        poll_landed();
+    }
+    __device__ __forceinline__ void finish()
+    {
+        int it = 0;
+        for (; it < GLDS_SPIN && in_flight() != 0u; it++) { poll_landed(); __builtin_amdgcn_s_sleep(1); }
+        fail = it >= GLDS_SPIN ? 4u : fail;
+        wait_vm<0>();
+        pub = issued;
+        store_landed(issued);
+    }
+};
+
+// ---- shared by the tile-form kernels ----------------------------------------------------------------------------------------------
+// plain-vector prologue (k_attout: the gated wkv vector; k_ffnv: the 4 D hidden units as ONE vector), run by waves 0..3: scale and
+// offset from the producer's per-workgroup partials, then quantise and stage n elements (n % 1024 == 0 here).  NQ = quads per thread.
+template <int NQ>
+__device__ __forceinline__ void tile_vec(const float *vec, const double *partS, const float *partM, int n_part, int n, double *red, unsigned *xq,
+                                         TileCtl *tc, unsigned long long *tl)
+{
+    constexpr int NTP = NT / 2, NWP = NTP / 64;
+    const int lane = threadIdx.x & 63, wave = wave_id(), nqd = n >> 2;
+    float *bc = reinterpret_cast<float *>(red + RED_BC);
+    unsigned *spin = reinterpret_cast<unsigned *>(bc + 8);
+    double ps = partS[(int)threadIdx.x < n_part ? threadIdx.x : 0];
+    float pm = partM[(int)threadIdx.x < n_part ? threadIdx.x : 0];
+    f32x4 vl[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NTP;
+        vl[i] = reinterpret_cast<const f32x4 *>(vec)[qd < nqd ? qd : nqd - 1];
+    }
+    tl_stamp(tl, 1);
+    if (threadIdx.x == 0) *spin = 0u;
+    __syncthreads();   // order
+    if ((int)threadIdx.x >= n_part) { ps = 0.0; pm = 0.f; }
+    float *redf = reinterpret_cast<float *>(red + RED_MAX);
+    const double ws = wave_sum(ps);
+    const float wm = wave_max(pm);
+    if (lane == 0) { red[RED_OFFS + wave] = ws; redf[wave] = wm; }
+    tl_stamp(tl, 3);
+    if (lane == 0) __hip_atomic_fetch_add(spin, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned f_ = 0u;
+    wait_count(spin, NWP, f_);
+    double ts = 0.0; float tm = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWP; i++) { ts += red[RED_OFFS + i]; tm = fmaxf(tm, redf[i]); }
+    tl_stamp(tl, 4);
+    unsigned long long sq = 0ull;
+    const float inv = inv_scale(tm);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int qd = threadIdx.x + i * NTP;
+        if (qd < nqd) {
+            const float v[4] = {vl[i][0], vl[i][1], vl[i][2], vl[i][3]};
+            sq += stage_quad_t(xq, qd, v, inv);
+        }
+    }
+    {
+        const unsigned lo = wave_sum_dpp((unsigned)sq & 0xffffu), hi = wave_sum_dpp((unsigned)(sq >> 16));
+        if (lane == 0) __hip_atomic_fetch_add(&tc->sq[0], (unsigned long long)lo + ((unsigned long long)hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (threadIdx.x == 0) { bc[0] = (float)ts; bc[4] = tm; }
+    if (lane == 0) __hip_atomic_fetch_add(&tc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// the loader wave's whole life: zero the control block and the tile sums, first units before the order barrier, the stream, the landing
+template <int S, int UPT, class Src>
+__device__ __forceinline__ unsigned tile_loader(int NU, int ntile, unsigned char *ring, int ns, TileCtl *tc, int *tsum, int lane, Src unit_src)
+{
+    static_assert(UPT % 2 == 0, "pairs of units never straddle a tile");
+    loader_clean_slate();
+    for (int i = lane; i < (int)(sizeof(TileCtl) / 4); i += 64) reinterpret_cast<unsigned *>(tc)[i] = 0u;
+    for (int i = lane; i < ntile * 48; i += 64) tsum[i] = 0;
+    TileLoader<S> ld(tc, lds_addr(ring), ns, lane);
+    // units in stream order = tile after tile, S k-blocks at a time: contiguous within a tile; the loader moves PAIRS of units
+    const uint8_t *src = unit_src(0);
+    int u = 0, c = 0;
+    auto next = [&]() {
+        u += 2; c += 2; src += 2 * S * 1024;
+        if (c == UPT) { c = 0; src = unit_src(u < NU ? u : 0); }
+    };
+    const int pre = RWKV_RING_PRE < ns - 2 ? RWKV_RING_PRE : ns - 2;
+    for (; u < NU && u < pre; next()) ld.template pair<RWKV_RING_PRE_DEPTH>(src);
+    __syncthreads();   // order: the control block is zero, the prologue's requests are in the pipe
+    // (TEST build -DRWKV_TEST_DROP_GROUP=1, tests/test_engine_gpu.py: the loader "loses" the workgroup's last pair of units -- the consumers'
+    // bounded wait must give up and the call must fail with RWKV_E_DEVICE instead of returning garbage)
+    for (; u < NU - (RWKV_TEST_DROP_GROUP ? 2 : 0); next()) ld.template pair<(RWKV_RING_DEPTH < 63 ? RWKV_RING_DEPTH : 63)>(src);
+    ld.finish();
+    return ld.fail;
+}
+
+// exact integer sum of tile t's row `row`: M = D0 + 2^8 D1 + 2^16 D2 over the three limb planes
+__device__ __forceinline__ long long tile_row_sum(const int *tsum, int t, int row)
+{
+    const int *p = tsum + (t * 16 + row) * 3;
+    return (long long)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+           + 256ll * (long long)__hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+           + 65536ll * (long long)__hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// per-vector constant of the signed-limb form: 128 * sum_j (q_j + 2^22) - 16384 * 65793 * N
+__device__ __forceinline__ double tile_cA(const TileCtl *tc, int m, double n)
+{
+    return 128.0 * (double)__hip_atomic_load(&tc->sq[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + TILE_CN * n;
+}
+
+// The consumer waves' streaming loop (wave < NC).  Unit u (tile u / UPT, k-blocks S (u % UPT) ..) belongs to wave u % NC: wait for it,
+// copy its S KiB out of the ring, hand it back, multiply it with the limbs of vector vec_of(tile); when the wave's last unit of a tile is
+// in, its partial sums join the tile's in LDS and the unit count; the wave that completes the count calls on_tile(t) (all lanes; the
+// tile's row sums are final: tile_row_sum).
+template <int S, int UPT, class VecOf, class OnTile>
+__device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, int ns, TileCtl *tc, int *tsum, const unsigned *xq, int xvd_t,
+                                             int wave, int lane, unsigned &fail, VecOf vec_of, OnTile on_tile)
+{
+    const int qq = lane >> 4, r = lane & 15;
+    int acc0 = 0, acc1 = 0, acc2 = 0, cnt = 0;
+    unsigned p = (unsigned)wave % (unsigned)ns;
+    unsigned taken = 0, seen = 0;
+    for (int u = wave; u < NU; u += NC) {
+        if ((int)(seen - (unsigned)(u + 1)) < 0) {       // (`landed` only grows: what an earlier look saw still holds)
+            bool ok = false;
+            for (int it = 0; it < GLDS_SPIN; it++) {
+                seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tc->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if ((int)(seen - (unsigned)(u + 1)) >= 0) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            fail = ok ? fail : 2u;
+        }
+        const u32x4 *wp = reinterpret_cast<const u32x4 *>(ring + (size_t)p * (S * 1024)) + lane;
+        u32x4 w[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) w[s] = wp[s * 64];
+        taken++;
+        // (relaxed + a compiler barrier: a wave's LDS operations execute in order, so the loader that sees the count finds the reads done;
+        // a release store would make the wave WAIT for its reads before it may even request the activation limbs)
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&tc->freed[wave], taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        p += NC; p = p >= (unsigned)ns ? p - (unsigned)ns : p;
+        const int t = u / UPT, c = u - t * UPT;
+        const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + (c * S) * 12 + qq * 3;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const u32x4 x0 = xp[s * 12], x1 = xp[s * 12 + 1], x2 = xp[s * 12 + 2];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                acc0 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x0[d], acc0, false);
+                acc1 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x1[d], acc1, false);
+                acc2 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x2[d], acc2, false);
+            }
+        }
+        cnt++;
+        const int un = u + NC;
+        if (un >= NU || un / UPT != t) {
+            int *ts = tsum + (t * 16 + r) * 3;
+            __hip_atomic_fetch_add(ts + 0, acc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(ts + 1, acc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(ts + 2, acc2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            unsigned old = 0u;
+            if (lane == 0) old = __hip_atomic_fetch_add(&tc->tcnt[t], (unsigned)cnt, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+            if (old + (unsigned)cnt == (unsigned)UPT) on_tile(t);
+            acc0 = acc1 = acc2 = 0; cnt = 0;
+        }
+    }
+}
+
+// Every tile-form kernel: workgroup b owns the 16-channel block b (D / 16 = the grid: D = 4096 on 256 CUs).  KBT = k-blocks of a matrix
+// row (K / 64), S = k-blocks (KiB) per ring unit, SD = ceil(D / 1024).  The argument blocks are the row-form kernels' (site, epilogue
+// inputs and outputs, D, ns = ring units, tl, herr; w / rw / cy unused) + the image.
+struct TileImage {
+    const uint8_t *bimg;          // MFMA B-operand image of this layer's matrix (k_bimage: tile id = class * CB + channel block, signed bytes)
+    int CB;                       // 16-channel blocks of the matrix
+};
+struct FfnRKTArgs { FfnRKArgs a; TileImage im; };
+struct AttTArgs { AttArgs a; TileImage im; };
+struct AttOutTArgs { AttOutArgs a; TileImage im; };
+struct FfnVTArgs { FfnVArgs a; TileImage im; };
+constexpr int TILE_NWP = NT / 2 / 64;
+// LDS in front of the ring (bytes), per kernel: must match the carving at the head of each kernel
+constexpr size_t tile_fixed_frk(int D) { return RED_BYTES + (size_t)2 * (D / 64) * 192 + 208 * 4 + 5 * 192 + sizeof(TileCtl); }
+constexpr size_t tile_fixed_att(int D) { return RED_BYTES + (size_t)3 * (D / 64) * 192 + 48 * 4 + 64 * 8 + 32 * 4 + 32 * 8 + 32 * 4 + 3 * 192 + sizeof(TileCtl); }
+constexpr size_t tile_fixed_attout(int D) { return RED_BYTES + (size_t)(D / 64) * 192 + 64 * 8 + 16 * 12 * 4 + 16 * 4 + 160 * 8 + 192 + sizeof(TileCtl); }
+constexpr size_t tile_fixed_fv(int D) { return RED_BYTES + (size_t)(4 * D / 64) * 192 + 64 * 8 + 16 * 16 * 4 + 16 * 4 + 16 * 4 + 160 * 8 + 192 + sizeof(TileCtl); }
+
+// ln2 site -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573): 5 tiles, classes 0..3 = ffn_k outputs 4 i + q, class 4 = ffn_r output i
+template <int SD, int S, int KBT>
+__global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FfnRKArgs &a = ta.a;
+    constexpr int NTILE = 5, UPT = KBT / S, NU = NTILE * UPT;
+    static_assert(KBT % S == 0, "whole units per tile");
+    double *red = reinterpret_cast<double *>(smem);
+    const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
+    constexpr int xvd_t = KBT * 48;                        // dwords of one staged vector
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
+    // LDS: [scratch][2 staged vectors][stash: rs[80], r_fv[64], o_fv[64]][tile sums][TileCtl][ring]
+    unsigned *stash = xq + 2 * xvd_t;
+    int *tsum = reinterpret_cast<int *>(stash + 208);
+    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * 48);
+    unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
+    RWKV_ARGS_NOW(a.x, a.st.C, a.st.TC, a.st.maxC, a.dy.B, a.dy.pd, a.dy.pf, a.dy.n_part);
+    const int cb = blockIdx.x, ch0 = cb * 16;
+    tl_stamp(a.tl, 0);
+    auto unit_src = [&](int u) {
+        const int t = u / UPT, c = u - t * UPT;
+        return ta.im.bimg + ((size_t)(t * ta.im.CB + cb) * KBT + (size_t)c * S) * 1024;
+    };
+    double part = 0.0;
+    float pmax = 0.f;
+    unsigned fail = 0u;
+    if (wave == NC) {
+        fail = tile_loader<S, UPT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        tl_stamp(a.tl, 2);
+    } else {
+        if (wave < TILE_NWP) {
+            tile_site<2, SD>(a.st, a.dy, a.x, D, red, xq, xvd_t, true, tc, a.tl);
+        } else {
+            // waves 4..6 have nothing to do until the vectors are staged: they fetch the epilogues' inputs of the workgroup's 80 rows into
+            // LDS (row sums of the unsigned weights, ffn_v's scale and offset of the 64 hidden units): requested in front of the order
+            // barrier, stored behind it (a wave that waited for its loads in front of the barrier would hold the prologue waves there)
+            unsigned v0 = 0u, v1 = 0u;
+            if (wave == 4) { v0 = a.rs[ch0 * 5 + lane]; v1 = a.rs[ch0 * 5 + 64 + (lane & 15)]; }
+            else if (wave == 5) v0 = __float_as_uint(a.r_fv[ch0 * 4 + lane]);
+            else v0 = __float_as_uint(a.o_fv[ch0 * 4 + lane]);
+            __syncthreads();   // order
+            if (wave == 4) { stash[lane] = v0; if (lane < 16) stash[64 + lane] = v1; }
+            else if (wave == 5) stash[80 + lane] = v0;
+            else stash[144 + lane] = v0;
+        }
+        float *bc = reinterpret_cast<float *>(red + RED_BC);
+        wait_count(&tc->staged, TILE_NWP, fail);
+        const double sck = scale_of(bc[4]), scr = scale_of(bc[5]);
+        const float Sk = bc[0], Sr = bc[1];
+        const double cAk = tile_cA(tc, 0, (double)D), cAr = tile_cA(tc, 1, (double)D);
+        tl_stamp(a.tl, 5);
+        auto on_tile = [&](int q) {          // tile = class q: this lane's row is channel ch0 + lane
+            if (lane < 16) {
+                const long long M = tile_row_sum(tsum, q, lane);
+                const unsigned rs = stash[lane * 5 + q];
+                if (q < 4) {
+                    const float val = (float)(sck * ((double)M + cAk + TILE_CU * (double)rs)) + Sk;
+                    float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
+                    h = h * h;
+                    const int hi = lane * 4 + q;
+                    const float hs = h * __uint_as_float(stash[80 + hi]);
+                    a.hbuf[4 * ch0 + hi] = hs;
+                    part += (double)(h * __uint_as_float(stash[144 + hi]));
+                    pmax = fmaxf(pmax, fabsf(hs));
+                } else {
+                    const float val = (float)(scr * ((double)M + cAr + TILE_CU * (double)rs)) + Sr;
+                    a.rgate[ch0 + lane] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
+                }
+            }
+        };
+        tile_consume<S, UPT>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t < 4 ? 0 : 1; }, on_tile);
+    }
+    tl_stamp(a.tl, 6);
+    __syncthreads();   // every wave is past its last read of the reduction scratch
+    block_sum_max(part, pmax, red + RED_PART);
+    if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
+    ring_report(fail, a.herr);
+    tl_stamp(a.tl, 7);
+}
+
+// ln1 site -> K, V, R dequant-GEMV -> WKV (rwkv.cu:535-545; kernels :351-392, :58-100, :221-259): 3 tiles = the K, V, R rows of the
+// workgroup's 16 channels.  The tile finishers leave k's two exponentials, v and r in LDS; whoever completes the third tile runs the 16
+// recurrences side by side.
+template <int SD, int S, int KBT>
+__global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const AttArgs &a = ta.a;
+    constexpr int NTILE = 3, UPT = KBT / S, NU = NTILE * UPT;
+    double *red = reinterpret_cast<double *>(smem);
+    const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
+    constexpr int xvd_t = KBT * 48;
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
+    // LDS: [scratch][3 staged vectors][stash: rs[48] | aa, bb, uw, ew [4][16] f64 | ra, oa [2][16] f32 | e1, ek [2][16] f64 | v, r [2][16] f32][tile sums][TileCtl][ring]
+    unsigned *stash = xq + 3 * xvd_t;
+    double *sd = reinterpret_cast<double *>(stash + 48);          // aa, bb, uw, ew
+    float *sf = reinterpret_cast<float *>(sd + 64);               // ra, oa
+    double *ed = reinterpret_cast<double *>(sf + 32);             // e1, ek
+    float *ef = reinterpret_cast<float *>(ed + 32);               // v, r
+    int *tsum = reinterpret_cast<int *>(ef + 32);
+    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * 48);
+    unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
+    RWKV_ARGS_NOW(a.x, a.st.C, a.st.TC, a.st.maxC, a.dy.B, a.dy.pd, a.dy.pf, a.dy.n_part);
+    const int cb = blockIdx.x, ch0 = cb * 16;
+    tl_stamp(a.tl, 0);
+    auto unit_src = [&](int u) {
+        const int t = u / UPT, c = u - t * UPT;
+        return ta.im.bimg + ((size_t)(t * ta.im.CB + cb) * KBT + (size_t)c * S) * 1024;
+    };
+    double part = 0.0;
+    float pmax = 0.f;
+    unsigned fail = 0u;
+    if (wave == NC) {
+        fail = tile_loader<S, UPT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        tl_stamp(a.tl, 2);
+    } else {
+        const size_t so = (size_t)a.ctl->slot * a.slot_stride;
+        if (wave < TILE_NWP) {
+            tile_site<3, SD>(a.st, a.dy, a.x, D, red, xq, xvd_t, true, tc, a.tl);
+        } else {
+            // epilogue inputs of the 16 channels: wave 4 the 48 row sums, wave 5 the state (aa | bb) and the decay terms (uw | ew), wave 6 att_out's scale / offset
+            unsigned v0 = 0u;
+            double d0 = 0.0;
+            const int i = lane & 15, g = lane >> 4;
+            if (wave == 4) { if (lane < 48) v0 = a.rs[ch0 * 3 + lane]; }
+            else if (wave == 5) d0 = g == 0 ? a.saa[so + ch0 + i] : g == 1 ? a.sbb[so + ch0 + i] : g == 2 ? a.uw[ch0 + i] : a.ew[ch0 + i];
+            else if (lane < 32) v0 = __float_as_uint(g == 0 ? a.r_att[ch0 + i] : a.o_att[ch0 + i]);
+            __syncthreads();   // order
+            if (wave == 4) { if (lane < 48) stash[lane] = v0; }
+            else if (wave == 5) sd[lane] = d0;
+            else if (lane < 32) sf[lane] = __uint_as_float(v0);
+        }
+        float *bc = reinterpret_cast<float *>(red + RED_BC);
+        wait_count(&tc->staged, TILE_NWP, fail);
+        double sc[3], cA[3];
+        float So[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) { sc[m] = scale_of(bc[4 + m]); So[m] = bc[m]; cA[m] = tile_cA(tc, m, (double)D); }
+        tl_stamp(a.tl, 5);
+        auto on_tile = [&](int t) {
+            if (lane < 16) {
+                const long long M = tile_row_sum(tsum, t, lane);
+                const float val = (float)(sc[t] * ((double)M + cA[t] + TILE_CU * (double)stash[lane * 3 + t])) + So[t];
+                if (t == 0) { ed[lane] = exp(sd[32 + lane] + (double)val); ed[16 + lane] = exp((double)val); }      // exp(u + w + k), exp(k)
+                else ef[(t - 1) * 16 + lane] = val;
+            }
+            unsigned old = 0u;
+            if (lane == 0) old = __hip_atomic_fetch_add(&tc->tcnt[7], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+            if (old == 2u && lane < 16) {            // all three tiles in: the WKV recurrence and the gate of the 16 channels (rwkv.cu:242-255)
+                const int g = ch0 + lane;
+                const double aa = sd[lane], bb = sd[16 + lane], ew = sd[48 + lane];
+                const double e1 = *reinterpret_cast<volatile double *>(ed + lane), ek = *reinterpret_cast<volatile double *>(ed + 16 + lane);
+                const float v = *reinterpret_cast<volatile float *>(ef + lane), r = *reinterpret_cast<volatile float *>(ef + 16 + lane);
+                const double vv = (double)v;
+                double y = (aa + e1 * vv) / (bb + e1);
+                y = (1.0 / (1.0 + (double)expf(-r))) * y;       // rwkv.cu:250: exp of a float argument
+                a.saa[so + g] = (aa + ek * vv) * ew;
+                a.sbb[so + g] = (bb + ek) * ew;
+                const float yf = (float)y;                       // att_out GEMV casts its input to f32 (rwkv.cu:290)
+                const float ys = yf * sf[lane];
+                a.ybuf[g] = ys;
+                part += (double)(yf * sf[16 + lane]);
+                pmax = fmaxf(pmax, fabsf(ys));
+            }
+        };
+        tile_consume<S, UPT>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t; }, on_tile);
+    }
+    tl_stamp(a.tl, 6);
+    __syncthreads();
+    block_sum_max(part, pmax, red + RED_PART);
+    if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
+    ring_report(fail, a.herr);
+    tl_stamp(a.tl, 7);
+}
+
+// the row owners' partial tuple of a tile-form kernel with ONE finishing wave: its 16 lanes leave their accumulators in LDS, thread k < 12
+// adds the 16 entries up (kernels.hip.h site_publish does it for R lanes of every wave)
+template <int NV>
+__device__ __forceinline__ void tile_site_leave(const SiteAcc<NV> &acc, double *scr, int lane)
+{
+    float *scf = reinterpret_cast<float *>(scr + 16 * 8);
+#pragma unroll
+    for (int k = 0; k < 8; k++) scr[lane * 8 + k] = acc.d[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) scf[lane * 4 + k] = acc.f[k];
+}
+__device__ __forceinline__ void tile_site_publish(const SiteDyn &dy, const double *scr)
+{
+    const float *scf = reinterpret_cast<const float *>(scr + 16 * 8);
+    if (threadIdx.x < 8) {
+        double t = 0.0;
+        for (int i = 0; i < 16; i++) t += scr[i * 8 + threadIdx.x];
+        dy.pd[(size_t)blockIdx.x * 8 + threadIdx.x] = t;
+    } else if (threadIdx.x < 12) {
+        float t = 0.f;
+        for (int i = 0; i < 16; i++) t = fmaxf(t, scf[i * 4 + (threadIdx.x - 8)]);
+        dy.pf[(size_t)blockIdx.x * 4 + (threadIdx.x - 8)] = t;
+    }
+}
+
+// att_out dequant-GEMV + residual through f32 (rwkv.cu:548-553); commits state xy; opens the ln2 site for its 16 rows: ONE tile
+template <int SD, int S, int KBT>
+__global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const AttOutArgs &a = ta.a;
+    constexpr int NTILE = 1, UPT = KBT / S, NU = UPT;
+    double *red = reinterpret_cast<double *>(smem);
+    const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
+    constexpr int xvd_t = KBT * 48;
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
+    // LDS: [scratch][1 staged vector][stash: xold, lw, lb, prev2 [4][16] f64 | P [16][12] f32 | rs[16]][publish scratch 16 x 12 words x 2][tile sums][TileCtl][ring]
+    double *sd = reinterpret_cast<double *>(xq + xvd_t);
+    float *sp = reinterpret_cast<float *>(sd + 64);
+    unsigned *srs = reinterpret_cast<unsigned *>(sp + 16 * 12);
+    double *scr = reinterpret_cast<double *>(srs + 16);
+    int *tsum = reinterpret_cast<int *>(scr + 16 * 8 + 32);
+    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * 48);
+    unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
+    RWKV_ARGS_NOW(a.ybuf, a.partS, a.partM, a.n_part);
+    const int cb = blockIdx.x, ch0 = cb * 16;
+    tl_stamp(a.tl, 0);
+    auto unit_src = [&](int u) { return ta.im.bimg + ((size_t)cb * KBT + (size_t)u * S) * 1024; };
+    unsigned fail = 0u;
+    if (wave == NC) {
+        fail = tile_loader<S, UPT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        tl_stamp(a.tl, 2);
+    } else {
+        const double mean1 = a.lnstat[0], rstd1 = a.lnstat[1];
+        const size_t so = (size_t)a.ctl->slot * a.slot_stride;
+        if (wave < TILE_NWP) {
+            tile_vec<SD>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, tc, a.tl);
+        } else {
+            const int i = lane & 15, g = lane >> 4;
+            double d0 = 0.0;
+            f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            unsigned v0 = 0u;
+            if (wave == 4) d0 = g == 0 ? a.x[ch0 + i] : g == 1 ? a.lnw[ch0 + i] : g == 2 ? a.lnb[ch0 + i] : a.sdd[so + ch0 + i];
+            else if (wave == 5) { if (lane < 48) p0 = reinterpret_cast<const f32x4 *>(a.st.P + (size_t)ch0 * 12)[lane]; }
+            else if (lane < 16) v0 = a.rs[ch0 + lane];
+            __syncthreads();   // order
+            if (wave == 4) sd[lane] = d0;
+            else if (wave == 5) { if (lane < 48) reinterpret_cast<f32x4 *>(sp)[lane] = p0; }
+            else if (lane < 16) srs[lane] = v0;
+        }
+        float *bc = reinterpret_cast<float *>(red + RED_BC);
+        wait_count(&tc->staged, TILE_NWP, fail);
+        const float Sf = bc[0];
+        const double sc = scale_of(bc[4]), cA = tile_cA(tc, 0, (double)D);
+        tl_stamp(a.tl, 5);
+        auto on_tile = [&](int) {
+            if (lane < 16) {
+                const int mi = ch0 + lane;
+                const long long M = tile_row_sum(tsum, 0, lane);
+                const double xold = sd[lane];
+                const float accf = (float)xold + ((float)(sc * ((double)M + cA + TILE_CU * (double)srs[lane])) + Sf);   // f32 accumulator pre-loaded with x (:548)
+                const double xnew = (double)accf;                                                                       // :553
+                a.x[mi] = xnew;
+                a.sxy[so + mi] = sd[16 + lane] * ((xold - mean1) * rstd1) + sd[32 + lane];                              // mixatt's state write (:385): ln1 output
+                SitePre<2> pre;
+#pragma unroll
+                for (int k = 0; k < 3; k++) pre.p[k] = reinterpret_cast<const f32x4 *>(sp + lane * 12)[k];
+                SiteAcc<2> acc;
+                acc.clear();
+                site_emit<2>(pre, a.dy, D, mi, xnew, sd[48 + lane], acc);
+                tile_site_leave<2>(acc, scr, lane);
+            }
+        };
+        tile_consume<S, UPT>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile);
+    }
+    tl_stamp(a.tl, 6);
+    __syncthreads();
+    tile_site_publish(a.dy, scr);
+    ring_report(fail, a.herr);
+    tl_stamp(a.tl, 7);
+}
+
+// ffn_v dequant-GEMV, x += v * sigmoid(r) (rwkv.cu:574-577); commits state dd; opens the next site: ONE tile of K = 4 D (KBT = 4 D / 64)
+template <int SD, int S, int KBT, int NVN>
+__global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FfnVArgs &a = ta.a;
+    constexpr int NTILE = 1, UPT = KBT / S, NU = UPT, PW = site_pw<NVN>();
+    double *red = reinterpret_cast<double *>(smem);
+    const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
+    constexpr int xvd_t = KBT * 48;
+    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
+    // LDS: [scratch][1 staged vector of 4 D][stash: xold, lw, lb, prevn [4][16] f64 | P [16][PW] f32 | rs[16] | rgate[16]][publish scratch][tile sums][TileCtl][ring]
+    double *sd = reinterpret_cast<double *>(xq + xvd_t);
+    float *sp = reinterpret_cast<float *>(sd + 64);
+    unsigned *srs = reinterpret_cast<unsigned *>(sp + 16 * 16);
+    float *srg = reinterpret_cast<float *>(srs + 16);
+    double *scr = reinterpret_cast<double *>(srg + 16);
+    int *tsum = reinterpret_cast<int *>(scr + 16 * 8 + 32);
+    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * 48);
+    unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
+    RWKV_ARGS_NOW(a.hbuf, a.partS, a.partM, a.n_part);
+    const int cb = blockIdx.x, ch0 = cb * 16;
+    tl_stamp(a.tl, 0);
+    auto unit_src = [&](int u) { return ta.im.bimg + ((size_t)cb * KBT + (size_t)u * S) * 1024; };
+    unsigned fail = 0u;
+    if (wave == NC) {
+        fail = tile_loader<S, UPT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        tl_stamp(a.tl, 2);
+    } else {
+        const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
+        const size_t so = (size_t)a.ctl->slot * a.slot_stride;
+        if (wave < TILE_NWP) {
+            tile_vec<4 * SD>(a.hbuf, a.partS, a.partM, a.n_part, 4 * D, red, xq, tc, a.tl);
+        } else {
+            const int i = lane & 15, g = lane >> 4;
+            double d0 = 0.0;
+            f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            unsigned v0 = 0u;
+            if (wave == 4) d0 = g == 0 ? a.x[ch0 + i] : g == 1 ? a.lnw[ch0 + i] : g == 2 ? a.lnb[ch0 + i] : (NVN == 3 ? a.sprev[so + ch0 + i] : 0.0);
+            else if (wave == 5) { if (lane < 4 * PW) p0 = reinterpret_cast<const f32x4 *>(a.st.P + (size_t)ch0 * PW)[lane]; }
+            else if (lane < 32) v0 = lane < 16 ? a.rs[ch0 + lane] : __float_as_uint(a.rgate[ch0 + lane - 16]);
+            __syncthreads();   // order
+            if (wave == 4) sd[lane] = d0;
+            else if (wave == 5) { if (lane < 4 * PW) reinterpret_cast<f32x4 *>(sp)[lane] = p0; }
+            else if (lane < 32) srs[lane] = v0;          // (rs[16] and rgate[16] are adjacent)
+        }
+        float *bc = reinterpret_cast<float *>(red + RED_BC);
+        wait_count(&tc->staged, TILE_NWP, fail);
+        const float Sf = bc[0];
+        const double sc = scale_of(bc[4]), cA = tile_cA(tc, 0, 4.0 * (double)D);
+        tl_stamp(a.tl, 5);
+        auto on_tile = [&](int) {
+            if (lane < 16) {
+                const int g = ch0 + lane;
+                const long long M = tile_row_sum(tsum, 0, lane);
+                const float v = (float)(sc * ((double)M + cA + TILE_CU * (double)srs[lane])) + Sf;
+                const double xold = sd[lane];
+                const double xnew = xold + (double)(v * srg[lane]);                       // blockout, rwkv.cu:407 (f32 product)
+                a.x[g] = xnew;
+                a.sdd[so + g] = sd[16 + lane] * ((xold - mean2) * rstd2) + sd[32 + lane];   // mixffn's state write (:344): ln2 output
+                SitePre<NVN> pre;
+#pragma unroll
+                for (int k = 0; k < PW / 4; k++) pre.p[k] = reinterpret_cast<const f32x4 *>(sp + lane * PW)[k];
+                SiteAcc<NVN> acc;
+                acc.clear();
+                site_emit<NVN>(pre, a.dy, D, g, xnew, sd[48 + lane], acc);
+                tile_site_leave<NVN>(acc, scr, lane);
+            }
+        };
+        tile_consume<S, UPT>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile);
+    }
+    tl_stamp(a.tl, 6);
+    __syncthreads();
+    tile_site_publish(a.dy, scr);
+    ring_report(fail, a.herr);
+    tl_stamp(a.tl, 7);
+}
+
+} // namespace rwkvk

@@ -407,11 +407,14 @@ def fault_libs(built, tmp_path_factory):
 
 
 
-def test_a_lost_ring_hand_off_fails_the_call_instead_of_returning_garbage(fault_libs):
+@pytest.mark.parametrize("tile", ["0", "15"])
+def test_a_lost_ring_hand_off_fails_the_call_instead_of_returning_garbage(fault_libs, tile):
     """every wait of the LDS-ring kernels is bounded; one that gives up is recorded and reported (kernels.hip.h ring_report,
     engine.hip device_check): a variant of the engine whose loader wave never issues a workgroup's last group
     (-DRWKV_TEST_DROP_GROUP=1, built here with hipcc) must fail the forward with RWKV_E_DEVICE, and the context must be usable
-    for error reporting afterwards -- no hang, no silently wrong logits.  Runs in a subprocess (RWKV_LIB selects the variant)."""
+    for error reporting afterwards -- no hang, no silently wrong logits.  Runs in a subprocess (RWKV_LIB selects the variant), once
+    with the row-form ring kernels (RWKV_TILE=0) and once with the tile-form kernels a 4096-wide model gets by default (their loader
+    loses its last pair of units in the same build)."""
     import subprocess
     import sys
     lib = fault_libs["drop"]
@@ -428,7 +431,7 @@ def test_a_lost_ring_hand_off_fails_the_call_instead_of_returning_garbage(fault_
         "except engine.RWKVError as e:\n"
         "    print('RWKVERROR', str(e)[-120:], '|', str(e)[:120])\n"
     )
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RWKV_LIB=lib, RWKV_RING="13"), capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RWKV_LIB=lib, RWKV_RING="13", RWKV_TILE=tile), capture_output=True, text=True, timeout=600)
     assert "RWKVERROR" in out.stdout and "device-side wait gave up" in out.stdout and "status -3" in out.stdout, out.stdout[-400:] + out.stderr[-400:]
 
 
@@ -463,8 +466,8 @@ def test_rows_carried_across_kernel_boundaries_are_found_and_change_nothing(buil
     launches x 256 workgroups, none missed), and tokens and logits must be bit-identical to a run with RWKV_CARRY=0: the carried
     rows are the same bytes, multiplied by the same code."""
     code = _CARRY_PROBE.format(root=ROOT, L=L, D=D)
-    on = _run_py(code, RWKV_CARRY="32", RWKV_CARRY_COUNT="1")
-    off = _run_py(code, RWKV_CARRY="0", RWKV_CARRY_COUNT="1")
+    on = _run_py(code, RWKV_CARRY="32", RWKV_CARRY_COUNT="1", RWKV_TILE="0")        # (RWKV_TILE=0: the ROW-form kernels; 4096-wide models default to tile form, which does not carry)
+    off = _run_py(code, RWKV_CARRY="0", RWKV_CARRY_COUNT="1", RWKV_TILE="0")
     get = lambda out, key: [ln for ln in out.stdout.splitlines() if ln.startswith(key)]
     assert get(on, "IDS") and get(on, "IDS") == get(off, "IDS"), on.stdout[-600:] + on.stderr[-600:] + off.stdout[-300:]
     assert get(on, "LOGITS") == get(off, "LOGITS")
@@ -483,8 +486,8 @@ def test_damaged_carried_rows_are_reloaded_not_used(fault_libs):
     workgroup finds its rows and re-loads one group."""
     lib = fault_libs["corrupt"]
     L, D = 2, 4096
-    bad = _run_py(_CARRY_PROBE.format(root=ROOT, L=L, D=D), RWKV_LIB=lib, RWKV_CARRY="32")
-    ref = _run_py(_CARRY_PROBE.format(root=ROOT, L=L, D=D), RWKV_LIB=lib, RWKV_CARRY="0")
+    bad = _run_py(_CARRY_PROBE.format(root=ROOT, L=L, D=D), RWKV_LIB=lib, RWKV_CARRY="32", RWKV_TILE="0")
+    ref = _run_py(_CARRY_PROBE.format(root=ROOT, L=L, D=D), RWKV_LIB=lib, RWKV_CARRY="0", RWKV_TILE="0")
     get = lambda out, key: [ln for ln in out.stdout.splitlines() if ln.startswith(key)]
     assert "RWKVERROR" not in bad.stdout and get(bad, "IDS"), bad.stdout[-500:] + bad.stderr[-400:]
     assert get(bad, "IDS") == get(ref, "IDS") and get(bad, "LOGITS") == get(ref, "LOGITS"), bad.stdout[-400:] + ref.stdout[-400:]
@@ -494,8 +497,8 @@ def test_damaged_carried_rows_are_reloaded_not_used(fault_libs):
     assert miss == 0 and hit == 25 * (3 * L - 1) * grid and repaired == hit, (hit, miss, repaired)
 
 
-@pytest.mark.parametrize("shared", [True, False])
-def test_two_contexts_decoding_at_once_do_not_take_each_others_rows(built, shared, monkeypatch):
+@pytest.mark.parametrize("shared,tile", [(True, "0"), (False, "0"), (False, "15")])
+def test_two_contexts_decoding_at_once_do_not_take_each_others_rows(built, shared, tile, monkeypatch):
     """two contexts of one process, a stream and a host thread each, greedy-decoding AT THE SAME TIME.  With the carry forced on
     (RWKV_CARRY_SHARED=1) their kernels interleave on the CUs, so a workgroup regularly finds that another context's kernel has had
     its CU since its predecessor left rows there (every ring kernel clears the stamp on entry; the stamp carries the context's
@@ -507,6 +510,7 @@ def test_two_contexts_decoding_at_once_do_not_take_each_others_rows(built, share
         monkeypatch.setenv("RWKV_CARRY_SHARED", "1")
     else:
         monkeypatch.delenv("RWKV_CARRY_SHARED", raising=False)
+    monkeypatch.setenv("RWKV_TILE", tile)       # "0": the row-form kernels and their carry; "15": the tile-form kernels a 4096-wide model gets by default
     import torch
     from rwkv_cpp_accelerated_amd import engine
     L, D, steps = 4, 4096, 96
@@ -538,3 +542,68 @@ def test_two_contexts_decoding_at_once_do_not_take_each_others_rows(built, share
     for m in ms:
         m.close()
     torch.cuda.synchronize()
+
+
+def test_tile_form_decode_is_the_row_form_bit_for_bit_on_one_weight_image(built, monkeypatch):
+    """A 4096-wide model on 256 CUs decodes in TILE form by default (csrc/tile.hip.h: the four per-layer kernels stream the MFMA B-operand
+    image the chunk path uses, v_dot4_i32_i8 on signed limbs, exact integer sums met in LDS) and holds ONLY that image of the per-layer
+    matrices.  Every row value is the same exact integer as in row form (RWKV_TILE=0), so greedy ids AND logits must be identical, step
+    after step -- also on a second state slot (PARRALEL mode through the token-by-token path, RWKV_SEQ=0) and on a context that owns a layer
+    range (pipeline stage) -- and the resident bytes must be those of ONE copy of the matrices."""
+    import torch
+    from rwkv_cpp_accelerated_amd import engine
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("tile form is chosen where a workgroup owns one 16-channel block: D = 4096 on 256 CUs")
+    L, D = 3, 4096
+    t = mf.synthetic_tensors(L, D, seed=77)
+    monkeypatch.setenv("RWKV_TILE", "0")
+    row = engine.RWKV(resident=True); row.loadTensors(L, D, t, maxGPT=2)
+    monkeypatch.delenv("RWKV_TILE")
+    til = engine.RWKV(resident=True); til.loadTensors(L, D, t, maxGPT=2)
+    weights = 13 * L * D * D + mf.VOCAB * D
+    assert til.resident_bytes() < row.resident_bytes() - 0.9 * (weights - mf.VOCAB * D), (til.resident_bytes(), row.resident_bytes())
+    tk = 9
+    for step in range(12):
+        a = row.forward(tk)[: mf.VOCAB].copy(); b = til.forward(tk)[: mf.VOCAB].copy()
+        assert np.array_equal(a, b), step
+        tk = parity.argmax_ban0(a)
+    assert np.array_equal(row.decode_greedy(tk, 16), til.decode_greedy(tk, 16))
+    row.close(); til.close()
+    # two state slots, token by token (RWKV_SEQ=0 keeps PARRALEL mode on the decode kernels): slot 1's state offset in the tile epilogues
+    monkeypatch.setenv("RWKV_SEQ", "0")
+    outs = []
+    for tile in ("0", None):
+        if tile is None:
+            monkeypatch.delenv("RWKV_TILE", raising=False)
+        else:
+            monkeypatch.setenv("RWKV_TILE", tile)
+        m = engine.RWKV(resident=True); m.loadTensors(L, D, t, maxGPT=2)
+        o = []
+        for pair in ([5, 900], [17, 33], [2, 40000]):
+            o.append(m.forward(pair, engine.MODE_PARRALEL)[: 2 * mf.VOCAB].copy())
+        outs.append(o)
+        m.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    monkeypatch.delenv("RWKV_SEQ")
+    # contexts that own a layer range (pipeline stages): the stages' kernels in tile form, chained on this one GPU
+    from rwkv_cpp_accelerated_amd import pipeline
+    st = []
+    for tile in ("0", None):
+        if tile is None:
+            monkeypatch.delenv("RWKV_TILE", raising=False)
+        else:
+            monkeypatch.setenv("RWKV_TILE", tile)
+        stages = [pipeline.EngineStage(t, L, D, l0, l1, n_slots=1) for l0, l1 in ((0, 1), (1, 3))]
+        picks, tk = [], 21
+        for step in range(6):
+            for i, sg in enumerate(stages):
+                if i > 0:
+                    sg.x.copy_(stages[i - 1].x); torch.cuda.synchronize()
+                nxt = sg.forward(tk, 0, want_pick=sg.last)
+            tk = nxt
+            picks.append(tk)
+        st.append((picks, stages[-1].m.logits(1)[: mf.VOCAB].copy()))
+        for sg in stages:
+            sg.m.close()
+    assert st[0][0] == st[1][0] and np.array_equal(st[0][1], st[1][1]), (st[0][0], st[1][0])
