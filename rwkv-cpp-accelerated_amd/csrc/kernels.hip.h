@@ -1218,12 +1218,20 @@ template <int R, int S>
 __device__ __forceinline__ void carry_check_taken(u32x4 (&w)[R][S], int k, const CarryCheck &ck, const GldsCtl *ctl, int lane)
 {
     const unsigned want = lane < ck.nrs ? ctl->csum[(k * ck.nrs + lane) & 63] : 0u;
+    // (the weight of a piece depends on its place in the row only: the rows' pieces of one step are summed first, one multiply per step)
     unsigned t = 0u;
 #pragma unroll
-    for (int r = 0; r < R; r++)
+    for (int s = 0; s < S; s++) {
+        unsigned a = 0u;
 #pragma unroll
-        for (int s = 0; s < S; s++)
-            if (lane + 64 * s < ck.chunks) t += ck_piece(w[r][s], lane + 64 * s);
+        for (int r = 0; r < R; r++) {
+            a = __builtin_amdgcn_udot4(w[r][s][0], CK_PAT0, a, false);
+            a = __builtin_amdgcn_udot4(w[r][s][1], CK_PAT1, a, false);
+            a = __builtin_amdgcn_udot4(w[r][s][2], CK_PAT2, a, false);
+            a = __builtin_amdgcn_udot4(w[r][s][3], CK_PAT3, a, false);
+        }
+        if (lane + 64 * s < ck.chunks) t += a * (unsigned)(lane + 64 * s + 1);
+    }
     if (wave_sum_dpp(t) != wave_sum_dpp(want)) {
         const uint8_t *src = ck.w + (size_t)(ck.g0 + k) * R * ((size_t)ck.chunks << 4);
 #pragma unroll
@@ -1285,6 +1293,10 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
     constexpr bool ET = early_take<S>() && !CARRIED;
     bool first = true;
     if (!ET) { ready(); first = false; }
+    // (`carried` was set by the loader in front of the order barrier, ready() is behind it; read ONCE: a look into LDS per group would put a
+    // round trip under the loader's stream on every group's path)
+    int ncar = 0;
+    if constexpr (CARRIED && RWKV_CARRY_VERIFY == 1) ncar = __builtin_amdgcn_readfirstlane((int)ctl->carried);
     const bool late_pre = ET && wave >= NWP;       // the waves that take their first group before the vectors are staged
     for (int g = g0 + (ET ? (wave + NC - NWP) % NC : wave); g < g1; g += NC) {
         decltype(pre(g)) in;
@@ -1296,8 +1308,7 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
         glds_take<R, S>(w, g - g0, nu, ring, ctl, lane, fail, pos0);
         if (first) { ready(); if (late_pre) in = pre(g); first = false; }
         if constexpr (CARRIED && RWKV_CARRY_VERIFY == 1) {
-            // (`carried` was set by the loader in front of the order barrier; only a wave's first group can be a carried one: carried <= NC)
-            if (g - g0 < __builtin_amdgcn_readfirstlane((int)ctl->carried)) carry_check_taken<R, S>(w, g - g0, ck, ctl, lane);
+            if (g - g0 < ncar) carry_check_taken<R, S>(w, g - g0, ck, ctl, lane);
         }
 #ifdef RWKV_TL_GROUPS
         asm volatile("" : "+v"(w[R - 1][S - 1]));
