@@ -403,7 +403,7 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     tensors = mf.synthetic_tensors_torch(L, D, seed=args.seed, device=dev)     # same seed on every rank: one model
     l0, l1 = pipeline.partition_layers(L, world, D)[rank]
     native = (dist.get_backend() == "nccl" or bool(os.environ.get("RWKV_RCCL_LIB"))) and os.environ.get("RWKV_BENCH_NATIVE", "1") == "1"
-    stage = pipeline.EngineStage(tensors, L, D, l0, l1, n_slots=world, device=local_rank, prefill=native and args.prefill_chunks > 0)
+    stage = pipeline.EngineStage(tensors, L, D, l0, l1, n_slots=2 * world, device=local_rank, prefill=native and args.prefill_chunks > 0)
     lastr = rank == world - 1
     if not (lastr or rank == 0):
         del tensors
@@ -538,9 +538,10 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     transport = ("RCCL ncclSend/ncclRecv of the residual vector inside the engine, on its stream" if native and dist.get_backend() == "nccl"
                  else "the engine's native schedule over the shared-memory RCCL stand-in (tests/fake_rccl.cpp; dry run)" if native
                  else "torch.distributed P2P ops (Python schedule)" + ("" if native_note is None else " -- FALLBACK: the engine-side RCCL transport did not come up"))
+    out = None
     if rank == 0:
         worst = min(per_stage)
-        print(json.dumps(dict(
+        out = (dict(
             metric=f"tokens/sec RWKV-4 uint8 greedy decode, layers pipelined over {world} GPUs, AGGREGATE of {world} streams in flight (one per stage); "
                    "one_stream.tokens_per_s is the single-stream rate on the same pipeline",
             value=round(tok_s, 2), unit="tokens/s",
@@ -563,7 +564,41 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
                             note=f"ONE stream in flight through the {world} stages (rwkv_pipe_decode_streams, n_streams = 1): "
                                  "t_tok(1 GPU) + (N - 1) hops + the fed-back id per token (SURVEY 8e); N - 1 GPUs idle at any time"),
             hop=hop, parity_vs_single_gpu=parity, cpu_baseline=cpu,
-            prefill=prefill, transport_fallback=native_note, transport_info=tinfo)), flush=True)
+            prefill=prefill, transport_fallback=native_note, transport_info=tinfo))
+    # ---- two streams per stage in flight on two communicators: one parity's hop under the other's stage (rwkv_pipe_decode_dual) ----
+    # LAST, and under its own watchdog: this schedule has never met real RCCL either; if it hangs, the line measured so far is printed
+    # with the leg marked as timed out and the run exits non-zero -- a new leg must not cost the record of the established ones
+    dual = None
+    if native and os.environ.get("RWKV_BENCH_DUAL", "1") == "1":
+        import threading
+
+        def give_up():
+            if rank == 0 and out is not None:
+                out["two_streams_per_stage"] = dict(error="timed out: the two-communicator schedule did not finish")
+                print(json.dumps(out), flush=True)
+            os._exit(5)
+        timer = threading.Timer(float(os.environ.get("RWKV_BENCH_DUAL_TIMEOUT_S", "240")), give_up)
+        timer.daemon = True
+        timer.start()
+        first2 = [int(x) for x in np.random.default_rng(2).integers(2, mf.VOCAB, 2 * world)]
+        try:
+            stage.m.reset_state()
+            pipeline.run_pipeline_native_dual(stage, rank, world, first2, max(2, args.warmup // world))
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipeline.run_pipeline_native_dual(stage, rank, world, first2, args.steps)
+            dist.barrier(); torch.cuda.synchronize()
+            td = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            dual = dict(streams=2 * world, tokens_per_s=round(2 * world * args.steps / float(td.item()), 2), ms_per_step=round(1e3 * float(td.item()) / args.steps, 5),
+                        note="2 x N streams in flight, the streams of even / odd index on their own communicator and HIP stream, the stage alternating "
+                             "between them on the engine's stream: a tick costs max(t_stage, t_hop) instead of their sum (rwkv_pipe_decode_dual)")
+        except Exception as e:          # noqa: BLE001
+            dual = dict(error=str(e)[:300])
+        timer.cancel()
+    if rank == 0:
+        out["two_streams_per_stage"] = dual
+        print(json.dumps(out), flush=True)
     faulthandler.cancel_dump_traceback_later()
     dist.barrier()
     dist.destroy_process_group()

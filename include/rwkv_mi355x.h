@@ -177,6 +177,12 @@ int rwkv_pipe_init(rwkv_ctx *ctx, const void *id128, int rank, int world);
 int rwkv_pipe_info(rwkv_ctx *ctx, char *out, uint64_t cap);
 int rwkv_pipe_decode(rwkv_ctx *ctx, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks);
 int rwkv_pipe_decode_streams(rwkv_ctx *ctx, const uint64_t *first_tokens, uint64_t n_steps, uint64_t n_streams, uint64_t *picks);
+/* 2 x world streams in flight on TWO communicators (the second one is created at the first call, its id travels over the first): the
+ * streams of even and odd index run the tick schedule above on their own communicator and HIP stream, the stage alternates between
+ * them on the engine's stream -- one parity's hop is in flight while the stage works on the other's item (a tick costs
+ * max(t_stage, t_hop) instead of their sum).  first_tokens[2 * world] (rank 0), picks[2 * world][n_steps] (last rank); needs
+ * max_ctx >= 2 * world state slots.  Every rank of the pipeline must call it. */
+int rwkv_pipe_decode_dual(rwkv_ctx *ctx, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks);
 int rwkv_pipe_profile(rwkv_ctx *ctx, int on);
 int rwkv_pipe_hop_stats(rwkv_ctx *ctx, double *out4);
 int rwkv_pipe_prefill(rwkv_ctx *ctx, const uint64_t *tokens, uint64_t n_tokens);

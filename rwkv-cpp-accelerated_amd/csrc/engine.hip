@@ -139,6 +139,13 @@ struct Pipe {
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     int (*GetVersion)(int *) = nullptr;
+    // two-communicator schedule (rwkv_pipe_decode_dual): sub-schedule k = streams of parity k on comm k (comm / comm2) and HIP stream cs[k],
+    // hop buffers per parity, events between the comm streams and the engine's compute stream
+    void *comm2 = nullptr;
+    hipStream_t cs[2] = {nullptr, nullptr};
+    double *xin[2] = {nullptr, nullptr}, *xout[2] = {nullptr, nullptr};
+    unsigned long long *idbuf[2] = {nullptr, nullptr};
+    hipEvent_t ev_rx[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
     uint64_t ch = 0;             // rows per prefill micro-batch every rank of this pipeline agreed on (rwkv_pipe_init)
     std::string info;            // one JSON object describing this rank's end of the transport (rwkv_pipe_info)
 };
@@ -2234,6 +2241,146 @@ int rwkv_pipe_decode_streams(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t
     return rc;
 }
 
+// ---- 2 x world streams in flight on TWO communicators: the hop under the compute -------------------------------------------------------
+// rwkv_pipe_decode* above runs hop and stage strictly one after the other on the engine's stream: every tick costs t_hop + t_stage.  Here a
+// rank keeps TWO independent copies of that schedule going -- the streams of even index on communicator 0 and HIP stream cs[0], those of odd
+// index on communicator 1 and cs[1], each with its own hop buffers -- and ONE compute stream (the engine's) that alternates between them:
+// while the stage works on parity 0's item, parity 1's RCCL group {send the previous result | recv the next input} is in flight, and vice
+// versa.  A tick costs max(t_stage, t_hop) once both are primed.  Two communicators, because operations of one communicator are serialised
+// in the order they were enqueued whatever stream they are on: a receive that waits for its peer would hold the other parity's send behind
+// it.  Each sub-schedule is the tick schedule of rwkv_pipe_decode_streams (same group composition, same deadlock argument); events order
+// the comm streams against the compute stream: ev_rx[k] (the group's receives have landed) and ev_cp[k] (the stage's output is in
+// xout[k], xin[k] has been consumed).  Results are those of 2 x world independent greedy decodes (stream g on state slot g).
+namespace {
+int pipe_dual_setup(rwkv_ctx *c)
+{
+    Pipe *p = c->pipe;
+    if (p->cs[0]) return 0;
+    const int S = p->world, rank = p->rank;
+    if (S > 1 && !p->comm2) {
+        // the second communicator's id is made by rank 0 and travels over the first one (16 x u64)
+        unsigned long long *d = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), sizeof(Pipe::Id)));
+        Pipe::Id id;
+        memset(&id, 0, sizeof(id));
+        int r = 0;
+        if (rank == 0) {
+            NCHK(p->GetUniqueId(&id));
+            HIPCHK(hipMemcpyAsync(d, id.b, sizeof(id.b), hipMemcpyHostToDevice, c->stream));
+            r = p->GroupStart();
+            for (int q = 1; q < S && !r; q++) r = p->Send(d, sizeof(id.b) / 8, kNcclUint64, q, p->comm, c->stream);
+            const int r2 = p->GroupEnd();
+            if (!r) r = r2;
+        } else {
+            r = p->Recv(d, sizeof(id.b) / 8, kNcclUint64, 0, p->comm, c->stream);
+            if (!r && hipMemcpyAsync(id.b, d, sizeof(id.b), hipMemcpyDeviceToHost, c->stream) != hipSuccess) r = -1;
+        }
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d);
+        if (r) return pipe_fail(p, r > 0 ? r : 1, "exchange of the second communicator's id");
+        HIPCHK(e);
+        r = p->CommInitRank(&p->comm2, S, id, rank);
+        if (r) { p->comm2 = nullptr; return pipe_fail(p, r, "ncclCommInitRank (second communicator)"); }
+    }
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(hipStreamCreateWithFlags(&p->cs[k], hipStreamNonBlocking));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&p->xin[k]), c->D * sizeof(double)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&p->xout[k]), c->D * sizeof(double)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&p->idbuf[k]), 64));
+        HIPCHK(hipEventCreateWithFlags(&p->ev_rx[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p->ev_cp[k], hipEventDisableTiming));
+    }
+    return 0;
+}
+} // namespace
+
+// first_tokens: [2 * world] (read on rank 0); picks: [2 * world][n_steps] (written on the last rank).  Needs max_ctx >= 2 * world state slots.
+int rwkv_pipe_decode_dual(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks)
+{
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    if (!c->loaded || !c->pipe) return fail(RWKV_E_STATE, "needs a loaded context with rwkv_pipe_init done");
+    Pipe *p = c->pipe;
+    const int S = p->world, rank = p->rank;
+    const bool lastr = rank == S - 1;
+    const uint64_t n_sub = (uint64_t)S * n_steps;             // items of ONE sub-schedule
+    if (n_steps == 0 || 2 * n_sub > c->gen_cap) return fail(RWKV_E_ARG, "2 * world * n_steps must be in 1..%u", c->gen_cap);
+    if ((uint64_t)(2 * S) > c->maxT) return fail(RWKV_E_ARG, "needs max_ctx >= %d state slots (two streams per stage in flight)", 2 * S);
+    if (rank == 0 && !first_tokens) return fail(RWKV_E_ARG, "rank 0 needs first_tokens");
+    if (lastr && !picks) return fail(RWKV_E_ARG, "the last rank needs picks");
+    bool bad_id = false;
+    if (rank == 0)
+        for (int g = 0; g < 2 * S; g++) bad_id = bad_id || first_tokens[g] >= RWKV_VOCAB;
+    HIPCHK(hipSetDevice(c->device));
+    const int rc_begin = begin_call(c);
+    { const int rs = pipe_dual_setup(c); if (rs) return rs; }
+    if (c->pipe_ring_cap < 2 * n_sub) {
+        if (c->pipe_ring) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->pipe_ring); c->pipe_ring = nullptr; c->pipe_ring_cap = 0; }
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->pipe_ring), sizeof(Ctl) * 2 * n_sub, hipHostMallocDefault));
+        c->pipe_ring_cap = 2 * n_sub;
+    }
+    // item (k, i): sub-schedule k, sub-item i -> global stream g = 2 (i % S) + k, step i / S, id J = 2 i + k (its slot in the pick list)
+    Ctl *ring = c->pipe_ring;
+    for (uint64_t i = 0; i < n_sub; i++)
+        for (int k = 0; k < 2; k++) {
+            const uint64_t J = 2 * i + k, g = 2 * (i % S) + k, step = i / S;
+            ring[J].token = (rank == 0 && step == 0) ? (first_tokens[g] < RWKV_VOCAB ? first_tokens[g] : 0) : 0;
+            ring[J].slot = (unsigned)g; ring[J].out_row = (unsigned)g; ring[J].step = (unsigned)J; ring[J].pad = 0;
+        }
+    auto has_work = [&](int r, uint64_t t) { return t >= (uint64_t)r && t - r < n_sub; };
+    int rc = 0;
+    // everything enqueued so far on the engine's stream precedes the comm streams' first operation
+    for (int k = 0; k < 2 && !rc; k++) {
+        if (hipEventRecord(p->ev_cp[k], c->stream) != hipSuccess || hipStreamWaitEvent(p->cs[k], p->ev_cp[k], 0) != hipSuccess) rc = fail(RWKV_E_DEVICE, "event setup failed");
+    }
+    for (uint64_t tick = 0; tick < n_sub + S - 1 && !rc; tick++) {
+        const bool work = has_work(rank, tick);
+        const bool feedback = tick >= (uint64_t)S && tick < n_sub;       // stage 0 starts a step >= 1: its token is the last stage's pick
+        const uint64_t i = tick - rank;
+        // ---- the hops of both parities, each on its own communicator and stream ----
+        for (int k = 0; k < 2 && !rc && S > 1; k++) {
+            void *comm = k == 0 ? p->comm : p->comm2;
+            hipStream_t cs = p->cs[k];
+            if (tick > 0 && has_work(rank, tick - 1) && hipStreamWaitEvent(cs, p->ev_cp[k], 0) != hipSuccess) { rc = fail(RWKV_E_DEVICE, "event wait failed"); break; }
+            int r = p->GroupStart();
+            if (!r && rank < S - 1 && has_work(rank + 1, tick)) r = p->Send(p->xout[k], c->D, kNcclFloat64, rank + 1, comm, cs);
+            if (!r && lastr && feedback) r = p->Send(c->gen + (2 * (tick - S) + k), 1, kNcclUint64, 0, comm, cs);      // sub-item tick - S: finished here one tick ago
+            if (!r && rank > 0 && work) r = p->Recv(p->xin[k], c->D, kNcclFloat64, rank - 1, comm, cs);
+            if (!r && rank == 0 && feedback) r = p->Recv(p->idbuf[k], 1, kNcclUint64, S - 1, comm, cs);
+            const int r2 = p->GroupEnd();
+            if (r || r2) { rc = pipe_fail(p, r ? r : r2, "RCCL hop"); break; }
+            if (hipEventRecord(p->ev_rx[k], cs) != hipSuccess) rc = fail(RWKV_E_DEVICE, "event record failed");
+        }
+        // ---- the stage, parity 0 then parity 1, on the engine's stream ----
+        for (int k = 0; k < 2 && !rc && work; k++) {
+            const uint64_t J = 2 * i + k;
+            if (S > 1 && hipStreamWaitEvent(c->stream, p->ev_rx[k], 0) != hipSuccess) { rc = fail(RWKV_E_DEVICE, "event wait failed"); break; }
+            if (hipMemcpyAsync(c->ctl, &ring[J], sizeof(Ctl), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(RWKV_E_DEVICE, "control block copy failed"); break; }
+            if (feedback && rank == 0) {
+                const void *src = S > 1 ? static_cast<const void *>(p->idbuf[k]) : static_cast<const void *>(c->gen + (J - 2 * (uint64_t)S));
+                if (hipMemcpyAsync(&c->ctl->token, src, sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) { rc = fail(RWKV_E_DEVICE, "id copy failed"); break; }
+            }
+            if (rank > 0 && hipMemcpyAsync(c->x_in, p->xin[k], c->D * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) { rc = fail(RWKV_E_DEVICE, "hop copy failed"); break; }
+            rc = run_token(c, lastr);
+            if (!rc && rank < S - 1 && hipMemcpyAsync(p->xout[k], c->x, c->D * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = fail(RWKV_E_DEVICE, "hop copy failed");
+            if (!rc && hipEventRecord(p->ev_cp[k], c->stream) != hipSuccess) rc = fail(RWKV_E_DEVICE, "event record failed");
+        }
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 2; k++) { const hipError_t e2 = hipStreamSynchronize(p->cs[k]); if (e == hipSuccess) e = e2; }
+    if (!rc && e != hipSuccess) rc = fail(RWKV_E_DEVICE, "pipeline decode (dual): %s", hipGetErrorString(e));
+    if (!rc && lastr) {
+        std::vector<uint64_t> g(2 * n_sub);
+        if (hipMemcpy(g.data(), c->gen, 2 * n_sub * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RWKV_E_DEVICE, "copy of the picks failed");
+        else
+            for (uint64_t i = 0; i < n_sub; i++)
+                for (int k = 0; k < 2; k++) picks[(2 * (i % S) + k) * n_steps + i / S] = g[2 * i + k];
+    }
+    { const int dc = device_check(c); if (!rc) rc = dc; }
+    if (!rc && rc_begin) rc = rc_begin;
+    if (!rc && bad_id) rc = fail(RWKV_E_ARG, "token id out of range (the schedule ran with id 0 in its place)");
+    return rc;
+}
+
 int rwkv_pipe_decode(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t n_steps, uint64_t *picks)
 {
     if (!c || !c->pipe) return fail(RWKV_E_STATE, "needs a loaded context with rwkv_pipe_init done");
@@ -2360,6 +2507,15 @@ void rwkv_pipe_free(rwkv_ctx *c)
 {
     if (!c || !c->pipe) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 2; k++) {
+        if (c->pipe->cs[k]) { (void)hipStreamSynchronize(c->pipe->cs[k]); (void)hipStreamDestroy(c->pipe->cs[k]); }
+        if (c->pipe->xin[k]) (void)hipFree(c->pipe->xin[k]);
+        if (c->pipe->xout[k]) (void)hipFree(c->pipe->xout[k]);
+        if (c->pipe->idbuf[k]) (void)hipFree(c->pipe->idbuf[k]);
+        if (c->pipe->ev_rx[k]) (void)hipEventDestroy(c->pipe->ev_rx[k]);
+        if (c->pipe->ev_cp[k]) (void)hipEventDestroy(c->pipe->ev_cp[k]);
+    }
+    if (c->pipe->comm2 && c->pipe->CommDestroy) (void)c->pipe->CommDestroy(c->pipe->comm2);
     if (c->pipe->comm && c->pipe->CommDestroy) (void)c->pipe->CommDestroy(c->pipe->comm);
     delete c->pipe;
     c->pipe = nullptr;

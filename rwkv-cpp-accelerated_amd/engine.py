@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
     "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_debug_carry_hits", "rwkv_debug_carry_stats", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
     "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_rccl_path", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode", "rwkv_pipe_decode_streams", "rwkv_pipe_profile", "rwkv_pipe_hop_stats",
-    "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device", "rwkv_pipe_info",
+    "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device", "rwkv_pipe_info", "rwkv_pipe_decode_dual",
 ]
 
 _lib = None
@@ -95,6 +95,7 @@ def lib():
     L.rwkv_pipe_prefill.argtypes = [vp, C.POINTER(u64), u64]; L.rwkv_pipe_prefill.restype = i32
     L.rwkv_pipe_free.argtypes = [vp]; L.rwkv_pipe_free.restype = None
     L.rwkv_pipe_info.argtypes = [vp, C.c_char_p, u64]; L.rwkv_pipe_info.restype = i32
+    L.rwkv_pipe_decode_dual.argtypes = [vp, C.POINTER(u64), u64, C.POINTER(u64)]; L.rwkv_pipe_decode_dual.restype = i32
     L.rwkv_tensor_device.argtypes = [vp, i32]; L.rwkv_tensor_device.restype = vp
     _lib = L
     return L
@@ -263,6 +264,15 @@ class RWKV:
         picks = (C.c_uint64 * (world * n_steps))() if last else None
         _chk(lib().rwkv_pipe_decode_streams(self._h, ft, n_steps, world if n_streams is None else n_streams, picks))
         return np.frombuffer(picks, dtype=np.uint64).reshape(world, n_steps).astype(np.int64) if last else None
+
+    def pipe_decode_dual(self, first_tokens, n_steps: int, world: int, last: bool):
+        """greedy decode of 2 * world streams, two per stage in flight on two communicators (the hop of one under the stage of the other);
+        [2 * world][n_steps] ids on the last rank"""
+        n = 2 * world
+        ft = (C.c_uint64 * n)(*([int(t) for t in first_tokens] + [0] * n)[:n]) if first_tokens is not None else None
+        picks = (C.c_uint64 * (n * n_steps))() if last else None
+        _chk(lib().rwkv_pipe_decode_dual(self._h, ft, n_steps, picks))
+        return np.frombuffer(picks, dtype=np.uint64).reshape(n, n_steps).astype(np.int64) if last else None
 
     def pipe_profile(self, on: bool = True):
         _chk(lib().rwkv_pipe_profile(self._h, 1 if on else 0))

@@ -141,6 +141,12 @@ def run_pipeline_native(stage, rank, world, first_tokens, n_steps, n_streams=Non
     return stage.m.pipe_decode(first_tokens if rank == 0 else None, n_steps, world, last=(rank == world - 1), n_streams=n_streams)
 
 
+def run_pipeline_native_dual(stage, rank, world, first_tokens, n_steps):
+    """greedy decode of 2 * world streams, two per stage in flight: the engine's two-communicator schedule (rwkv_pipe_decode_dual), one
+    parity's RCCL hop under the other's stage.  [2 * world][n_steps] ids on the last rank.  The stage needs 2 * world state slots."""
+    return stage.m.pipe_decode_dual(first_tokens if rank == 0 else None, n_steps, world, last=(rank == world - 1))
+
+
 def run_prefill_native(stage, rank, tokens, n_tokens):
     """pipelined prompt ingestion (32-token chunks as micro-batches) with the hop inside the engine"""
     stage.m.pipe_prefill(tokens if rank == 0 else None, n_tokens)

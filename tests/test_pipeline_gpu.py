@@ -156,10 +156,14 @@ def _native_worker(rank, world, port, first_tokens, L, D, seed, steps, prompt, q
                 bad = str(e)
         else:
             pipeline.run_prefill_native(st, rank, None, 43)
+        # 2 x world streams on two communicators (rwkv_pipe_decode_dual): fresh state, every rank takes part
+        st.m.reset_state()
+        first2 = [(7 * g + 3) % 50000 + 2 for g in range(2 * world)]
+        picks2 = pipeline.run_pipeline_native_dual(st, rank, world, first2, steps)
         if rank == 0:
             q.put(("rank0", bad))
         if rank == world - 1:
-            q.put(("ok", picks, lg, picks1, hop, info))
+            q.put(("ok", picks, lg, picks1, hop, info, picks2, first2))
         dist.barrier()
         st.m.close()
         dist.destroy_process_group()
@@ -174,7 +178,8 @@ def test_native_transport_with_several_ranks_on_one_gpu(eng_mod, world):
     refuses two ranks on one device and a gpurun box has one GPU).  Exercises what world = 1 cannot: the composition of the
     per-tick group, the (ci - 1) & 1 / ci & 1 buffer parity of the prefill hop, the recv of the fed-back id into the control
     block behind its memcpy, the item order of the picks.  Picks and last-chunk logits must be bit-identical to a single
-    whole-model context; a bad token id fails on rank 0 without stranding the other ranks."""
+    whole-model context; a bad token id fails on rank 0 without stranding the other ranks.  Then the two-communicator schedule
+    (rwkv_pipe_decode_dual: 2 x world streams, one parity's hop under the other's stage): every stream's picks equal a decode alone."""
     import torch.multiprocessing as mp
     if not os.path.exists(FAKE_RCCL):
         pytest.fail("tests/_build/libfake_rccl.so is missing: run __graft_entry__.build()")
@@ -201,7 +206,7 @@ def test_native_transport_with_several_ranks_on_one_gpu(eng_mod, world):
                 p.kill()
     assert "error" not in res, res["error"]
     assert "out of range" in (res["rank0"][1] or ""), res["rank0"]
-    _, picks, lg, picks1, hop, info = res["ok"]
+    _, picks, lg, picks1, hop, info, picks2, first2 = res["ok"]
     # rwkv_pipe_info: what the first run on real xGMI will be diagnosed from (here: the stand-in's version code 1 and its path)
     assert info["rank"] == world - 1 and info["world"] == world and info["prefill_rows"] == 64 and info["rccl_version"] == 1, info
     assert info["rccl_path"].endswith("libfake_rccl.so") and info["device"] == 0 and info["arch"].startswith("gfx"), info
@@ -226,6 +231,14 @@ def test_native_transport_with_several_ranks_on_one_gpu(eng_mod, world):
         cur = parity.argmax_ban0(m.forward(cur)[: mf.VOCAB]); ids.append(cur)
     assert list(picks1[0]) == ids and not picks1[1:].any(), picks1
     assert hop["n"] == steps and 0.0 < hop["min_us"] <= hop["mean_us"] <= hop["max_us"], hop
+    # rwkv_pipe_decode_dual: 2 x world independent streams, two per stage in flight on two communicators; every stream from a fresh state
+    assert picks2.shape == (2 * world, steps)
+    for g, tk in enumerate(first2):
+        m.reset_state()
+        cur, ids = tk, []
+        for _ in range(steps):
+            cur = parity.argmax_ban0(m.forward(cur)[: mf.VOCAB]); ids.append(cur)
+        assert list(picks2[g]) == ids, (g, list(picks2[g]), ids)
     m.close()
 
 
