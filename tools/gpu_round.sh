@@ -42,7 +42,8 @@ for f in glob.glob(O + "/kt/**/*domain_stats.csv", recursive=True): shutil.copy(
 rows = list(csv.reader(open(O + "/bench7b_kernel_stats.csv")))
 for r in rows[:10]: print([c[:60] for c in r[:6]])
 alg = dict(att_kvr_wkv=3, att_out=1, ffn_rk=5, ffn_v=4)
-names = {"k_att<": "att_kvr_wkv", "k_attout<": "att_out", "k_ffn_rk<": "ffn_rk", "k_ffnv<": "ffn_v", "k_head<": "head"}
+names = {"k_att<": "att_kvr_wkv", "k_attout<": "att_out", "k_ffn_rk<": "ffn_rk", "k_ffnv<": "ffn_v", "k_head<": "head",
+         "k_att_t<": "att_kvr_wkv", "k_attout_t<": "att_out", "k_ffn_rk_t<": "ffn_rk", "k_ffnv_t<": "ffn_v"}      # (row form | tile form, tile.hip.h)
 agg = collections.defaultdict(list)
 for f in glob.glob(O + "/pmc/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
