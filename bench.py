@@ -226,20 +226,21 @@ def main():
         kernels={k: dict(us=round(v["us"], 3), GBps=round(v["gbps"], 1), us_event_pair=round(v["us_event_pair"], 3))
                  for k, v in per_launch.items()},
         load_s=round(load_s, 2),
-        carry=dict(RWKV_CARRY=os.environ.get("RWKV_CARRY", "default: 32 KiB per workgroup where rows are 4 KiB (7B), 20 where they are 3 KiB (3B), else off"),
+        carry=dict(RWKV_CARRY=os.environ.get("RWKV_CARRY", "default: off in a context with a tile-form class (7B, 14B); row form: 32 KiB per workgroup where rows are 4 KiB, 20 where they are 3 KiB (3B), else off"),
                    timed_region=dict(found=c_hit, not_found=c_miss, reloaded_after_failed_check=c_rep,
                                      hit_rate=(round(c_hit / (c_hit + c_miss), 6) if c_hit + c_miss else None)),
-                   note="ring kernels leave the first rows of the next ring kernel in the CU's LDS across the kernel boundary; every carried "
-                        "group is checked against a position-weighted row sum before use and re-loaded from memory if the check fails "
-                        "(DESIGN.md 4.5).  timed_region = workgroup launches of the TIMED decode that found / did not find their rows "
-                        "(one counter word per workgroup, counted inside the timed region itself).  The carry changes no result "
-                        "(bit-identical logits with RWKV_CARRY=0, tests/test_engine_gpu.py) and is worth +1.3 % at 7B"),
+                   note="row-form ring kernels leave the first rows of the next ring kernel in the CU's LDS across the kernel boundary; every "
+                        "carried group is checked against a position-weighted row sum as it is taken and re-loaded from memory if the check "
+                        "fails (DESIGN.md 4.5).  timed_region = workgroup launches of the TIMED decode that found / did not find their rows "
+                        "(one counter word per workgroup; all zero when the carry is off).  The carry changes no result (bit-identical logits "
+                        "with RWKV_CARRY=0, tests/test_engine_gpu.py); measured this round: +1 % at 3B, +-0 in row form at 7B"),
         hbm_resident_bytes=dict(total=m.resident_bytes(), weight_bytes_one_copy=13 * L * D * D + mf.VOCAB * D,
-                                note="device bytes of this context: weights + row-sum tables + embedding + state + scratch.  A 4096-wide model on 256 CUs "
-                                     "decodes in TILE form (csrc/tile.hip.h) and holds ONE image of the per-layer matrices -- the MFMA B-operand image the "
-                                     "chunk path multiplies -- plus the head in row form (and the head's tile image when max_ctx > 1); other widths (and "
-                                     "RWKV_TILE=0) keep the row-form matrices and, when max_ctx > 1, the tile image as a second copy (DESIGN.md 3)"),
-        decode_form=("tile" if os.environ.get("RWKV_TILE", "-1") not in ("0",) and D == 4096 and torch.cuda.get_device_properties(local_rank).multi_processor_count == 256 else "row"),
+                                note="device bytes of this context: weights + row-sum tables + embedding + state + scratch.  The matrices of a decode "
+                                     "kernel class are resident in the ONE layout its kernel streams: the tile image (csrc/tile.hip.h) for the classes in "
+                                     "decode_form.tile, the row form for the others, the head in row form.  The chunk path (max_ctx > 1) multiplies with the "
+                                     "16-row tile image of every matrix: the same image at 4096 channels, a second copy elsewhere (DESIGN.md 3)"),
+        decode_form=(lambda f: dict(mask=f, tile=[n for b, n in enumerate(("att_kvr_wkv", "att_out", "ffn_rk", "ffn_v")) if f >> b & 1],
+                                    row=[n for b, n in enumerate(("att_kvr_wkv", "att_out", "ffn_rk", "ffn_v")) if not f >> b & 1] + ["head"]))(m.decode_form()),
     )
 
     if drop_in is not None:

@@ -210,6 +210,11 @@ void *rwkv_stream(rwkv_ctx *ctx);
  * max_ctx > 1 on a whole-model context, the SECOND resident copy of the matrices in the MFMA B-operand image of the chunk
  * path (+7.2 GB at 7B, +13.9 GB at 14B). */
 uint64_t rwkv_resident_bytes(const rwkv_ctx *ctx);
+/* Which of the four per-layer decode kernel classes of a loaded context stream the tile image (csrc/tile.hip.h):
+ * bit 0 K/V/R + WKV, bit 1 att_out, bit 2 ffn k/r, bit 3 ffn_v; a clear bit = that class streams its matrices in row form.  A
+ * class's matrices are resident in the one layout its kernel streams (15 at 4096 channels on 256 CUs, 4 at 5120, 0 otherwise;
+ * RWKV_TILE=<mask> before the load overrides).  -1 without a loaded model. */
+int rwkv_decode_form(const rwkv_ctx *ctx);
 /* Carry counters since the previous call: out3[0] / out3[1] = workgroup launches of the decode kernels that found /
  * did not find, in their CU's LDS, the first weight rows their predecessor was asked to leave there; out3[2] = carried row groups
  * whose position-weighted checksum failed and that were re-loaded from memory before use (0 unless something else wrote the CU's

@@ -271,6 +271,10 @@ struct rwkv_ctx {
     float *sq_pk3 = nullptr, *sq_pk5 = nullptr, *sq_pk1 = nullptr;   // per-slice partial values [SEQ_O][SEQ_T][3D / 5D / D] of the K/V/R, ffn k/r, att_out | ffn_v GEMMs
     // second resident copy of the matrices (chunked path only): MFMA B-operand images, row sums per octant of K
     uint8_t *b_kvr = nullptr, *b_att = nullptr, *b_frk = nullptr, *b_fv = nullptr, *b_head = nullptr;
+    // tile images the tile-form DECODE kernels stream (tile.hip.h): the chunk path's own (16-row tiles) where a workgroup owns one 16-channel
+    // block, else a decode-only image of 4-row tiles
+    uint8_t *t_kvr = nullptr, *t_att = nullptr, *t_frk = nullptr, *t_fv = nullptr;
+    int tile_th = 0, tile_s = 0, tile_tpc = 0;     // rows per tile, KiB per ring unit, tiles per row class and workgroup (0: no tile form at this width)
     unsigned *r8_kvr = nullptr, *r8_att = nullptr, *r8_frk = nullptr, *r8_fv = nullptr, *r8_head = nullptr;
     std::vector<void *> allocs;
     size_t alloc_bytes = 0;                       // device bytes behind `allocs` (rwkv_resident_bytes)
@@ -308,18 +312,46 @@ int ring_units(int nv, int S, bool common) { return (int)((LDS_BYTES - RED_BYTES
 int ring_xq_bytes(int nv, int S, bool common) { return (common ? 4 : nv) * S * 3072; }
 size_t smem_ring3(int nv, int S, bool common) { return RED_BYTES + (size_t)ring_xq_bytes(nv, S, common) + sizeof(GldsCtl) + (size_t)ring_units(nv, S, common) * S * 1024; }
 
-// tile-form decode kernels (tile.hip.h; classes 1 att, 2 att_out, 3 ffn_rk, 4 ffn_v): ring of 4 KiB units behind each kernel's fixed LDS
-constexpr int TILE_SU = 4;
-size_t tile_fixed(int cls, int D) { return cls == 1 ? tile_fixed_att(D) : cls == 2 ? tile_fixed_attout(D) : cls == 3 ? tile_fixed_frk(D) : tile_fixed_fv(D); }
-int tile_units(int cls, int D)
+// tile-form decode kernels (tile.hip.h; classes 1 att, 2 att_out, 3 ffn_rk, 4 ffn_v): ring of S KiB units behind each kernel's fixed LDS.
+// Which widths have a tile form: those whose channels split into whole TH-row tiles per workgroup on this grid --
+//   D = 4096 on 256 CUs: 16 channels = ONE 16-row tile per class (the chunk path's own image; the default there)
+//   D = 5120 on 256 CUs: 20 channels = five 4-row tiles (a decode-only image of 4-row tiles)
+//   D = 2048 on 256 CUs:  8 channels = two 4-row tiles
+struct TileCfg { int th, s, tpc; };
+TileCfg tile_cfg_for(uint64_t D, int grid)
 {
-    const int nu = (cls == 1 ? 3 : cls == 3 ? 5 : cls == 4 ? 4 : 1) * (D / 64) / TILE_SU;          // units a workgroup streams
-    const int fit = (int)((LDS_BYTES - tile_fixed(cls, D)) / ((size_t)TILE_SU * 1024)) & ~1;         // (even: the loader moves pairs of units)
+    if (grid != 256) return TileCfg{0, 0, 0};
+    if (D == 4096) return TileCfg{16, 4, 1};
+    if (D == 5120) return TileCfg{4, 5, 5};
+    if (D == 2048) return TileCfg{4, 4, 2};
+    return TileCfg{0, 0, 0};
+}
+size_t tile_fixed(const rwkv_ctx *c, int cls)
+{
+    const int D = (int)c->D, cpw = c->tile_th * c->tile_tpc;
+    return cls == 1 ? tile_fixed_att(D, cpw) : cls == 2 ? tile_fixed_attout(D, cpw) : cls == 3 ? tile_fixed_frk(D, cpw) : tile_fixed_fv(D, cpw);
+}
+int tile_units(const rwkv_ctx *c, int cls)
+{
+    const int kbt = (int)((cls == 4 ? 4 * c->D : c->D) * c->tile_th / 1024);                         // fragments of a tile along K
+    const int nu = (cls == 1 ? 3 : cls == 3 ? 5 : 1) * c->tile_tpc * kbt / c->tile_s;                 // units a workgroup streams
+    const int fit = (int)((LDS_BYTES - tile_fixed(c, cls)) / ((size_t)c->tile_s * 1024)) & ~1;         // (even: the loader moves pairs of units)
     return std::min(fit, nu);
 }
-size_t tile_smem(int cls, int D) { return tile_fixed(cls, D) + (size_t)tile_units(cls, D) * TILE_SU * 1024; }
-// a class runs in tile form when asked to (RWKV_TILE bit cls - 1), the chunk path's image is loaded, and a workgroup owns exactly one 16-channel block
-bool tile_ok(const rwkv_ctx *c, int cls) { return c->tile > 0 && ((c->tile >> (cls - 1)) & 1) && c->b_frk != nullptr; }
+size_t tile_smem(const rwkv_ctx *c, int cls) { return tile_fixed(c, cls) + (size_t)tile_units(c, cls) * c->tile_s * 1024; }
+// a class runs in tile form when asked to (RWKV_TILE bit cls - 1) and its image is there
+bool tile_ok(const rwkv_ctx *c, int cls)
+{
+    const uint8_t *img = cls == 1 ? c->t_kvr : cls == 2 ? c->t_att : cls == 3 ? c->t_frk : c->t_fv;
+    return c->tile > 0 && ((c->tile >> (cls - 1)) & 1) && img != nullptr;
+}
+// launch of a tile-form kernel template for the context's configuration
+#define TILE_DISPATCH(c, CALL16, CALL4_5, CALL4_2)                                  \
+    do {                                                                            \
+        if ((c)->tile_th == 16) { CALL16; }                                         \
+        else if ((c)->tile_tpc == 5) { CALL4_5; }                                   \
+        else { CALL4_2; }                                                           \
+    } while (0)
 
 // k-blocks a wave of k_seq_gemm_p keeps in flight (K/V/R, ffn k/r at up to 4 KiB rows; a divisor of 8)
 #ifndef RWKV_SEQ_DEPTH0
@@ -540,9 +572,12 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
         AttArgs aa = mk.att(l);
         if (tile_ok(c, 1)) {
             AttTArgs ta;
-            ta.a = aa; ta.a.ns = tile_units(1, mk.D); ta.a.cy = RingCarry{};
-            ta.im.CB = mk.D / 16; ta.im.bimg = c->b_kvr + (size_t)(l - c->l0) * 3 * (size_t)ta.im.CB * 16 * mk.D;
-            k_att_t<4, TILE_SU, 64><<<dim3(grid), dim3(NT), tile_smem(1, mk.D), c->stream>>>(ta);
+            ta.a = aa; ta.a.ns = tile_units(c, 1); ta.a.cy = RingCarry{};
+            ta.im.CB = mk.D / c->tile_th; ta.im.bimg = c->t_kvr + (size_t)(l - c->l0) * 3 * (size_t)mk.D * mk.D;
+            const size_t sm = tile_smem(c, 1);
+            TILE_DISPATCH(c, (k_att_t<4, 4, 64, 16, 1><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
+                          (k_att_t<5, 5, 20, 4, 5><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
+                          (k_att_t<2, 4, 8, 4, 2><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)));
         }
         else if (c->ring & 1) {
             aa.ns = ring_units(3, S, mk.common);
@@ -555,9 +590,12 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
         AttOutArgs ao = mk.attout(l);
         if (tile_ok(c, 2)) {
             AttOutTArgs ta;
-            ta.a = ao; ta.a.ns = tile_units(2, mk.D); ta.a.cy = RingCarry{};
-            ta.im.CB = mk.D / 16; ta.im.bimg = c->b_att + (size_t)(l - c->l0) * (size_t)ta.im.CB * 16 * mk.D;
-            k_attout_t<4, TILE_SU, 64><<<dim3(grid), dim3(NT), tile_smem(2, mk.D), c->stream>>>(ta);
+            ta.a = ao; ta.a.ns = tile_units(c, 2); ta.a.cy = RingCarry{};
+            ta.im.CB = mk.D / c->tile_th; ta.im.bimg = c->t_att + (size_t)(l - c->l0) * (size_t)mk.D * mk.D;
+            const size_t sm = tile_smem(c, 2);
+            TILE_DISPATCH(c, (k_attout_t<4, 4, 64, 16, 1><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
+                          (k_attout_t<5, 5, 20, 4, 5><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
+                          (k_attout_t<2, 4, 8, 4, 2><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)));
         }
         else if ((c->ring & 2) && mk.common && mk.ring_cls(2)) {
             ao.ns = ring_units(1, S, true);
@@ -570,9 +608,12 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
         FfnRKArgs fa = mk.frk(l);
         if (tile_ok(c, 3)) {
             FfnRKTArgs ta;
-            ta.a = fa; ta.a.ns = tile_units(3, mk.D); ta.a.cy = RingCarry{};
-            ta.im.CB = mk.D / 16; ta.im.bimg = c->b_frk + (size_t)(l - c->l0) * 5 * (size_t)ta.im.CB * 16 * mk.D;
-            k_ffn_rk_t<4, TILE_SU, 64><<<dim3(grid), dim3(NT), tile_smem(3, mk.D), c->stream>>>(ta);
+            ta.a = fa; ta.a.ns = tile_units(c, 3); ta.a.cy = RingCarry{};
+            ta.im.CB = mk.D / c->tile_th; ta.im.bimg = c->t_frk + (size_t)(l - c->l0) * 5 * (size_t)mk.D * mk.D;
+            const size_t sm = tile_smem(c, 3);
+            TILE_DISPATCH(c, (k_ffn_rk_t<4, 4, 64, 16, 1><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
+                          (k_ffn_rk_t<5, 5, 20, 4, 5><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
+                          (k_ffn_rk_t<2, 4, 8, 4, 2><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)));
         }
         else if (c->ring & 4) {
             fa.ns = ring_units(2, S, mk.common);
@@ -586,10 +627,17 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
         fv.ns = ring_units(4, S, mk.common);
         if (tile_ok(c, 4)) {
             FfnVTArgs ta;
-            ta.a = fv; ta.a.ns = tile_units(4, mk.D); ta.a.cy = RingCarry{};
-            ta.im.CB = mk.D / 16; ta.im.bimg = c->b_fv + (size_t)(l - c->l0) * (size_t)ta.im.CB * 16 * 4 * mk.D;
-            if (mk.fv_next_att(l)) k_ffnv_t<4, TILE_SU, 256, 3><<<dim3(grid), dim3(NT), tile_smem(4, mk.D), c->stream>>>(ta);
-            else k_ffnv_t<4, TILE_SU, 256, 1><<<dim3(grid), dim3(NT), tile_smem(4, mk.D), c->stream>>>(ta);
+            ta.a = fv; ta.a.ns = tile_units(c, 4); ta.a.cy = RingCarry{};
+            ta.im.CB = mk.D / c->tile_th; ta.im.bimg = c->t_fv + (size_t)(l - c->l0) * 4 * (size_t)mk.D * mk.D;
+            const size_t sm = tile_smem(c, 4);
+            if (mk.fv_next_att(l))
+                TILE_DISPATCH(c, (k_ffnv_t<4, 4, 256, 16, 1, 3><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
+                              (k_ffnv_t<5, 5, 80, 4, 5, 3><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
+                              (k_ffnv_t<2, 4, 32, 4, 2, 3><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)));
+            else
+                TILE_DISPATCH(c, (k_ffnv_t<4, 4, 256, 16, 1, 1><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
+                              (k_ffnv_t<5, 5, 80, 4, 5, 1><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
+                              (k_ffnv_t<2, 4, 32, 4, 2, 1><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)));
         }
         else if (mk.fv_next_att(l)) {
             if (c->ring & 8) {
@@ -743,12 +791,20 @@ int set_smem_limits(rwkv_ctx *c)
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, 1>, smem_ring3(4, S, false))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, 2>, smem_ring3(4, S, true))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_head<S_, 1, 1>, smem_ring(smem_head(S), RWKV_HEAD_RR, S))); if (rc) return rc;
-    if (c->D == 4096) {
-        if ((rc = allow_smem(k_att_t<4, TILE_SU, 64>, tile_smem(1, 4096)))) return rc;
-        if ((rc = allow_smem(k_attout_t<4, TILE_SU, 64>, tile_smem(2, 4096)))) return rc;
-        if ((rc = allow_smem(k_ffn_rk_t<4, TILE_SU, 64>, tile_smem(3, 4096)))) return rc;
-        if ((rc = allow_smem(k_ffnv_t<4, TILE_SU, 256, 3>, tile_smem(4, 4096)))) return rc;
-        if ((rc = allow_smem(k_ffnv_t<4, TILE_SU, 256, 1>, tile_smem(4, 4096)))) return rc;
+    if (c->tile_th) {
+#define TILE_ALLOW(K16, K45, K42, CLS)                                                                   \
+        do {                                                                                             \
+            if (c->tile_th == 16) rc = allow_smem(K16, tile_smem(c, CLS));                               \
+            else if (c->tile_tpc == 5) rc = allow_smem(K45, tile_smem(c, CLS));                          \
+            else rc = allow_smem(K42, tile_smem(c, CLS));                                                \
+            if (rc) return rc;                                                                           \
+        } while (0)
+        TILE_ALLOW((k_att_t<4, 4, 64, 16, 1>), (k_att_t<5, 5, 20, 4, 5>), (k_att_t<2, 4, 8, 4, 2>), 1);
+        TILE_ALLOW((k_attout_t<4, 4, 64, 16, 1>), (k_attout_t<5, 5, 20, 4, 5>), (k_attout_t<2, 4, 8, 4, 2>), 2);
+        TILE_ALLOW((k_ffn_rk_t<4, 4, 64, 16, 1>), (k_ffn_rk_t<5, 5, 20, 4, 5>), (k_ffn_rk_t<2, 4, 8, 4, 2>), 3);
+        TILE_ALLOW((k_ffnv_t<4, 4, 256, 16, 1, 3>), (k_ffnv_t<5, 5, 80, 4, 5, 3>), (k_ffnv_t<2, 4, 32, 4, 2, 3>), 4);
+        TILE_ALLOW((k_ffnv_t<4, 4, 256, 16, 1, 1>), (k_ffnv_t<5, 5, 80, 4, 5, 1>), (k_ffnv_t<2, 4, 32, 4, 2, 1>), 4);
+#undef TILE_ALLOW
     }
     return 0;
 }
@@ -844,89 +900,105 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
 
     // uint8 matrices.  Two device layouts exist: ROW form -- re-tiled to row-per-output, what the row-form decode kernels
     // stream -- and the TILE image -- [16-row tile][k-block of 64][lane][16 B], signed: the MFMA B operand of the chunk path AND what the
-    // tile-form decode kernels stream (tile.hip.h).  A context whose four per-layer decode classes all run in tile form (7B-wide models on
-    // 256 CUs: c->tile == 15) keeps ONLY the tile image: every matrix goes file layout -> row form in a scratch buffer -> row sums,
-    // octant row sums, tile image, layer by layer.  Otherwise the row form is resident and the tile image is the second copy the chunk
-    // path (max_ctx > 1) needs.  The head stays in row form (k_head) either way (+ its tile image for the chunk path).
+    // tile-form decode kernels stream (tile.hip.h).  A decode class (K/V/R, att_out, ffn k/r, ffn_v: bits 0..3 of c->tile) is resident in
+    // the ONE layout its decode kernel streams: the matrices of a class that runs in tile form go file layout -> row form in a scratch
+    // buffer -> row sums, octant row sums, tile image, layer by layer, and their row form is never kept (7B-wide models on 256 CUs: all
+    // four classes).  The 16-row tile image of every class is also what the chunk path (max_ctx > 1) multiplies with; at the widths whose
+    // decode tiles are 4 rows high (tile.hip.h) a tile-form class has its own image.  The head stays in row form (k_head) either way
+    // (+ its tile image for the chunk path).
     const bool want_seq = [&] { const char *e = getenv("RWKV_SEQ"); return max_ctx > 1 && D % 64 == 0 && !(e && e[0] == '0'); }();
-    if (c->tile < 0) c->tile = (D == 4096 && c->grid * 16 == (int)D) ? 15 : 0;       // (auto: where a workgroup owns exactly one 16-channel block)
-    if (!(D % 64 == 0 && c->grid * 16 == (int)D && D == 4096)) c->tile = 0;
-    if (c->tile) c->carry_kib = 0;      // (the row-form loaders' carry has no tile-form counterpart yet)
-    const bool tile_only = c->tile == 15;
-    const bool need_b = want_seq || c->tile != 0;
-    if (!tile_only) {
-        if ((rc = dalloc(c, &c->w_kvr, nl * 3 * D * D))) return rc;
-        if ((rc = dalloc(c, &c->w_att, nl * D * D))) return rc;
-        if ((rc = dalloc(c, &c->w_frk, nl * 5 * D * D))) return rc;
-        if ((rc = dalloc(c, &c->w_fv, nl * 4 * D * D))) return rc;
-    }
+    const TileCfg tcfg = tile_cfg_for(D, c->grid);
+    // auto: every class where a workgroup owns exactly one 16-channel block (D = 4096); ffn k/r alone on 4-row tiles at D = 5120
+    // (measured: the other classes, and every class at D = 2048, are faster in row form: profiles/r05/tile_14B_masks.txt, tile_run_ab.txt)
+    if (c->tile < 0) c->tile = tcfg.th == 16 ? 15 : tcfg.tpc == 5 ? 4 : 0;
+    if (tcfg.th == 0) c->tile = 0;
+    c->tile &= 15;
+    if (c->tile) { c->carry_kib = 0; c->tile_th = tcfg.th; c->tile_s = tcfg.s; c->tile_tpc = tcfg.tpc; }      // (the row-form loaders' carry has no tile-form counterpart)
+    auto in_tile = [&](int cls) { return ((c->tile >> (cls - 1)) & 1) != 0; };
+    const bool own_t = tcfg.th != 16;                         // the decode kernels' tile image is not the chunk path's
+    auto need_b = [&](int cls) { return want_seq || (in_tile(cls) && !own_t); };
+    if (!in_tile(1) && (rc = dalloc(c, &c->w_kvr, nl * 3 * D * D))) return rc;
+    if (!in_tile(2) && (rc = dalloc(c, &c->w_att, nl * D * D))) return rc;
+    if (!in_tile(3) && (rc = dalloc(c, &c->w_frk, nl * 5 * D * D))) return rc;
+    if (!in_tile(4) && (rc = dalloc(c, &c->w_fv, nl * 4 * D * D))) return rc;
     if (last && (rc = dalloc(c, &c->w_head, V * D))) return rc;
     if (!rc) rc = dalloc(c, &c->rs_kvr, nl * 3 * D);
     if (!rc) rc = dalloc(c, &c->rs_att, nl * D);
     if (!rc) rc = dalloc(c, &c->rs_frk, nl * 5 * D);
     if (!rc) rc = dalloc(c, &c->rs_fv, nl * D);
     if (!rc) rc = dalloc(c, &c->rs_head, V);
-    if (!rc && !tile_only) {
-        rc = dalloc(c, &c->rw_kvr, nl * 3 * D);
-        if (!rc) rc = dalloc(c, &c->rw_att, nl * D);
-        if (!rc) rc = dalloc(c, &c->rw_frk, nl * 5 * D);
-        if (!rc) rc = dalloc(c, &c->rw_fv, nl * D);
-    }
+    if (!rc && !in_tile(1)) rc = dalloc(c, &c->rw_kvr, nl * 3 * D);
+    if (!rc && !in_tile(2)) rc = dalloc(c, &c->rw_att, nl * D);
+    if (!rc && !in_tile(3)) rc = dalloc(c, &c->rw_frk, nl * 5 * D);
+    if (!rc && !in_tile(4)) rc = dalloc(c, &c->rw_fv, nl * D);
     if (rc) return rc;
     // tile images (+ octant row sums for the chunk path): per = bytes of one layer's image
     const uint64_t cbD = (D + 15) / 16;
     const uint64_t per_kvr = 3 * cbD * 16 * D, per_att = cbD * 16 * D, per_frk = 5 * cbD * 16 * D, per_fv = cbD * 16 * 4 * D;
-    if (need_b) {
-        if ((rc = dalloc(c, &c->b_kvr, nl * per_kvr))) return rc;
-        if ((rc = dalloc(c, &c->b_att, nl * per_att))) return rc;
-        if ((rc = dalloc(c, &c->b_frk, nl * per_frk))) return rc;
-        if ((rc = dalloc(c, &c->b_fv, nl * per_fv))) return rc;
-        if (want_seq) {
-            if ((rc = dalloc(c, &c->r8_kvr, nl * SEQ_O * 3 * D))) return rc;
-            if ((rc = dalloc(c, &c->r8_att, nl * SEQ_O * D))) return rc;
-            if ((rc = dalloc(c, &c->r8_frk, nl * SEQ_O * 5 * D))) return rc;
-            if ((rc = dalloc(c, &c->r8_fv, nl * SEQ_O * D))) return rc;
-        }
+    if (need_b(1) && (rc = dalloc(c, &c->b_kvr, nl * per_kvr))) return rc;
+    if (need_b(2) && (rc = dalloc(c, &c->b_att, nl * per_att))) return rc;
+    if (need_b(3) && (rc = dalloc(c, &c->b_frk, nl * per_frk))) return rc;
+    if (need_b(4) && (rc = dalloc(c, &c->b_fv, nl * per_fv))) return rc;
+    if (want_seq) {
+        if ((rc = dalloc(c, &c->r8_kvr, nl * SEQ_O * 3 * D))) return rc;
+        if ((rc = dalloc(c, &c->r8_att, nl * SEQ_O * D))) return rc;
+        if ((rc = dalloc(c, &c->r8_frk, nl * SEQ_O * 5 * D))) return rc;
+        if ((rc = dalloc(c, &c->r8_fv, nl * SEQ_O * D))) return rc;
+    }
+    if (own_t) {
+        if (in_tile(1) && (rc = dalloc(c, &c->t_kvr, nl * 3 * D * D))) return rc;
+        if (in_tile(2) && (rc = dalloc(c, &c->t_att, nl * D * D))) return rc;
+        if (in_tile(3) && (rc = dalloc(c, &c->t_frk, nl * 5 * D * D))) return rc;
+        if (in_tile(4) && (rc = dalloc(c, &c->t_fv, nl * 4 * D * D))) return rc;
+    } else {
+        if (in_tile(1)) c->t_kvr = c->b_kvr;
+        if (in_tile(2)) c->t_att = c->b_att;
+        if (in_tile(3)) c->t_frk = c->b_frk;
+        if (in_tile(4)) c->t_fv = c->b_fv;
     }
     auto rowsum = [&](const uint8_t *w, unsigned *rs, unsigned *rw, uint64_t rows, uint64_t N) {
         k_rowsum<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream>>>(w, rs, rw, (size_t)rows, (int)N, (int)D);
     };
     // one layer's matrix in row form (w_t[N][K]) -> its tile image (and octant row sums)
-    auto image = [&](const uint8_t *w_t, uint8_t *bdst, unsigned *r8dst, uint64_t N, uint64_t K, int Q, uint64_t per) {
-        k_bimage<<<dim3((unsigned)((per / 16 + 255) / 256)), dim3(256), 0, c->stream>>>(w_t, bdst, (int)N, (int)K, Q, (int)((((N + Q - 1) / Q) + 15) / 16));
+    auto image = [&](const uint8_t *w_t, uint8_t *bdst, unsigned *r8dst, uint64_t N, uint64_t K, int Q, uint64_t per, int TH = 16) {
+        k_bimage<<<dim3((unsigned)((per / 16 + 255) / 256)), dim3(256), 0, c->stream>>>(w_t, bdst, (int)N, (int)K, Q, (int)((((N + Q - 1) / Q) + TH - 1) / TH), TH);
         if (r8dst) k_rowsum8<<<dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream>>>(w_t, r8dst, (int)N, (int)K);
     };
     uint8_t *staging = nullptr, *rowtmp = nullptr;
     if (!src.on_device) HIPCHK(hipMalloc(reinterpret_cast<void **>(&staging), std::max<uint64_t>(4 * D * D, V * D)));
-    if (tile_only) HIPCHK(hipMalloc(reinterpret_cast<void **>(&rowtmp), 5 * D * D));
+    if (c->tile) HIPCHK(hipMalloc(reinterpret_cast<void **>(&rowtmp), 5 * D * D));
     for (uint64_t l = l0; l < l1 && !rc; l++) {
         const uint64_t lr = l - l0;
-        uint8_t *kvr = tile_only ? rowtmp : c->w_kvr + lr * 3 * D * D;
+        uint8_t *kvr = in_tile(1) ? rowtmp : c->w_kvr + lr * 3 * D * D;
         if (!rc) rc = retile(c, src, KM, l, D, D, kvr, 1, 3, 0, staging);
         if (!rc) rc = retile(c, src, VM, l, D, D, kvr, 1, 3, 1, staging);
         if (!rc) rc = retile(c, src, RM, l, D, D, kvr, 1, 3, 2, staging);
         if (!rc) {
-            rowsum(kvr, c->rs_kvr + lr * 3 * D, tile_only ? nullptr : c->rw_kvr + lr * 3 * D, 3 * D, D);
-            if (need_b) image(kvr, c->b_kvr + lr * per_kvr, want_seq ? c->r8_kvr + lr * SEQ_O * 3 * D : nullptr, 3 * D, D, 3, per_kvr);
+            rowsum(kvr, c->rs_kvr + lr * 3 * D, in_tile(1) ? nullptr : c->rw_kvr + lr * 3 * D, 3 * D, D);
+            if (need_b(1)) image(kvr, c->b_kvr + lr * per_kvr, want_seq ? c->r8_kvr + lr * SEQ_O * 3 * D : nullptr, 3 * D, D, 3, per_kvr);
+            if (own_t && in_tile(1)) image(kvr, c->t_kvr + lr * 3 * D * D, nullptr, 3 * D, D, 3, 3 * D * D, tcfg.th);
         }
-        uint8_t *att = tile_only ? rowtmp : c->w_att + lr * D * D;
+        uint8_t *att = in_tile(2) ? rowtmp : c->w_att + lr * D * D;
         if (!rc) rc = retile(c, src, ATTOUT, l, D, D, att, 1, 1, 0, staging);
         if (!rc) {
-            rowsum(att, c->rs_att + lr * D, tile_only ? nullptr : c->rw_att + lr * D, D, D);
-            if (need_b) image(att, c->b_att + lr * per_att, want_seq ? c->r8_att + lr * SEQ_O * D : nullptr, D, D, 1, per_att);
+            rowsum(att, c->rs_att + lr * D, in_tile(2) ? nullptr : c->rw_att + lr * D, D, D);
+            if (need_b(2)) image(att, c->b_att + lr * per_att, want_seq ? c->r8_att + lr * SEQ_O * D : nullptr, D, D, 1, per_att);
+            if (own_t && in_tile(2)) image(att, c->t_att + lr * D * D, nullptr, D, D, 1, D * D, tcfg.th);
         }
-        uint8_t *frk = tile_only ? rowtmp : c->w_frk + lr * 5 * D * D;
+        uint8_t *frk = in_tile(3) ? rowtmp : c->w_frk + lr * 5 * D * D;
         if (!rc) rc = retile(c, src, FFNK, l, D, 4 * D, frk, 4, 5, 0, staging);
         if (!rc) rc = retile(c, src, FFNR, l, D, D, frk, 1, 5, 4, staging);
         if (!rc) {
-            rowsum(frk, c->rs_frk + lr * 5 * D, tile_only ? nullptr : c->rw_frk + lr * 5 * D, 5 * D, D);
-            if (need_b) image(frk, c->b_frk + lr * per_frk, want_seq ? c->r8_frk + lr * SEQ_O * 5 * D : nullptr, 5 * D, D, 5, per_frk);
+            rowsum(frk, c->rs_frk + lr * 5 * D, in_tile(3) ? nullptr : c->rw_frk + lr * 5 * D, 5 * D, D);
+            if (need_b(3)) image(frk, c->b_frk + lr * per_frk, want_seq ? c->r8_frk + lr * SEQ_O * 5 * D : nullptr, 5 * D, D, 5, per_frk);
+            if (own_t && in_tile(3)) image(frk, c->t_frk + lr * 5 * D * D, nullptr, 5 * D, D, 5, 5 * D * D, tcfg.th);
         }
-        uint8_t *fvm = tile_only ? rowtmp : c->w_fv + lr * 4 * D * D;
+        uint8_t *fvm = in_tile(4) ? rowtmp : c->w_fv + lr * 4 * D * D;
         if (!rc) rc = retile(c, src, FFNV, l, 4 * D, D, fvm, 1, 1, 0, staging);
         if (!rc) {
-            rowsum(fvm, c->rs_fv + lr * D, tile_only ? nullptr : c->rw_fv + lr * D, D, 4 * D);
-            if (need_b) image(fvm, c->b_fv + lr * per_fv, want_seq ? c->r8_fv + lr * SEQ_O * D : nullptr, D, 4 * D, 1, per_fv);
+            rowsum(fvm, c->rs_fv + lr * D, in_tile(4) ? nullptr : c->rw_fv + lr * D, D, 4 * D);
+            if (need_b(4)) image(fvm, c->b_fv + lr * per_fv, want_seq ? c->r8_fv + lr * SEQ_O * D : nullptr, D, 4 * D, 1, per_fv);
+            if (own_t && in_tile(4)) image(fvm, c->t_fv + lr * 4 * D * D, nullptr, D, 4 * D, 1, 4 * D * D, tcfg.th);
         }
     }
     if (!rc && last) {
@@ -1760,6 +1832,7 @@ double *rwkv_state_device(rwkv_ctx *c, int which) { return (c && which >= 0 && w
 void *rwkv_stream(rwkv_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int rwkv_abi_version(void) { return RWKV_MI355X_ABI_VERSION; }
 uint64_t rwkv_resident_bytes(const rwkv_ctx *c) { return c ? (uint64_t)c->alloc_bytes : 0; }
+int rwkv_decode_form(const rwkv_ctx *c) { return c && c->loaded ? (c->tile > 0 ? c->tile : 0) : -1; }
 
 // carry counters since the last call: [0] workgroup launches that found the rows their predecessor was asked to leave in LDS, [1] that
 // did not (they stream the rows themselves), [2] carried groups whose check failed and that were re-loaded from memory (kernels.hip.h

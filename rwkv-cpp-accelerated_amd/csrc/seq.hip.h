@@ -491,13 +491,15 @@ __global__ __launch_bounds__(TCAP * WKV_CH) void k_seq_wkv(SeqWkvArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// Load-time: MFMA B-operand image of a re-tiled matrix w_t[N][K] (row-per-output).  Tiles are enumerated class-major:
-// tile id -> class q = id / CB, 16-channel block cb = id % CB, tile row c -> matrix row Q * (16 cb + c) + q (Q row classes
-// interleaved in w_t: K/V/R 3, ffn k,k,k,k,r 5, else 1), so that consecutive tiles share an activation vector.
-// bimg[((id * KB + kb) * 64 + lane) * 16 + b] = w_t[row(id, lane & 15)][64 kb + 16 (lane >> 4) + b] - 128 (rows past N: 0).
-__global__ void k_bimage(const uint8_t *__restrict__ w_t, uint8_t *__restrict__ bimg, int N, int K, int Q, int CB)
+// Load-time: tile image of a re-tiled matrix w_t[N][K] (row-per-output).  A tile is TH rows (16: the MFMA B operand of the chunk path, also
+// what the tile-form decode kernels of a 4096-wide model stream; 4: the decode-only image of widths whose channels do not split into
+// 16-row blocks per workgroup, tile.hip.h); a fragment (1 KiB, one wave instruction) holds TH rows x 64 / TH 16-byte pieces of k.  Tiles
+// are enumerated class-major: tile id -> class q = id / CB, TH-channel block cb = id % CB, tile row c -> matrix row Q * (TH cb + c) + q
+// (Q row classes interleaved in w_t: K/V/R 3, ffn k,k,k,k,r 5, else 1), so that consecutive tiles share an activation vector.
+// bimg[((id * KB + kb) * 64 + lane) * 16 + b] = w_t[row(id, lane % TH)][(1024 / TH) kb + 16 (lane / TH) + b] - 128 (rows past N: 0); KB = K TH / 1024.
+__global__ void k_bimage(const uint8_t *__restrict__ w_t, uint8_t *__restrict__ bimg, int N, int K, int Q, int CB, int TH)
 {
-    const int KB = K >> 6;
+    const int KF = 1024 / TH, KB = K / KF;
     const size_t unit = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte unit per thread
     const size_t total = (size_t)Q * CB * KB * 64;
     if (unit >= total) return;
@@ -505,11 +507,11 @@ __global__ void k_bimage(const uint8_t *__restrict__ w_t, uint8_t *__restrict__ 
     const size_t tk = unit >> 6;
     const int kb = (int)(tk % KB), id = (int)(tk / KB);
     const int q = id / CB, cb = id % CB;
-    const int ch = 16 * cb + (lane & 15), row = Q * ch + q;
+    const int ch = TH * cb + (lane % TH), row = Q * ch + q;
     const int nch = (N + Q - 1) / Q;
     u32x4 v = u32x4{0u, 0u, 0u, 0u};
     if (ch < nch && row < N) {
-        v = *reinterpret_cast<const u32x4 *>(w_t + (size_t)row * K + (size_t)kb * 64 + 16 * (lane >> 4));
+        v = *reinterpret_cast<const u32x4 *>(w_t + (size_t)row * K + (size_t)kb * KF + 16 * (lane / TH));
 #pragma unroll
         for (int d = 0; d < 4; d++) v[d] ^= 0x80808080u;
     }

@@ -29,8 +29,9 @@ constexpr double TILE_CN = -1077952512.0;      // -16384 * 65793: coefficient of
 struct TileCtl {                 // LDS control block of a tile-form ring
     unsigned staged;             // prologue waves that have staged their part of the vectors
     unsigned landed;             // ring units whose DMA has completed (loader -> consumers, monotonic)
-    unsigned freed[8];           // freed[w]: units consumer wave w has copied out of the ring (its units are w, w + 7, w + 14, ...)
-    unsigned tcnt[8];            // per tile of the workgroup: units already added into tsum
+    unsigned freed[8];           // freed[w]: units consumer wave w has copied out of the ring (in ITS order: runs of RUN units, run r belongs to wave r % 7)
+    unsigned tcnt[32];           // per tile of the workgroup: units already added into tsum
+    unsigned done[8];            // k_att_t: per channel block of the workgroup, tiles (K, V, R) whose values are in
     unsigned pad[2];
     unsigned long long sq[4];    // per staged vector: sum of (q_j + 2^22) over its elements (one ds_add_u64 per staging wave)
     unsigned dump[64];           // where lanes 1..63 of the loader put their copy of `landed` (a store by ALL lanes needs no exec juggling: two instructions)
@@ -141,6 +142,13 @@ RWKV_DMA_UNIT_S(2, RWKV_DMA_LS(0) RWKV_DMA_LS(1024))
 RWKV_DMA_UNIT_S(4, RWKV_DMA_LS(0) RWKV_DMA_LS(1024) RWKV_DMA_LS(2048) RWKV_DMA_LS(3072))
 #undef RWKV_DMA_LS
 #undef RWKV_DMA_UNIT_S
+template <> __device__ __forceinline__ void dma_unit_s<5>(const uint8_t *src, unsigned voff, unsigned lds_dst)      // (the offset field ends at 4095)
+{
+    dma_unit_s<4>(src, voff, lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:0 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(src + 4096), "s"(lds_dst + 4096u) : "memory");
+}
 
 // The loader wave of a tile-form kernel: units of S KiB (S k-blocks of one tile), in order.  Same rules as RingLoader (kernels.hip.h):
 // one asm statement per unit, vmcnt READ instead of waited on, every wait bounded -- and, because one wave's instruction issue IS the
@@ -149,7 +157,7 @@ RWKV_DMA_UNIT_S(4, RWKV_DMA_LS(0) RWKV_DMA_LS(1024) RWKV_DMA_LS(2048) RWKV_DMA_L
 // `landed` is stored by all lanes at once (lane 0 into the control block, the others into dump slots).  Consumers free units by
 // per-wave counters (unit u belongs to wave u % NC, which takes its units in order), so the first unit still in use is
 // min_w (NC * freed[w] + w): looked at only when the cached value says the ring is full.
-template <int S> struct TileLoader {
+template <int S, int RUN = 1> struct TileLoader {
     TileCtl *tc;
     unsigned ring, nu;
     unsigned issued = 0, pub = 0, tailu = 0, pos = 0;
@@ -182,7 +190,8 @@ template <int S> struct TileLoader {
     {
         const unsigned f = __hip_atomic_load(&tc->freed[lane & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
-        const unsigned v = f * (unsigned)NC + (unsigned)(lane & 7);
+        // the f-th unit wave w takes is unit ((f / RUN) NC + w) RUN + f % RUN: the first one it has NOT taken yet
+        const unsigned v = ((f / (unsigned)RUN) * (unsigned)NC + (unsigned)(lane & 7)) * (unsigned)RUN + f % (unsigned)RUN;
         unsigned m = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
 #pragma unroll
         for (int w = 1; w < NC; w++) { const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)v, w); m = o < m ? o : m; }
@@ -274,14 +283,14 @@ __device__ __forceinline__ void tile_vec(const float *vec, const double *partS, 
 }
 
 // the loader wave's whole life: zero the control block and the tile sums, first units before the order barrier, the stream, the landing
-template <int S, int UPT, class Src>
+template <int S, int UPT, int RUN, int TH, class Src>
 __device__ __forceinline__ unsigned tile_loader(int NU, int ntile, unsigned char *ring, int ns, TileCtl *tc, int *tsum, int lane, Src unit_src)
 {
     static_assert(UPT % 2 == 0, "pairs of units never straddle a tile");
     loader_clean_slate();
     for (int i = lane; i < (int)(sizeof(TileCtl) / 4); i += 64) reinterpret_cast<unsigned *>(tc)[i] = 0u;
-    for (int i = lane; i < ntile * 48; i += 64) tsum[i] = 0;
-    TileLoader<S> ld(tc, lds_addr(ring), ns, lane);
+    for (int i = lane; i < ntile * TH * 3; i += 64) tsum[i] = 0;
+    TileLoader<S, RUN> ld(tc, lds_addr(ring), ns, lane);
     // units in stream order = tile after tile, S k-blocks at a time: contiguous within a tile; the loader moves PAIRS of units
     const uint8_t *src = unit_src(0);
     int u = 0, c = 0;
@@ -300,9 +309,10 @@ __device__ __forceinline__ unsigned tile_loader(int NU, int ntile, unsigned char
 }
 
 // exact integer sum of tile t's row `row`: M = D0 + 2^8 D1 + 2^16 D2 over the three limb planes
+template <int TH>
 __device__ __forceinline__ long long tile_row_sum(const int *tsum, int t, int row)
 {
-    const int *p = tsum + (t * 16 + row) * 3;
+    const int *p = tsum + (t * TH + row) * 3;
     return (long long)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
            + 256ll * (long long)__hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
            + 65536ll * (long long)__hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -313,129 +323,155 @@ __device__ __forceinline__ double tile_cA(const TileCtl *tc, int m, double n)
     return 128.0 * (double)__hip_atomic_load(&tc->sq[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + TILE_CN * n;
 }
 
-// The consumer waves' streaming loop (wave < NC).  Unit u (tile u / UPT, k-blocks S (u % UPT) ..) belongs to wave u % NC: wait for it,
-// copy its S KiB out of the ring, hand it back, multiply it with the limbs of vector vec_of(tile); when the wave's last unit of a tile is
-// in, its partial sums join the tile's in LDS and the unit count; the wave that completes the count calls on_tile(t) (all lanes; the
-// tile's row sums are final: tile_row_sum).
-template <int S, int UPT, class VecOf, class OnTile>
+// The consumer waves' streaming loop (wave < NC).  A tile is TH rows (16: the chunk path's image; 4: the decode-only image of widths
+// whose channels do not split into 16-row blocks per workgroup) x K inputs; a fragment (1 KiB, one wave instruction) holds TH rows x
+// 64 / TH 16-byte pieces of k: lane l = piece l / TH of row l % TH.  Unit u (tile u / UPT, fragments S (u % UPT) ..) belongs to the wave
+// that owns its RUN of units (run u / RUN -> wave (u / RUN) % NC; RUN = 1: round robin; RUN = UPT: a wave multiplies whole small tiles):
+// wait for it, copy its S KiB out of the ring, hand it back, multiply it with the limbs of vector vec_of(tile); when the wave's last
+// unit of a tile is in, its partial sums join the tile's in LDS and the unit count; the wave that completes the count calls on_tile(t)
+// (all lanes; the tile's row sums are final: tile_row_sum).
+template <int TH, int S, int UPT, int RUN, class VecOf, class OnTile>
 __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, int ns, TileCtl *tc, int *tsum, const unsigned *xq, int xvd_t,
                                              int wave, int lane, unsigned &fail, VecOf vec_of, OnTile on_tile)
 {
-    const int qq = lane >> 4, r = lane & 15;
+    static_assert(UPT % RUN == 0, "a run of units never straddles a tile");
+    constexpr int PPB = 64 / TH;                         // 16-byte pieces of k per row and fragment
+    const int pc = lane / TH, r = lane % TH;
     int acc0 = 0, acc1 = 0, acc2 = 0, cnt = 0;
-    unsigned p = (unsigned)wave % (unsigned)ns;
     unsigned taken = 0, seen = 0;
-    for (int u = wave; u < NU; u += NC) {
-        if ((int)(seen - (unsigned)(u + 1)) < 0) {       // (`landed` only grows: what an earlier look saw still holds)
-            bool ok = false;
-            for (int it = 0; it < GLDS_SPIN; it++) {
-                seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tc->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if ((int)(seen - (unsigned)(u + 1)) >= 0) { ok = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+    unsigned p = (unsigned)(wave * RUN) % (unsigned)ns;      // ring position of the wave's next unit: advanced unit by unit, run by run
+    for (int run = wave; run * RUN < NU; run += NC) {
+#pragma unroll 1
+        for (int cc = 0; cc < RUN; cc++) {
+            const int u = run * RUN + cc;
+            if ((int)(seen - (unsigned)(u + 1)) < 0) {       // (`landed` only grows: what an earlier look saw still holds)
+                bool ok = false;
+                for (int it = 0; it < GLDS_SPIN; it++) {
+                    seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tc->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if ((int)(seen - (unsigned)(u + 1)) >= 0) { ok = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                fail = ok ? fail : 2u;
             }
-            fail = ok ? fail : 2u;
-        }
-        const u32x4 *wp = reinterpret_cast<const u32x4 *>(ring + (size_t)p * (S * 1024)) + lane;
-        u32x4 w[S];
+            const u32x4 *wp = reinterpret_cast<const u32x4 *>(ring + (size_t)p * (S * 1024)) + lane;
+            u32x4 w[S];
 #pragma unroll
-        for (int s = 0; s < S; s++) w[s] = wp[s * 64];
-        taken++;
-        // (relaxed + a compiler barrier: a wave's LDS operations execute in order, so the loader that sees the count finds the reads done;
-        // a release store would make the wave WAIT for its reads before it may even request the activation limbs)
-        asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&tc->freed[wave], taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        p += NC; p = p >= (unsigned)ns ? p - (unsigned)ns : p;
-        const int t = u / UPT, c = u - t * UPT;
-        const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + (c * S) * 12 + qq * 3;
+            for (int s = 0; s < S; s++) w[s] = wp[s * 64];
+            taken++;
+            // (relaxed + a compiler barrier: a wave's LDS operations execute in order, so the loader that sees the count finds the reads done;
+            // a release store would make the wave WAIT for its reads before it may even request the activation limbs)
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&tc->freed[wave], taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            p = p + 1 == (unsigned)ns ? 0u : p + 1;
+            const int t = u / UPT, c = u - t * UPT;
+            const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + pc) * 3;
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            const u32x4 x0 = xp[s * 12], x1 = xp[s * 12 + 1], x2 = xp[s * 12 + 2];
+            for (int s = 0; s < S; s++) {
+                const u32x4 x0 = xp[s * PPB * 3], x1 = xp[s * PPB * 3 + 1], x2 = xp[s * PPB * 3 + 2];
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                acc0 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x0[d], acc0, false);
-                acc1 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x1[d], acc1, false);
-                acc2 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x2[d], acc2, false);
+                for (int d = 0; d < 4; d++) {
+                    acc0 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x0[d], acc0, false);
+                    acc1 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x1[d], acc1, false);
+                    acc2 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x2[d], acc2, false);
+                }
+            }
+            cnt++;
+            const int un = cc + 1 < RUN ? u + 1 : (run + NC) * RUN;      // this wave's next unit
+            if (un >= NU || un / UPT != t) {
+                if (TH == 4) {
+                    // 16 lanes hold pieces of one row: fold the pieces 4 apart inside every row of 16 lanes first (DPP), then the four rows of
+                    // 16 lanes meet in LDS like the four k-quarters of the 16-row form
+                    acc0 += __builtin_amdgcn_update_dpp(0, acc0, 0x124, 0xf, 0xf, true); acc0 += __builtin_amdgcn_update_dpp(0, acc0, 0x128, 0xf, 0xf, true);
+                    acc1 += __builtin_amdgcn_update_dpp(0, acc1, 0x124, 0xf, 0xf, true); acc1 += __builtin_amdgcn_update_dpp(0, acc1, 0x128, 0xf, 0xf, true);
+                    acc2 += __builtin_amdgcn_update_dpp(0, acc2, 0x124, 0xf, 0xf, true); acc2 += __builtin_amdgcn_update_dpp(0, acc2, 0x128, 0xf, 0xf, true);
+                }
+                if (TH == 16 || (lane & 15) < 4) {
+                    int *ts = tsum + (t * TH + r) * 3;
+                    __hip_atomic_fetch_add(ts + 0, acc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(ts + 1, acc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(ts + 2, acc2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                unsigned old = 0u;
+                if (lane == 0) old = __hip_atomic_fetch_add(&tc->tcnt[t], (unsigned)cnt, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+                if (old + (unsigned)cnt == (unsigned)UPT) on_tile(t);
+                acc0 = acc1 = acc2 = 0; cnt = 0;
             }
         }
-        cnt++;
-        const int un = u + NC;
-        if (un >= NU || un / UPT != t) {
-            int *ts = tsum + (t * 16 + r) * 3;
-            __hip_atomic_fetch_add(ts + 0, acc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(ts + 1, acc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(ts + 2, acc2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            unsigned old = 0u;
-            if (lane == 0) old = __hip_atomic_fetch_add(&tc->tcnt[t], (unsigned)cnt, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-            if (old + (unsigned)cnt == (unsigned)UPT) on_tile(t);
-            acc0 = acc1 = acc2 = 0; cnt = 0;
-        }
+        p += (unsigned)((NC - 1) * RUN);
+        while (p >= (unsigned)ns) p -= (unsigned)ns;
     }
 }
 
-// Every tile-form kernel: workgroup b owns the 16-channel block b (D / 16 = the grid: D = 4096 on 256 CUs).  KBT = k-blocks of a matrix
-// row (K / 64), S = k-blocks (KiB) per ring unit, SD = ceil(D / 1024).  The argument blocks are the row-form kernels' (site, epilogue
-// inputs and outputs, D, ns = ring units, tl, herr; w / rw / cy unused) + the image.
+// Every tile-form kernel: workgroup b owns CPW = TH * TPC consecutive channels -- TPC tiles of TH rows per row class (TH = 16, TPC = 1: D = 4096
+// on 256 CUs, the chunk path's own image; TH = 4: a decode-only image, TPC = 5 at D = 5120, 2 at D = 2048).  KBT = fragments (1 KiB) of a
+// tile along K (K TH / 1024), S = fragments (KiB) per ring unit, SD = ceil(D / 1024).  The argument blocks are the row-form kernels' (site,
+// epilogue inputs and outputs, D, ns = ring units, tl, herr; w / rw / cy unused) + the image.
 struct TileImage {
-    const uint8_t *bimg;          // MFMA B-operand image of this layer's matrix (k_bimage: tile id = class * CB + channel block, signed bytes)
-    int CB;                       // 16-channel blocks of the matrix
+    const uint8_t *bimg;          // tile image of this layer's matrix (k_bimage: tile id = class * CB + block, TH rows per tile, signed bytes)
+    int CB;                       // TH-row blocks per row class (channels / TH)
 };
 struct FfnRKTArgs { FfnRKArgs a; TileImage im; };
 struct AttTArgs { AttArgs a; TileImage im; };
 struct AttOutTArgs { AttOutArgs a; TileImage im; };
 struct FfnVTArgs { FfnVArgs a; TileImage im; };
 constexpr int TILE_NWP = NT / 2 / 64;
-// LDS in front of the ring (bytes), per kernel: must match the carving at the head of each kernel
-constexpr size_t tile_fixed_frk(int D) { return RED_BYTES + (size_t)2 * (D / 64) * 192 + 208 * 4 + 5 * 192 + sizeof(TileCtl); }
-constexpr size_t tile_fixed_att(int D) { return RED_BYTES + (size_t)3 * (D / 64) * 192 + 48 * 4 + 64 * 8 + 32 * 4 + 32 * 8 + 32 * 4 + 3 * 192 + sizeof(TileCtl); }
-constexpr size_t tile_fixed_attout(int D) { return RED_BYTES + (size_t)(D / 64) * 192 + 64 * 8 + 16 * 12 * 4 + 16 * 4 + 160 * 8 + 192 + sizeof(TileCtl); }
-constexpr size_t tile_fixed_fv(int D) { return RED_BYTES + (size_t)(4 * D / 64) * 192 + 64 * 8 + 16 * 16 * 4 + 16 * 4 + 16 * 4 + 160 * 8 + 192 + sizeof(TileCtl); }
+// units a wave takes in a row.  1 = round robin: even shares whatever the tile count (14B: run 1 / 2 / 4 = 337 / 334 / 320 tokens/s, 15 tiles of
+// K/V/R over 7 waves in whole tiles is 3 : 2); at 1B5 (two tiles of 8 KiB per class) whole tiles are the better of three slower-than-row-form
+// choices (profiles/r05/tile_run_ab.txt)
+constexpr int tile_run(int TH, int UPT, int TPC) { return TH == 16 || TPC > 2 ? 1 : (UPT < 4 ? UPT : 4); }
+// LDS in front of the ring (bytes), per kernel: must match the carving at the head of each kernel (CPW = channels per workgroup)
+constexpr size_t tile_fixed_frk(int D, int CPW) { return RED_BYTES + (size_t)2 * (D / 16) * 48 + (size_t)13 * CPW * 4 + (size_t)5 * CPW * 12 + sizeof(TileCtl); }
+constexpr size_t tile_fixed_att(int D, int CPW) { return RED_BYTES + (size_t)3 * (D / 16) * 48 + (size_t)3 * CPW * 4 + (size_t)4 * CPW * 8 + (size_t)2 * CPW * 4 + (size_t)2 * CPW * 8 + (size_t)2 * CPW * 4 + (size_t)3 * CPW * 12 + sizeof(TileCtl); }
+constexpr size_t tile_fixed_attout(int D, int CPW) { return RED_BYTES + (size_t)(D / 16) * 48 + (size_t)4 * CPW * 8 + (size_t)CPW * 12 * 4 + (size_t)CPW * 4 + (size_t)CPW * 10 * 8 + (size_t)CPW * 12 + sizeof(TileCtl); }
+constexpr size_t tile_fixed_fv(int D, int CPW) { return RED_BYTES + (size_t)(4 * D / 16) * 48 + (size_t)4 * CPW * 8 + (size_t)CPW * 16 * 4 + (size_t)CPW * 4 + (size_t)CPW * 4 + (size_t)CPW * 10 * 8 + (size_t)CPW * 12 + sizeof(TileCtl); }
 
-// ln2 site -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573): 5 tiles, classes 0..3 = ffn_k outputs 4 i + q, class 4 = ffn_r output i
-template <int SD, int S, int KBT>
+// ln2 site -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573): 5 row classes (0..3 = ffn_k outputs 4 i + q, 4 = ffn_r output i) x TPC tiles
+template <int SD, int S, int KBT, int TH, int TPC>
 __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FfnRKArgs &a = ta.a;
-    constexpr int NTILE = 5, UPT = KBT / S, NU = NTILE * UPT;
-    static_assert(KBT % S == 0, "whole units per tile");
+    constexpr int CPW = TH * TPC, NTILE = 5 * TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC);
+    static_assert(KBT % S == 0 && NTILE <= 32, "whole units per tile; TileCtl::tcnt");
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
-    constexpr int xvd_t = KBT * 48;                        // dwords of one staged vector
+    const int xvd_t = (D >> 4) * 12;                       // dwords of one staged vector: [16-byte piece][limb][4]
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    // LDS: [scratch][2 staged vectors][stash: rs[80], r_fv[64], o_fv[64]][tile sums][TileCtl][ring]
+    // LDS: [scratch][2 staged vectors][stash: rs[5 CPW], r_fv[4 CPW], o_fv[4 CPW]][tile sums][TileCtl][ring]
     unsigned *stash = xq + 2 * xvd_t;
-    int *tsum = reinterpret_cast<int *>(stash + 208);
-    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * 48);
+    int *tsum = reinterpret_cast<int *>(stash + 13 * CPW);
+    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * TH * 3);
     unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
     RWKV_ARGS_NOW(a.x, a.st.C, a.st.TC, a.st.maxC, a.dy.B, a.dy.pd, a.dy.pf, a.dy.n_part);
-    const int cb = blockIdx.x, ch0 = cb * 16;
+    const int cb0 = blockIdx.x * TPC, ch0 = blockIdx.x * CPW;
     tl_stamp(a.tl, 0);
-    auto unit_src = [&](int u) {
+    auto unit_src = [&](int u) {          // tile t = class t / TPC, block cb0 + t % TPC
         const int t = u / UPT, c = u - t * UPT;
-        return ta.im.bimg + ((size_t)(t * ta.im.CB + cb) * KBT + (size_t)c * S) * 1024;
+        return ta.im.bimg + ((size_t)((t / TPC) * ta.im.CB + cb0 + t % TPC) * KBT + (size_t)c * S) * 1024;
     };
     double part = 0.0;
     float pmax = 0.f;
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
         tl_stamp(a.tl, 2);
     } else {
         if (wave < TILE_NWP) {
             tile_site<2, SD>(a.st, a.dy, a.x, D, red, xq, xvd_t, true, tc, a.tl);
         } else {
-            // waves 4..6 have nothing to do until the vectors are staged: they fetch the epilogues' inputs of the workgroup's 80 rows into
-            // LDS (row sums of the unsigned weights, ffn_v's scale and offset of the 64 hidden units): requested in front of the order
+            // waves 4..6 have nothing to do until the vectors are staged: they fetch the epilogues' inputs of the workgroup's 5 CPW rows into
+            // LDS (row sums of the unsigned weights, ffn_v's scale and offset of the 4 CPW hidden units): requested in front of the order
             // barrier, stored behind it (a wave that waited for its loads in front of the barrier would hold the prologue waves there)
+            const int n = wave == 4 ? 5 * CPW : 4 * CPW;
             unsigned v0 = 0u, v1 = 0u;
-            if (wave == 4) { v0 = a.rs[ch0 * 5 + lane]; v1 = a.rs[ch0 * 5 + 64 + (lane & 15)]; }
-            else if (wave == 5) v0 = __float_as_uint(a.r_fv[ch0 * 4 + lane]);
-            else v0 = __float_as_uint(a.o_fv[ch0 * 4 + lane]);
+            const unsigned *src = wave == 4 ? a.rs + ch0 * 5 : reinterpret_cast<const unsigned *>(wave == 5 ? a.r_fv + ch0 * 4 : a.o_fv + ch0 * 4);
+            if (lane < n) v0 = src[lane];
+            if (lane + 64 < n) v1 = src[lane + 64];
             __syncthreads();   // order
-            if (wave == 4) { stash[lane] = v0; if (lane < 16) stash[64 + lane] = v1; }
-            else if (wave == 5) stash[80 + lane] = v0;
-            else stash[144 + lane] = v0;
+            unsigned *dst = stash + (wave == 4 ? 0 : wave == 5 ? 5 * CPW : 9 * CPW);
+            if (lane < n) dst[lane] = v0;
+            if (lane + 64 < n) dst[lane + 64] = v1;
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
         wait_count(&tc->staged, TILE_NWP, fail);
@@ -443,26 +479,27 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
         const float Sk = bc[0], Sr = bc[1];
         const double cAk = tile_cA(tc, 0, (double)D), cAr = tile_cA(tc, 1, (double)D);
         tl_stamp(a.tl, 5);
-        auto on_tile = [&](int q) {          // tile = class q: this lane's row is channel ch0 + lane
-            if (lane < 16) {
-                const long long M = tile_row_sum(tsum, q, lane);
-                const unsigned rs = stash[lane * 5 + q];
+        auto on_tile = [&](int t) {          // tile t = class q, block sub: this lane's row is channel ch0 + sub TH + lane
+            if (lane < TH) {
+                const int q = t / TPC, li = (t % TPC) * TH + lane;
+                const long long M = tile_row_sum<TH>(tsum, t, lane);
+                const unsigned rs = stash[li * 5 + q];
                 if (q < 4) {
                     const float val = (float)(sck * ((double)M + cAk + TILE_CU * (double)rs)) + Sk;
                     float h = val * (float)(val > 0.f);   // rwkv.cu:189-190
                     h = h * h;
-                    const int hi = lane * 4 + q;
-                    const float hs = h * __uint_as_float(stash[80 + hi]);
+                    const int hi = li * 4 + q;
+                    const float hs = h * __uint_as_float(stash[5 * CPW + hi]);
                     a.hbuf[4 * ch0 + hi] = hs;
-                    part += (double)(h * __uint_as_float(stash[144 + hi]));
+                    part += (double)(h * __uint_as_float(stash[9 * CPW + hi]));
                     pmax = fmaxf(pmax, fabsf(hs));
                 } else {
                     const float val = (float)(scr * ((double)M + cAr + TILE_CU * (double)rs)) + Sr;
-                    a.rgate[ch0 + lane] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
+                    a.rgate[ch0 + li] = (float)(1.0 / (1.0 + exp(-(double)val)));   // rwkv.cu:212
                 }
             }
         };
-        tile_consume<S, UPT>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t < 4 ? 0 : 1; }, on_tile);
+        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t / TPC < 4 ? 0 : 1; }, on_tile);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();   // every wave is past its last read of the reduction scratch
@@ -472,93 +509,95 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
     tl_stamp(a.tl, 7);
 }
 
-// ln1 site -> K, V, R dequant-GEMV -> WKV (rwkv.cu:535-545; kernels :351-392, :58-100, :221-259): 3 tiles = the K, V, R rows of the
-// workgroup's 16 channels.  The tile finishers leave k's two exponentials, v and r in LDS; whoever completes the third tile runs the 16
-// recurrences side by side.
-template <int SD, int S, int KBT>
+// ln1 site -> K, V, R dequant-GEMV -> WKV (rwkv.cu:535-545; kernels :351-392, :58-100, :221-259): 3 row classes x TPC tiles.  The tile
+// finishers leave k's two exponentials, v and r in LDS; whoever completes a block's third tile runs its TH recurrences side by side.
+template <int SD, int S, int KBT, int TH, int TPC>
 __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AttArgs &a = ta.a;
-    constexpr int NTILE = 3, UPT = KBT / S, NU = NTILE * UPT;
+    constexpr int CPW = TH * TPC, NTILE = 3 * TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC);
+    static_assert(KBT % S == 0 && NTILE <= 32 && TPC <= 8, "whole units per tile; TileCtl::tcnt / done");
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
-    constexpr int xvd_t = KBT * 48;
+    const int xvd_t = (D >> 4) * 12;
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    // LDS: [scratch][3 staged vectors][stash: rs[48] | aa, bb, uw, ew [4][16] f64 | ra, oa [2][16] f32 | e1, ek [2][16] f64 | v, r [2][16] f32][tile sums][TileCtl][ring]
+    // LDS: [scratch][3 staged vectors][stash: rs[3 CPW] | aa, bb, uw, ew [4][CPW] f64 | ra, oa [2][CPW] f32 | e1, ek [2][CPW] f64 | v, r [2][CPW] f32][tile sums][TileCtl][ring]
     unsigned *stash = xq + 3 * xvd_t;
-    double *sd = reinterpret_cast<double *>(stash + 48);          // aa, bb, uw, ew
-    float *sf = reinterpret_cast<float *>(sd + 64);               // ra, oa
-    double *ed = reinterpret_cast<double *>(sf + 32);             // e1, ek
-    float *ef = reinterpret_cast<float *>(ed + 32);               // v, r
-    int *tsum = reinterpret_cast<int *>(ef + 32);
-    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * 48);
+    double *sd = reinterpret_cast<double *>(stash + 3 * CPW);       // aa, bb, uw, ew    (3 CPW words: CPW is a multiple of 4, 8-byte aligned)
+    float *sf = reinterpret_cast<float *>(sd + 4 * CPW);            // ra, oa
+    double *ed = reinterpret_cast<double *>(sf + 2 * CPW);          // e1, ek
+    float *ef = reinterpret_cast<float *>(ed + 2 * CPW);            // v, r
+    int *tsum = reinterpret_cast<int *>(ef + 2 * CPW);
+    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * TH * 3);
     unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
     RWKV_ARGS_NOW(a.x, a.st.C, a.st.TC, a.st.maxC, a.dy.B, a.dy.pd, a.dy.pf, a.dy.n_part);
-    const int cb = blockIdx.x, ch0 = cb * 16;
+    const int cb0 = blockIdx.x * TPC, ch0 = blockIdx.x * CPW;
     tl_stamp(a.tl, 0);
     auto unit_src = [&](int u) {
         const int t = u / UPT, c = u - t * UPT;
-        return ta.im.bimg + ((size_t)(t * ta.im.CB + cb) * KBT + (size_t)c * S) * 1024;
+        return ta.im.bimg + ((size_t)((t / TPC) * ta.im.CB + cb0 + t % TPC) * KBT + (size_t)c * S) * 1024;
     };
     double part = 0.0;
     float pmax = 0.f;
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
         tl_stamp(a.tl, 2);
     } else {
         const size_t so = (size_t)a.ctl->slot * a.slot_stride;
         if (wave < TILE_NWP) {
             tile_site<3, SD>(a.st, a.dy, a.x, D, red, xq, xvd_t, true, tc, a.tl);
         } else {
-            // epilogue inputs of the 16 channels: wave 4 the 48 row sums, wave 5 the state (aa | bb) and the decay terms (uw | ew), wave 6 att_out's scale / offset
-            unsigned v0 = 0u;
-            double d0 = 0.0;
-            const int i = lane & 15, g = lane >> 4;
-            if (wave == 4) { if (lane < 48) v0 = a.rs[ch0 * 3 + lane]; }
-            else if (wave == 5) d0 = g == 0 ? a.saa[so + ch0 + i] : g == 1 ? a.sbb[so + ch0 + i] : g == 2 ? a.uw[ch0 + i] : a.ew[ch0 + i];
-            else if (lane < 32) v0 = __float_as_uint(g == 0 ? a.r_att[ch0 + i] : a.o_att[ch0 + i]);
+            // epilogue inputs of the CPW channels: wave 4 the 3 CPW row sums, wave 5 the state (aa | bb) and the decay terms (uw | ew), wave 6 att_out's scale / offset
+            unsigned v0 = 0u, v1 = 0u;
+            double d0 = 0.0, d1 = 0.0;
+            auto dsrc = [&](int i) { const int g = i / CPW, j = i - g * CPW; return g == 0 ? a.saa[so + ch0 + j] : g == 1 ? a.sbb[so + ch0 + j] : g == 2 ? a.uw[ch0 + j] : a.ew[ch0 + j]; };
+            if (wave == 4) { if (lane < 3 * CPW) v0 = a.rs[ch0 * 3 + lane]; }
+            else if (wave == 5) { if (lane < 4 * CPW) d0 = dsrc(lane); if (lane + 64 < 4 * CPW) d1 = dsrc(lane + 64); }
+            else if (lane < 2 * CPW) v0 = __float_as_uint(lane < CPW ? a.r_att[ch0 + lane] : a.o_att[ch0 + lane - CPW]);
+            (void)v1;
             __syncthreads();   // order
-            if (wave == 4) { if (lane < 48) stash[lane] = v0; }
-            else if (wave == 5) sd[lane] = d0;
-            else if (lane < 32) sf[lane] = __uint_as_float(v0);
+            if (wave == 4) { if (lane < 3 * CPW) stash[lane] = v0; }
+            else if (wave == 5) { if (lane < 4 * CPW) sd[lane] = d0; if (lane + 64 < 4 * CPW) sd[lane + 64] = d1; }
+            else if (lane < 2 * CPW) sf[lane] = __uint_as_float(v0);
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
         wait_count(&tc->staged, TILE_NWP, fail);
-        double sc[3], cA[3];
-        float So[3];
-#pragma unroll
-        for (int m = 0; m < 3; m++) { sc[m] = scale_of(bc[4 + m]); So[m] = bc[m]; cA[m] = tile_cA(tc, m, (double)D); }
         tl_stamp(a.tl, 5);
         auto on_tile = [&](int t) {
-            if (lane < 16) {
-                const long long M = tile_row_sum(tsum, t, lane);
-                const float val = (float)(sc[t] * ((double)M + cA[t] + TILE_CU * (double)stash[lane * 3 + t])) + So[t];
-                if (t == 0) { ed[lane] = exp(sd[32 + lane] + (double)val); ed[16 + lane] = exp((double)val); }      // exp(u + w + k), exp(k)
-                else ef[(t - 1) * 16 + lane] = val;
+            const int q = t / TPC, sub = t % TPC;
+            if (lane < TH) {
+                const int li = sub * TH + lane;
+                const long long M = tile_row_sum<TH>(tsum, t, lane);
+                // (the class's scale, offset scalar and cA constant come out of LDS with the tile's sums, in the same batch of reads: a tile
+                // completes 3 TPC times per workgroup, and nine more live registers through the streaming loop made this kernel spill)
+                const double scq = scale_of(bc[4 + q]), cAq = tile_cA(tc, q, (double)D);
+                const float val = (float)(scq * ((double)M + cAq + TILE_CU * (double)stash[li * 3 + q])) + bc[q];
+                if (q == 0) { ed[li] = exp(sd[2 * CPW + li] + (double)val); ed[CPW + li] = exp((double)val); }      // exp(u + w + k), exp(k)
+                else ef[(q - 1) * CPW + li] = val;
             }
             unsigned old = 0u;
-            if (lane == 0) old = __hip_atomic_fetch_add(&tc->tcnt[7], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) old = __hip_atomic_fetch_add(&tc->done[sub], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-            if (old == 2u && lane < 16) {            // all three tiles in: the WKV recurrence and the gate of the 16 channels (rwkv.cu:242-255)
-                const int g = ch0 + lane;
-                const double aa = sd[lane], bb = sd[16 + lane], ew = sd[48 + lane];
-                const double e1 = *reinterpret_cast<volatile double *>(ed + lane), ek = *reinterpret_cast<volatile double *>(ed + 16 + lane);
-                const float v = *reinterpret_cast<volatile float *>(ef + lane), r = *reinterpret_cast<volatile float *>(ef + 16 + lane);
+            if (old == 2u && lane < TH) {            // the block's three tiles are in: the WKV recurrence and the gate of its TH channels (rwkv.cu:242-255)
+                const int li = sub * TH + lane, g = ch0 + li;
+                const double aa = sd[li], bb = sd[CPW + li], ew = sd[3 * CPW + li];
+                const double e1 = *reinterpret_cast<volatile double *>(ed + li), ek = *reinterpret_cast<volatile double *>(ed + CPW + li);
+                const float v = *reinterpret_cast<volatile float *>(ef + li), r = *reinterpret_cast<volatile float *>(ef + CPW + li);
                 const double vv = (double)v;
                 double y = (aa + e1 * vv) / (bb + e1);
                 y = (1.0 / (1.0 + (double)expf(-r))) * y;       // rwkv.cu:250: exp of a float argument
                 a.saa[so + g] = (aa + ek * vv) * ew;
                 a.sbb[so + g] = (bb + ek) * ew;
                 const float yf = (float)y;                       // att_out GEMV casts its input to f32 (rwkv.cu:290)
-                const float ys = yf * sf[lane];
+                const float ys = yf * sf[li];
                 a.ybuf[g] = ys;
-                part += (double)(yf * sf[16 + lane]);
+                part += (double)(yf * sf[CPW + li]);
                 pmax = fmaxf(pmax, fabsf(ys));
             }
         };
-        tile_consume<S, UPT>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t; }, on_tile);
+        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t / TPC; }, on_tile);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
@@ -568,57 +607,60 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
     tl_stamp(a.tl, 7);
 }
 
-// the row owners' partial tuple of a tile-form kernel with ONE finishing wave: its 16 lanes leave their accumulators in LDS, thread k < 12
-// adds the 16 entries up (kernels.hip.h site_publish does it for R lanes of every wave)
+// the row owners' partial tuple of a tile-form kernel: the finishers' lanes leave the accumulators of their rows in LDS (entry = the
+// row's index in the workgroup), thread k < 12 adds the CPW entries up (kernels.hip.h site_publish does it for R lanes of every wave)
 template <int NV>
-__device__ __forceinline__ void tile_site_leave(const SiteAcc<NV> &acc, double *scr, int lane)
+__device__ __forceinline__ void tile_site_leave(const SiteAcc<NV> &acc, double *scr, int cpw, int li)
 {
-    float *scf = reinterpret_cast<float *>(scr + 16 * 8);
+    float *scf = reinterpret_cast<float *>(scr + cpw * 8);
 #pragma unroll
-    for (int k = 0; k < 8; k++) scr[lane * 8 + k] = acc.d[k];
+    for (int k = 0; k < 8; k++) scr[li * 8 + k] = acc.d[k];
 #pragma unroll
-    for (int k = 0; k < 4; k++) scf[lane * 4 + k] = acc.f[k];
+    for (int k = 0; k < 4; k++) scf[li * 4 + k] = acc.f[k];
 }
-__device__ __forceinline__ void tile_site_publish(const SiteDyn &dy, const double *scr)
+__device__ __forceinline__ void tile_site_publish(const SiteDyn &dy, const double *scr, int cpw)
 {
-    const float *scf = reinterpret_cast<const float *>(scr + 16 * 8);
+    const float *scf = reinterpret_cast<const float *>(scr + cpw * 8);
     if (threadIdx.x < 8) {
         double t = 0.0;
-        for (int i = 0; i < 16; i++) t += scr[i * 8 + threadIdx.x];
+        for (int i = 0; i < cpw; i++) t += scr[i * 8 + threadIdx.x];
         dy.pd[(size_t)blockIdx.x * 8 + threadIdx.x] = t;
     } else if (threadIdx.x < 12) {
         float t = 0.f;
-        for (int i = 0; i < 16; i++) t = fmaxf(t, scf[i * 4 + (threadIdx.x - 8)]);
+        for (int i = 0; i < cpw; i++) t = fmaxf(t, scf[i * 4 + (threadIdx.x - 8)]);
         dy.pf[(size_t)blockIdx.x * 4 + (threadIdx.x - 8)] = t;
     }
 }
 
-// att_out dequant-GEMV + residual through f32 (rwkv.cu:548-553); commits state xy; opens the ln2 site for its 16 rows: ONE tile
-template <int SD, int S, int KBT>
+// att_out dequant-GEMV + residual through f32 (rwkv.cu:548-553); commits state xy; opens the ln2 site for its CPW rows: TPC tiles
+template <int SD, int S, int KBT, int TH, int TPC>
 __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AttOutArgs &a = ta.a;
-    constexpr int NTILE = 1, UPT = KBT / S, NU = UPT;
+    constexpr int CPW = TH * TPC, NTILE = TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC);
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
-    constexpr int xvd_t = KBT * 48;
+    const int xvd_t = (D >> 4) * 12;
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    // LDS: [scratch][1 staged vector][stash: xold, lw, lb, prev2 [4][16] f64 | P [16][12] f32 | rs[16]][publish scratch 16 x 12 words x 2][tile sums][TileCtl][ring]
+    // LDS: [scratch][1 staged vector][stash: xold, lw, lb, prev2 [4][CPW] f64 | P [CPW][12] f32 | rs[CPW]][publish scratch CPW x 10 f64][tile sums][TileCtl][ring]
     double *sd = reinterpret_cast<double *>(xq + xvd_t);
-    float *sp = reinterpret_cast<float *>(sd + 64);
-    unsigned *srs = reinterpret_cast<unsigned *>(sp + 16 * 12);
-    double *scr = reinterpret_cast<double *>(srs + 16);
-    int *tsum = reinterpret_cast<int *>(scr + 16 * 8 + 32);
-    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * 48);
+    float *sp = reinterpret_cast<float *>(sd + 4 * CPW);
+    unsigned *srs = reinterpret_cast<unsigned *>(sp + CPW * 12);
+    double *scr = reinterpret_cast<double *>(srs + CPW);
+    int *tsum = reinterpret_cast<int *>(scr + CPW * 10);
+    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * TH * 3);
     unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
     RWKV_ARGS_NOW(a.ybuf, a.partS, a.partM, a.n_part);
-    const int cb = blockIdx.x, ch0 = cb * 16;
+    const int cb0 = blockIdx.x * TPC, ch0 = blockIdx.x * CPW;
     tl_stamp(a.tl, 0);
-    auto unit_src = [&](int u) { return ta.im.bimg + ((size_t)cb * KBT + (size_t)u * S) * 1024; };
+    auto unit_src = [&](int u) {
+        const int t = u / UPT, c = u - t * UPT;
+        return ta.im.bimg + ((size_t)(cb0 + t) * KBT + (size_t)c * S) * 1024;
+    };
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
         tl_stamp(a.tl, 2);
     } else {
         const double mean1 = a.lnstat[0], rstd1 = a.lnstat[1];
@@ -626,77 +668,80 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
         if (wave < TILE_NWP) {
             tile_vec<SD>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, tc, a.tl);
         } else {
-            const int i = lane & 15, g = lane >> 4;
-            double d0 = 0.0;
+            auto dsrc = [&](int i) { const int g = i / CPW, j = i - g * CPW; return g == 0 ? a.x[ch0 + j] : g == 1 ? a.lnw[ch0 + j] : g == 2 ? a.lnb[ch0 + j] : a.sdd[so + ch0 + j]; };
+            double d0 = 0.0, d1 = 0.0;
             f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f};
             unsigned v0 = 0u;
-            if (wave == 4) d0 = g == 0 ? a.x[ch0 + i] : g == 1 ? a.lnw[ch0 + i] : g == 2 ? a.lnb[ch0 + i] : a.sdd[so + ch0 + i];
-            else if (wave == 5) { if (lane < 48) p0 = reinterpret_cast<const f32x4 *>(a.st.P + (size_t)ch0 * 12)[lane]; }
-            else if (lane < 16) v0 = a.rs[ch0 + lane];
+            if (wave == 4) { if (lane < 4 * CPW) d0 = dsrc(lane); if (lane + 64 < 4 * CPW) d1 = dsrc(lane + 64); }
+            else if (wave == 5) { if (lane < 3 * CPW) p0 = reinterpret_cast<const f32x4 *>(a.st.P + (size_t)ch0 * 12)[lane]; }
+            else if (lane < CPW) v0 = a.rs[ch0 + lane];
             __syncthreads();   // order
-            if (wave == 4) sd[lane] = d0;
-            else if (wave == 5) { if (lane < 48) reinterpret_cast<f32x4 *>(sp)[lane] = p0; }
-            else if (lane < 16) srs[lane] = v0;
+            if (wave == 4) { if (lane < 4 * CPW) sd[lane] = d0; if (lane + 64 < 4 * CPW) sd[lane + 64] = d1; }
+            else if (wave == 5) { if (lane < 3 * CPW) reinterpret_cast<f32x4 *>(sp)[lane] = p0; }
+            else if (lane < CPW) srs[lane] = v0;
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
         wait_count(&tc->staged, TILE_NWP, fail);
         const float Sf = bc[0];
         const double sc = scale_of(bc[4]), cA = tile_cA(tc, 0, (double)D);
         tl_stamp(a.tl, 5);
-        auto on_tile = [&](int) {
-            if (lane < 16) {
-                const int mi = ch0 + lane;
-                const long long M = tile_row_sum(tsum, 0, lane);
-                const double xold = sd[lane];
-                const float accf = (float)xold + ((float)(sc * ((double)M + cA + TILE_CU * (double)srs[lane])) + Sf);   // f32 accumulator pre-loaded with x (:548)
-                const double xnew = (double)accf;                                                                       // :553
+        auto on_tile = [&](int t) {
+            if (lane < TH) {
+                const int li = t * TH + lane, mi = ch0 + li;
+                const long long M = tile_row_sum<TH>(tsum, t, lane);
+                const double xold = sd[li];
+                const float accf = (float)xold + ((float)(sc * ((double)M + cA + TILE_CU * (double)srs[li])) + Sf);   // f32 accumulator pre-loaded with x (:548)
+                const double xnew = (double)accf;                                                                    // :553
                 a.x[mi] = xnew;
-                a.sxy[so + mi] = sd[16 + lane] * ((xold - mean1) * rstd1) + sd[32 + lane];                              // mixatt's state write (:385): ln1 output
+                a.sxy[so + mi] = sd[CPW + li] * ((xold - mean1) * rstd1) + sd[2 * CPW + li];                         // mixatt's state write (:385): ln1 output
                 SitePre<2> pre;
 #pragma unroll
-                for (int k = 0; k < 3; k++) pre.p[k] = reinterpret_cast<const f32x4 *>(sp + lane * 12)[k];
+                for (int k = 0; k < 3; k++) pre.p[k] = reinterpret_cast<const f32x4 *>(sp + li * 12)[k];
                 SiteAcc<2> acc;
                 acc.clear();
-                site_emit<2>(pre, a.dy, D, mi, xnew, sd[48 + lane], acc);
-                tile_site_leave<2>(acc, scr, lane);
+                site_emit<2>(pre, a.dy, D, mi, xnew, sd[3 * CPW + li], acc);
+                tile_site_leave<2>(acc, scr, CPW, li);
             }
         };
-        tile_consume<S, UPT>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile);
+        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
-    tile_site_publish(a.dy, scr);
+    tile_site_publish(a.dy, scr, CPW);
     ring_report(fail, a.herr);
     tl_stamp(a.tl, 7);
 }
 
-// ffn_v dequant-GEMV, x += v * sigmoid(r) (rwkv.cu:574-577); commits state dd; opens the next site: ONE tile of K = 4 D (KBT = 4 D / 64)
-template <int SD, int S, int KBT, int NVN>
+// ffn_v dequant-GEMV, x += v * sigmoid(r) (rwkv.cu:574-577); commits state dd; opens the next site: TPC tiles of K = 4 D
+template <int SD, int S, int KBT, int TH, int TPC, int NVN>
 __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FfnVArgs &a = ta.a;
-    constexpr int NTILE = 1, UPT = KBT / S, NU = UPT, PW = site_pw<NVN>();
+    constexpr int CPW = TH * TPC, NTILE = TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC), PW = site_pw<NVN>();
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
-    constexpr int xvd_t = KBT * 48;
+    const int xvd_t = (D >> 2) * 12;                       // the 4 D hidden units as ONE vector
     unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    // LDS: [scratch][1 staged vector of 4 D][stash: xold, lw, lb, prevn [4][16] f64 | P [16][PW] f32 | rs[16] | rgate[16]][publish scratch][tile sums][TileCtl][ring]
+    // LDS: [scratch][1 staged vector of 4 D][stash: xold, lw, lb, prevn [4][CPW] f64 | P [CPW][16] f32 | rs[CPW] | rgate[CPW]][publish scratch][tile sums][TileCtl][ring]
     double *sd = reinterpret_cast<double *>(xq + xvd_t);
-    float *sp = reinterpret_cast<float *>(sd + 64);
-    unsigned *srs = reinterpret_cast<unsigned *>(sp + 16 * 16);
-    float *srg = reinterpret_cast<float *>(srs + 16);
-    double *scr = reinterpret_cast<double *>(srg + 16);
-    int *tsum = reinterpret_cast<int *>(scr + 16 * 8 + 32);
-    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * 48);
+    float *sp = reinterpret_cast<float *>(sd + 4 * CPW);
+    unsigned *srs = reinterpret_cast<unsigned *>(sp + CPW * 16);
+    float *srg = reinterpret_cast<float *>(srs + CPW);
+    double *scr = reinterpret_cast<double *>(srg + CPW);
+    int *tsum = reinterpret_cast<int *>(scr + CPW * 10);
+    TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * TH * 3);
     unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
     RWKV_ARGS_NOW(a.hbuf, a.partS, a.partM, a.n_part);
-    const int cb = blockIdx.x, ch0 = cb * 16;
+    const int cb0 = blockIdx.x * TPC, ch0 = blockIdx.x * CPW;
     tl_stamp(a.tl, 0);
-    auto unit_src = [&](int u) { return ta.im.bimg + ((size_t)cb * KBT + (size_t)u * S) * 1024; };
+    auto unit_src = [&](int u) {
+        const int t = u / UPT, c = u - t * UPT;
+        return ta.im.bimg + ((size_t)(cb0 + t) * KBT + (size_t)c * S) * 1024;
+    };
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
         tl_stamp(a.tl, 2);
     } else {
         const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
@@ -704,46 +749,47 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
         if (wave < TILE_NWP) {
             tile_vec<4 * SD>(a.hbuf, a.partS, a.partM, a.n_part, 4 * D, red, xq, tc, a.tl);
         } else {
-            const int i = lane & 15, g = lane >> 4;
-            double d0 = 0.0;
-            f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto dsrc = [&](int i) { const int g = i / CPW, j = i - g * CPW; return g == 0 ? a.x[ch0 + j] : g == 1 ? a.lnw[ch0 + j] : g == 2 ? a.lnb[ch0 + j] : (NVN == 3 ? a.sprev[so + ch0 + j] : 0.0); };
+            double d0 = 0.0, d1 = 0.0;
+            f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f}, p1 = f32x4{0.f, 0.f, 0.f, 0.f};
             unsigned v0 = 0u;
-            if (wave == 4) d0 = g == 0 ? a.x[ch0 + i] : g == 1 ? a.lnw[ch0 + i] : g == 2 ? a.lnb[ch0 + i] : (NVN == 3 ? a.sprev[so + ch0 + i] : 0.0);
-            else if (wave == 5) { if (lane < 4 * PW) p0 = reinterpret_cast<const f32x4 *>(a.st.P + (size_t)ch0 * PW)[lane]; }
-            else if (lane < 32) v0 = lane < 16 ? a.rs[ch0 + lane] : __float_as_uint(a.rgate[ch0 + lane - 16]);
+            constexpr int NP4 = CPW * PW / 4;      // f32x4 pieces of the site's producer constants of the CPW channels
+            if (wave == 4) { if (lane < 4 * CPW) d0 = dsrc(lane); if (lane + 64 < 4 * CPW) d1 = dsrc(lane + 64); }
+            else if (wave == 5) { if (lane < NP4) p0 = reinterpret_cast<const f32x4 *>(a.st.P + (size_t)ch0 * PW)[lane]; if (lane + 64 < NP4) p1 = reinterpret_cast<const f32x4 *>(a.st.P + (size_t)ch0 * PW)[lane + 64]; }
+            else if (lane < 2 * CPW) v0 = lane < CPW ? a.rs[ch0 + lane] : __float_as_uint(a.rgate[ch0 + lane - CPW]);
             __syncthreads();   // order
-            if (wave == 4) sd[lane] = d0;
-            else if (wave == 5) { if (lane < 4 * PW) reinterpret_cast<f32x4 *>(sp)[lane] = p0; }
-            else if (lane < 32) srs[lane] = v0;          // (rs[16] and rgate[16] are adjacent)
+            if (wave == 4) { if (lane < 4 * CPW) sd[lane] = d0; if (lane + 64 < 4 * CPW) sd[lane + 64] = d1; }
+            else if (wave == 5) { if (lane < NP4) reinterpret_cast<f32x4 *>(sp)[lane] = p0; if (lane + 64 < NP4) reinterpret_cast<f32x4 *>(sp)[lane + 64] = p1; }
+            else if (lane < 2 * CPW) srs[lane] = v0;          // (rs[CPW] and rgate[CPW] are adjacent)
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
         wait_count(&tc->staged, TILE_NWP, fail);
         const float Sf = bc[0];
         const double sc = scale_of(bc[4]), cA = tile_cA(tc, 0, 4.0 * (double)D);
         tl_stamp(a.tl, 5);
-        auto on_tile = [&](int) {
-            if (lane < 16) {
-                const int g = ch0 + lane;
-                const long long M = tile_row_sum(tsum, 0, lane);
-                const float v = (float)(sc * ((double)M + cA + TILE_CU * (double)srs[lane])) + Sf;
-                const double xold = sd[lane];
-                const double xnew = xold + (double)(v * srg[lane]);                       // blockout, rwkv.cu:407 (f32 product)
+        auto on_tile = [&](int t) {
+            if (lane < TH) {
+                const int li = t * TH + lane, g = ch0 + li;
+                const long long M = tile_row_sum<TH>(tsum, t, lane);
+                const float v = (float)(sc * ((double)M + cA + TILE_CU * (double)srs[li])) + Sf;
+                const double xold = sd[li];
+                const double xnew = xold + (double)(v * srg[li]);                         // blockout, rwkv.cu:407 (f32 product)
                 a.x[g] = xnew;
-                a.sdd[so + g] = sd[16 + lane] * ((xold - mean2) * rstd2) + sd[32 + lane];   // mixffn's state write (:344): ln2 output
+                a.sdd[so + g] = sd[CPW + li] * ((xold - mean2) * rstd2) + sd[2 * CPW + li];   // mixffn's state write (:344): ln2 output
                 SitePre<NVN> pre;
 #pragma unroll
-                for (int k = 0; k < PW / 4; k++) pre.p[k] = reinterpret_cast<const f32x4 *>(sp + lane * PW)[k];
+                for (int k = 0; k < PW / 4; k++) pre.p[k] = reinterpret_cast<const f32x4 *>(sp + li * PW)[k];
                 SiteAcc<NVN> acc;
                 acc.clear();
-                site_emit<NVN>(pre, a.dy, D, g, xnew, sd[48 + lane], acc);
-                tile_site_leave<NVN>(acc, scr, lane);
+                site_emit<NVN>(pre, a.dy, D, g, xnew, sd[3 * CPW + li], acc);
+                tile_site_leave<NVN>(acc, scr, CPW, li);
             }
         };
-        tile_consume<S, UPT>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile);
+        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
-    tile_site_publish(a.dy, scr);
+    tile_site_publish(a.dy, scr, CPW);
     ring_report(fail, a.herr);
     tl_stamp(a.tl, 7);
 }

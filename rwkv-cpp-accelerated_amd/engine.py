@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "rwkv_create", "rwkv_load_file", "rwkv_load_tensors", "rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx",
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
-    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_debug_carry_hits", "rwkv_debug_carry_stats", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
+    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_decode_form", "rwkv_debug_carry_hits", "rwkv_debug_carry_stats", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
     "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_rccl_path", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode", "rwkv_pipe_decode_streams", "rwkv_pipe_profile", "rwkv_pipe_hop_stats",
     "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device", "rwkv_pipe_info", "rwkv_pipe_decode_dual",
 ]
@@ -73,6 +73,7 @@ def lib():
     L.rwkv_debug_timeline.argtypes = [vp, u64, vp, u64]; L.rwkv_debug_timeline.restype = i32
     L.rwkv_abi_version.argtypes = []; L.rwkv_abi_version.restype = i32
     L.rwkv_resident_bytes.argtypes = [vp]; L.rwkv_resident_bytes.restype = u64
+    L.rwkv_decode_form.argtypes = [vp]; L.rwkv_decode_form.restype = i32
     if hasattr(L, "rwkv_debug_carry_hits"):      # debug counters: absent from tuning variants built from older sources
         L.rwkv_debug_carry_hits.argtypes = [vp, C.POINTER(u64)]; L.rwkv_debug_carry_hits.restype = i32
     if hasattr(L, "rwkv_debug_carry_stats"):
@@ -391,6 +392,10 @@ class RWKV:
 
     def resident_bytes(self) -> int:
         return int(lib().rwkv_resident_bytes(self._h))
+
+    def decode_form(self) -> int:
+        """Mask of the per-layer decode kernel classes that stream the tile image (bit 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v)."""
+        return int(lib().rwkv_decode_form(self._h))
 
     def carry_hits(self):
         """(found, not found): workgroup launches whose first weight rows were / were not waiting in LDS (needs RWKV_CARRY_COUNT=1 at load)"""

@@ -607,3 +607,42 @@ def test_tile_form_decode_is_the_row_form_bit_for_bit_on_one_weight_image(built,
         for sg in stages:
             sg.m.close()
     assert st[0][0] == st[1][0] and np.array_equal(st[0][1], st[1][1]), (st[0][0], st[1][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,default_mask", [(5120, 4), (2048, 0), (4096, 15)])
+def test_each_decode_class_is_resident_in_the_one_layout_it_streams(built, monkeypatch, D, default_mask):
+    """RWKV_TILE is a mask over the four per-layer decode classes (rwkv_decode_form).  A class in tile form streams 16-row tiles at
+    4096 channels and 4-row tiles at 5120 / 2048 (five / two tiles per class and workgroup, csrc/tile.hip.h); its row form is not kept, a
+    class in row form keeps no tile image unless the chunk path needs one: the resident bytes of a max_ctx = 1 context are ONE copy of
+    the matrices whatever the mask.  Every mask gives the same logits bit for bit (the same exact integers reach the same epilogues), and
+    the default is what was measured faster on this part: all four classes at 4096, ffn k/r alone at 5120, none at 2048."""
+    import torch
+    from rwkv_cpp_accelerated_amd import engine
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the tile forms are laid out for 256 workgroups")
+    L = 2
+    t = mf.synthetic_tensors(L, D, seed=5 + D)
+    weights = 13 * L * D * D + mf.VOCAB * D
+    ref, sizes = None, {}
+    for mask in (0, None, 4, 9, 15):
+        if mask is None:
+            monkeypatch.delenv("RWKV_TILE", raising=False)
+        else:
+            monkeypatch.setenv("RWKV_TILE", str(mask))
+        m = engine.RWKV(resident=True); m.loadTensors(L, D, t, maxGPT=1)
+        assert m.decode_form() == (default_mask if mask is None else mask)
+        sizes[mask] = m.resident_bytes()
+        out, tk = [], 11
+        for step in range(6):
+            a = m.forward(tk)[: mf.VOCAB].copy()
+            out.append(a); tk = parity.argmax_ban0(a)
+        out.append(m.decode_greedy(tk, 8))
+        m.close()
+        if ref is None:
+            ref = out
+        else:
+            for x, y in zip(ref, out):
+                assert np.array_equal(x, y), mask
+    for mask, b in sizes.items():
+        assert abs(b - sizes[0]) < 0.02 * weights, sizes

@@ -1,14 +1,15 @@
 """tile-form decode kernels (csrc/tile.hip.h, env RWKV_TILE = bit mask of classes: 1 k_att, 2 k_attout, 4 k_ffn_rk, 8 k_ffnv) against the
-row-form kernels on the same synthetic 7B-wide model: greedy ids and logits over a few teacher-forced tokens per mask, then (optional)
-the phase timeline of one class in both forms.  python tools/tile_check.py [layers] [timeline class 1..4]"""
+row-form kernels on the same synthetic model (7B width by default): greedy ids and logits over a few teacher-forced tokens per mask, then (optional)
+the phase timeline of one class in both forms.  python tools/tile_check.py [layers] [timeline class 1..4] [n_embed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch                                                 # noqa: E402
 from rwkv_cpp_accelerated_amd import engine, modelfile as mf              # noqa: E402
 
-L, D = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 4096
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 tlc = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 4096          # 4096: 16-row tiles (the chunk path's image); 5120 / 2048: 4-row tiles (decode-only image)
 t = mf.synthetic_tensors_torch(L, D, seed=0)
 
 
