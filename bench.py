@@ -637,17 +637,18 @@ def ref_kernel_leg(mf, tensors, L, D, prompt, engine_model, steps, budget_s, B_t
 
 
 def decode_src_digest():
-    """sha256 over the sources that decide what a decode launch reads: the kernels AND the engine (grid, ring geometry, carry plan)"""
+    """sha256 over the sources that decide what a decode launch reads: the kernels (row form, tile form) AND the engine (grid, ring
+    geometry, which class runs in which form, carry plan)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip.h", "engine.hip"):
+    for f in ("kernels.hip.h", "tile.hip.h", "engine.hip"):
         h.update(open(os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
 
 def traffic_lookup(model, kernel):
     """HBM bytes per launch of `kernel` from the newest profiles/rNN/hbm_traffic.json whose recorded source digest matches the
-    kernels.hip.h + engine.hip in the tree (tools/gpu_round.sh records it); {traffic: None, traffic_source: why} otherwise."""
+    kernels.hip.h + tile.hip.h + engine.hip in the tree (tools/gpu_round.sh records it); {traffic: None, traffic_source: why} otherwise."""
     import glob
     digest = decode_src_digest()
     stale = []
@@ -662,8 +663,8 @@ def traffic_lookup(model, kernel):
             continue
         v = d.get(model, {}).get(kernel)
         if v is not None:
-            return dict(traffic=v, traffic_source=f"{rel} (rocprofv3 --pmc FETCH_SIZE x 2, per launch; same kernels.hip.h + engine.hip as this run)")
-    return dict(traffic=None, traffic_source="no PMC pass on record for this kernels.hip.h + engine.hip" + (f" (other sources: {', '.join(stale[:2])})" if stale else ""))
+            return dict(traffic=v, traffic_source=f"{rel} (rocprofv3 --pmc FETCH_SIZE x 2, per launch; same kernels.hip.h + tile.hip.h + engine.hip as this run)")
+    return dict(traffic=None, traffic_source="no PMC pass on record for this kernels.hip.h + tile.hip.h + engine.hip" + (f" (other sources: {', '.join(stale[:2])})" if stale else ""))
 
 
 def small_model_leg(mf, engine, name, steps, device, dev):

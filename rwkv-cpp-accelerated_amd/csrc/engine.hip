@@ -964,9 +964,14 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         k_bimage<<<dim3((unsigned)((per / 16 + 255) / 256)), dim3(256), 0, c->stream>>>(w_t, bdst, (int)N, (int)K, Q, (int)((((N + Q - 1) / Q) + TH - 1) / TH), TH);
         if (r8dst) k_rowsum8<<<dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream>>>(w_t, r8dst, (int)N, (int)K);
     };
-    uint8_t *staging = nullptr, *rowtmp = nullptr;
-    if (!src.on_device) HIPCHK(hipMalloc(reinterpret_cast<void **>(&staging), std::max<uint64_t>(4 * D * D, V * D)));
-    if (c->tile) HIPCHK(hipMalloc(reinterpret_cast<void **>(&rowtmp), 5 * D * D));
+    // load-time scratch (not part of the context): freed on every way out of this function, behind the stream's work
+    struct Scratch {
+        hipStream_t st; uint8_t *p = nullptr;
+        ~Scratch() { if (p) { (void)hipStreamSynchronize(st); (void)hipFree(p); } }
+    } staging_s{c->stream}, rowtmp_s{c->stream};
+    if (!src.on_device) HIPCHK(hipMalloc(reinterpret_cast<void **>(&staging_s.p), std::max<uint64_t>(4 * D * D, V * D)));
+    if (c->tile) HIPCHK(hipMalloc(reinterpret_cast<void **>(&rowtmp_s.p), 5 * D * D));
+    uint8_t *const staging = staging_s.p, *const rowtmp = rowtmp_s.p;
     for (uint64_t l = l0; l < l1 && !rc; l++) {
         const uint64_t lr = l - l0;
         uint8_t *kvr = in_tile(1) ? rowtmp : c->w_kvr + lr * 3 * D * D;
@@ -1011,11 +1016,8 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
             if (!rc) image(c->w_head, c->b_head, c->r8_head, V, D, 1, per_head);
         }
     }
-    hipError_t se = hipStreamSynchronize(c->stream);
-    if (staging) (void)hipFree(staging);
-    if (rowtmp) (void)hipFree(rowtmp);
     if (rc) return rc;
-    HIPCHK(se);
+    HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
 
     // state (zero, as `new RWKVState` does: rwkv.h:163-170) and scratch
