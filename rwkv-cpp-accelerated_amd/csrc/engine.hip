@@ -2157,13 +2157,17 @@ int rwkv_pipe_init(rwkv_ctx *c, const void *id128, int rank, int world)
     {
         const uint64_t my_ch = !c->seq_ok ? 0 : (c->seq_rows > SEQ_T && c->maxT >= (uint64_t)SEQ_TM) ? (uint64_t)SEQ_TM : (c->maxT >= (uint64_t)SEQ_T ? (uint64_t)SEQ_T : 0);
         uint64_t mm[8] = {my_ch, my_ch, c->D, c->D, c->L, c->L, (uint64_t)world, (uint64_t)world};      // (min, max) pairs
-        if (world > 1) {
+        {   // (world == 1: one hop to SELF -- nothing to agree on, but it is the one ncclSend / ncclRecv group a single process can make on the
+            //  real library: entry points, datatype codes, the group and the stream order are exercised before any pipeline depends on them)
             uint64_t *d = nullptr;
             if (hipMalloc(reinterpret_cast<void **>(&d), 16 * sizeof(uint64_t)) != hipSuccess) return undo(fail(RWKV_E_DEVICE, "rwkv_pipe_init: no device memory for the agreement round"));
             int r = 0;
             hipError_t e = hipSuccess;
-            for (int hop = 0; hop + 1 < world && !r && e == hipSuccess; hop++) {
+            bool self_ok = true;
+            const int hops = world > 1 ? world - 1 : 1;
+            for (int hop = 0; hop < hops && !r && e == hipSuccess; hop++) {
                 e = hipMemcpyAsync(d, mm, sizeof(mm), hipMemcpyHostToDevice, c->stream);
+                if (e == hipSuccess) e = hipMemsetAsync(d + 8, 0xff, 8 * sizeof(uint64_t), c->stream);
                 if (e != hipSuccess) break;
                 r = p->GroupStart();
                 if (!r) r = p->Send(d, 8, kNcclUint64, (rank + 1) % world, p->comm, c->stream);
@@ -2173,12 +2177,15 @@ int rwkv_pipe_init(rwkv_ctx *c, const void *id128, int rank, int world)
                 uint64_t got[8];
                 if (!r) e = hipMemcpyAsync(got, d + 8, sizeof(got), hipMemcpyDeviceToHost, c->stream);
                 if (!r && e == hipSuccess) e = hipStreamSynchronize(c->stream);
-                if (!r && e == hipSuccess)
+                if (!r && e == hipSuccess) {
+                    if (world == 1) self_ok = memcmp(got, mm, sizeof(got)) == 0;
                     for (int k = 0; k < 8; k += 2) { mm[k] = std::min(mm[k], got[k]); mm[k + 1] = std::max(mm[k + 1], got[k + 1]); }
+                }
             }
             (void)hipFree(d);
             if (r) { rc = pipe_fail(p, r, "agreement round of rwkv_pipe_init"); if (rank > 0) { c->x_in = nullptr; (void)rebuild_graphs(c); } return undo(rc); }
             if (e != hipSuccess) { rc = fail(RWKV_E_DEVICE, "agreement round of rwkv_pipe_init: %s", hipGetErrorString(e)); if (rank > 0) { c->x_in = nullptr; (void)rebuild_graphs(c); } return undo(rc); }
+            if (!self_ok) return undo(fail(RWKV_E_DEVICE, "rwkv_pipe_init: a grouped ncclSend / ncclRecv of 8 x uint64 to this rank itself did not deliver what was sent"));
         }
         if (mm[0] != mm[1] || mm[2] != mm[3] || mm[4] != mm[5] || mm[6] != mm[7]) {
             rc = fail(RWKV_E_ARG, "the ranks of this pipeline disagree: prefill micro-batch rows %llu..%llu (RWKV_SEQ_ROWS / max_ctx differ between ranks; this rank: %llu), "

@@ -8,13 +8,18 @@
 //
 // Transport: one POSIX shared-memory segment per communicator (its name travels in the 128-byte unique id), one channel per
 // (source, destination) pair: a ring of SLOTS staging slots with a produced / consumed sequence pair.  All of it STREAM
-// ORDERED like the real calls:
-//   send  = hipMemcpyAsync device -> slot (the segment is hipHostRegister'ed), then a host function that publishes the slot
-//   recv  = a host function that waits for the slot, hipMemcpyAsync slot -> device, then a host function that frees it
+// ORDERED like the real calls, and -- like the real calls -- every wait is made ON THE DEVICE, in the stream:
+//   send  = a one-lane kernel that waits for room in the ring, hipMemcpyAsync device -> slot (the segment is hipHostRegister'ed),
+//           then a host function that publishes the slot
+//   recv  = a one-lane kernel that waits for the slot's sequence number, hipMemcpyAsync slot -> device, then a host function that
+//           frees it
+// No host function ever blocks: HIP runs the host functions of all of a process's streams on one thread, so a blocking wait in one
+// stream's callback held back the publishing callbacks of the process's OTHER streams -- with two communicators on two streams per
+// rank (rwkv_pipe_decode_dual) two ranks could wait for each other that way until the time-out (seen once in a full GPU-suite run).
 // Inside ncclGroupStart / ncclGroupEnd the operations are queued and issued at GroupEnd, sends first -- a send never waits for
 // its peer unless SLOTS messages of that channel are unconsumed -- so a group that sends to one peer and receives from another
 // cannot deadlock, which is the property of an RCCL group the engine's tick relies on.
-// Bounded waits (30 s): a lost peer ends the test with an error instead of hanging the box.
+// Bounded waits (30 s of the device's wall clock): a lost peer ends the test with an error instead of hanging the box.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -58,7 +63,10 @@ struct Comm {
     int rank = 0, nranks = 1;
     std::string name;
     uint64_t sent[MAX_RANKS] = {}, recvd[MAX_RANKS] = {};     // messages enqueued so far per peer
-    std::atomic<int> failed{0};
+    Segment *seg_dev = nullptr;                                // the segment as the device addresses it
+    int *failed = nullptr;                                     // pinned host word, written by a wait kernel that gave up (or a size mismatch)
+    uint64_t wait_ticks = 0;                                   // WAIT_MS in ticks of the device's wall clock
+    bool has_failed() const { return __atomic_load_n(failed, __ATOMIC_ACQUIRE) != 0; }
     char *slot(int src, int dst, uint64_t seq) const
     {
         return reinterpret_cast<char *>(seg) + sizeof(Segment) + ((((size_t)src * nranks + dst) * SLOTS) + seq % SLOTS) * SLOT_BYTES;
@@ -69,21 +77,17 @@ struct Op { bool send; void *buf; size_t bytes; int peer; Comm *c; hipStream_t s
 thread_local int g_depth = 0;
 thread_local std::vector<Op> g_queue;
 
-struct Note { Comm *c; int src, dst; uint64_t seq; size_t bytes; int what; };   // what: 0 publish, 1 wait for data, 2 free, 3 wait for room
+struct Note { Comm *c; int src, dst; uint64_t seq; size_t bytes; int what; };   // what: 0 publish, 1 check the size of what arrived, 2 free
 
-bool wait_until(const std::atomic<uint64_t> &v, uint64_t least, Comm *c)
+// stream-ordered wait for *flag >= least (a sequence number another PROCESS advances in the shared segment): one lane polling host memory
+__global__ void k_wait(const uint64_t *flag, uint64_t least, int *failed, uint64_t ticks)
 {
-    const auto t0 = std::chrono::steady_clock::now();
-    while (v.load(std::memory_order_acquire) < least) {
-        if (c->failed.load()) return false;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(WAIT_MS)) {
-            fprintf(stderr, "[fake_rccl] rank %d: peer did not show up within %d ms\n", c->rank, WAIT_MS);
-            c->failed.store(1);
-            return false;
-        }
-        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    const uint64_t t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < least) {
+        if (__hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
+        if (wall_clock64() - t0 > ticks) { __hip_atomic_store(failed, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+        __builtin_amdgcn_s_sleep(127);
     }
-    return true;
 }
 void host_note(void *p)
 {
@@ -92,33 +96,38 @@ void host_note(void *p)
     switch (n->what) {
     case 0: ch.bytes[n->seq % SLOTS] = n->bytes; ch.produced.store(n->seq + 1, std::memory_order_release); break;
     case 1:
-        if (wait_until(ch.produced, n->seq + 1, n->c) && ch.bytes[n->seq % SLOTS] != n->bytes) {
+        if (ch.produced.load(std::memory_order_acquire) < n->seq + 1) {
+            if (__atomic_load_n(n->c->failed, __ATOMIC_ACQUIRE) == 2)
+                fprintf(stderr, "[fake_rccl] rank %d: peer %d did not show up within %d ms\n", n->c->rank, n->src, WAIT_MS);
+        } else if (ch.bytes[n->seq % SLOTS] != n->bytes) {
             fprintf(stderr, "[fake_rccl] rank %d: message %llu from %d has %llu bytes, receiver asked for %zu\n", n->c->rank,
                     (unsigned long long)n->seq, n->src, (unsigned long long)ch.bytes[n->seq % SLOTS], n->bytes);
-            n->c->failed.store(1);
+            __atomic_store_n(n->c->failed, 1, __ATOMIC_RELEASE);
         }
         break;
     case 2: ch.consumed.store(n->seq + 1, std::memory_order_release); break;
-    case 3: if (n->seq >= (uint64_t)SLOTS) wait_until(ch.consumed, n->seq - SLOTS + 1, n->c); break;
     }
     delete n;
 }
 int enqueue(const Op &o)
 {
     Comm *c = o.c;
-    if (o.bytes > SLOT_BYTES || o.peer < 0 || o.peer >= c->nranks || o.peer == c->rank) return 4;   // ncclInvalidArgument
+    if (o.bytes > SLOT_BYTES || o.peer < 0 || o.peer >= c->nranks) return 4;   // ncclInvalidArgument (a hop to the rank itself is allowed, as in NCCL >= 2.7 inside a group: the send is enqueued first)
     if (o.send) {
         const uint64_t seq = c->sent[o.peer]++;
-        if (hipLaunchHostFunc(o.st, host_note, new Note{c, c->rank, o.peer, seq, o.bytes, 3}) != hipSuccess) return 1;
+        if (seq >= (uint64_t)SLOTS)
+            k_wait<<<dim3(1), dim3(1), 0, o.st>>>(reinterpret_cast<const uint64_t *>(&c->seg_dev->ch[c->rank][o.peer].consumed), seq - SLOTS + 1, c->failed, c->wait_ticks);
         if (hipMemcpyAsync(c->slot(c->rank, o.peer, seq), o.buf, o.bytes, hipMemcpyDeviceToHost, o.st) != hipSuccess) return 1;
         if (hipLaunchHostFunc(o.st, host_note, new Note{c, c->rank, o.peer, seq, o.bytes, 0}) != hipSuccess) return 1;
     } else {
         const uint64_t seq = c->recvd[o.peer]++;
+        k_wait<<<dim3(1), dim3(1), 0, o.st>>>(reinterpret_cast<const uint64_t *>(&c->seg_dev->ch[o.peer][c->rank].produced), seq + 1, c->failed, c->wait_ticks);
         if (hipLaunchHostFunc(o.st, host_note, new Note{c, o.peer, c->rank, seq, o.bytes, 1}) != hipSuccess) return 1;
         if (hipMemcpyAsync(o.buf, c->slot(o.peer, c->rank, seq), o.bytes, hipMemcpyHostToDevice, o.st) != hipSuccess) return 1;
         if (hipLaunchHostFunc(o.st, host_note, new Note{c, o.peer, c->rank, seq, o.bytes, 2}) != hipSuccess) return 1;
     }
-    return c->failed.load() ? 2 : 0;
+    if (hipGetLastError() != hipSuccess) return 1;
+    return c->has_failed() ? 2 : 0;
 }
 size_t type_bytes(int t)
 {
@@ -160,13 +169,22 @@ int ncclCommInitRank(void **comm, int nranks, ncclUniqueId id, int rank)
     close(fd);
     if (p == MAP_FAILED) { delete c; return 2; }
     c->seg = static_cast<Segment *>(p);
-    if (hipHostRegister(p, c->bytes, hipHostRegisterPortable) != hipSuccess) { munmap(p, c->bytes); delete c; return 1; }
+    if (hipHostRegister(p, c->bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) { munmap(p, c->bytes); delete c; return 1; }
+    void *dp = nullptr;
+    int dev = 0, khz = 0;
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || hipHostMalloc(reinterpret_cast<void **>(&c->failed), 64, hipHostMallocMapped) != hipSuccess ||
+        hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) {
+        (void)hipHostUnregister(p); munmap(p, c->bytes); delete c; return 1;
+    }
+    c->seg_dev = static_cast<Segment *>(dp);
+    *c->failed = 0;
+    c->wait_ticks = (uint64_t)khz * (uint64_t)WAIT_MS;
     c->seg->nranks = (uint32_t)nranks;
     c->seg->joined.fetch_add(1);
     const auto t0 = std::chrono::steady_clock::now();
     while (c->seg->joined.load() < (uint32_t)nranks) {       // like the real call: returns once every rank has joined
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(WAIT_MS)) {
-            (void)hipHostUnregister(p); munmap(p, c->bytes); shm_unlink(c->name.c_str()); delete c;
+            (void)hipHostUnregister(p); (void)hipHostFree(c->failed); munmap(p, c->bytes); shm_unlink(c->name.c_str()); delete c;
             return 2;
         }
         std::this_thread::sleep_for(std::chrono::microseconds(100));
@@ -182,6 +200,7 @@ int ncclCommDestroy(void *comm)
     (void)hipDeviceSynchronize();
     const bool last = c->seg->left.fetch_add(1) + 1 == (uint32_t)c->nranks;
     (void)hipHostUnregister(c->seg);
+    (void)hipHostFree(c->failed);
     munmap(c->seg, c->bytes);
     if (last) shm_unlink(c->name.c_str());
     delete c;

@@ -103,14 +103,18 @@ def test_14b_shape_virtual_stages(eng_mod, S):
 
 
 def test_native_transport_single_rank(eng_mod):
-    """rwkv_pipe_init / rwkv_pipe_decode / rwkv_pipe_prefill with world = 1: librccl.so is resolved and a communicator is
-    made, the tick loop, the control-block ring and the device-side id feedback run (no hop to make): must equal
-    decode_greedy and the chunked forward"""
+    """rwkv_pipe_init / rwkv_pipe_decode / rwkv_pipe_prefill with world = 1 on the REAL library: librccl.so is resolved, a
+    communicator is made, and rwkv_pipe_init's agreement round makes its one hop to the rank itself -- a grouped ncclSend + ncclRecv of
+    8 x uint64 on the engine's stream, checked byte for byte: the entry points, datatype codes, group and stream order the multi-GPU
+    schedule is built on, executed by the library the driver's 8-GPU run will use.  Then the tick loop, the control-block ring and the
+    device-side id feedback run (no further hop to make): must equal decode_greedy and the chunked forward"""
     L, D, n = 3, 768, 24
     t = mf.synthetic_tensors(L, D, seed=92)
     a = eng_mod.RWKV(resident=True); a.loadTensors(L, D, t, maxGPT=32)
     b = eng_mod.RWKV(resident=True); b.loadTensors(L, D, t, maxGPT=32)
     b.pipe_init(eng_mod.RWKV.pipe_unique_id(), 0, 1)
+    info = b.pipe_info()
+    assert info["world"] == 1 and info["rccl_version"] > 20000 and "fake" not in info["rccl_path"], info      # (2.x.y as 2xxyy: not the test stand-in)
     prompt = [int(x) for x in np.random.default_rng(2).integers(2, mf.VOCAB, 70)]
     for i in range(0, 70, 32):
         a.forward(prompt[i:i + 32], eng_mod.MODE_GPT)
