@@ -7,7 +7,7 @@ R=$PWD; TAG=${1:-r05}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 export PYTHONUNBUFFERED=1
 if [ -z "$SKIP_TESTS" ]; then
-  timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rs 2>&1 | grep -v "^loading\|^n_layers\|^n_embed" | tail -8 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
+  timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rs -rf 2>&1 | grep -v "^loading\|^n_layers\|^n_embed\|amdgpu.ids\|socket.cpp\|^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl\|pipeline transport up" | tail -80 > $O/pytest_gpu.log; tail -12 $O/pytest_gpu.log
 fi
 timeout 900 python bench.py 2>$O/bench7b_full.err | tail -1 > $O/bench7b_full.json; cut -c1-300 $O/bench7b_full.json
 # the N > 1 line as the driver will run it, dry on the one GPU: 2 ranks, torch.distributed over gloo; (a) the engine's NATIVE schedule over the
