@@ -19,7 +19,7 @@
 // Inside ncclGroupStart / ncclGroupEnd the operations are queued and issued at GroupEnd, sends first -- a send never waits for
 // its peer unless SLOTS messages of that channel are unconsumed -- so a group that sends to one peer and receives from another
 // cannot deadlock, which is the property of an RCCL group the engine's tick relies on.
-// Bounded waits (30 s of the device's wall clock): a lost peer ends the test with an error instead of hanging the box.
+// Bounded waits (60 s of the device's wall clock; 120 s for the ranks to join): a lost peer ends the test with an error instead of hanging the box.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -41,7 +41,8 @@ namespace {
 constexpr int SLOTS = 4;
 constexpr size_t SLOT_BYTES = 3u << 20;       // largest message: a 64-row pass of the residual stream at D = 5120 (2.5 MiB)
 constexpr int MAX_RANKS = 8;
-constexpr int WAIT_MS = 30000;
+constexpr int WAIT_MS = 60000;       // a peer's data or room in the ring (device wall clock)
+constexpr int JOIN_MS = 120000;      // all ranks inside ncclCommInitRank (a rank may still be loading its share of the model)
 
 struct Channel {
     std::atomic<uint64_t> produced, consumed;
@@ -183,7 +184,7 @@ int ncclCommInitRank(void **comm, int nranks, ncclUniqueId id, int rank)
     c->seg->joined.fetch_add(1);
     const auto t0 = std::chrono::steady_clock::now();
     while (c->seg->joined.load() < (uint32_t)nranks) {       // like the real call: returns once every rank has joined
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(WAIT_MS)) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(JOIN_MS)) {
             (void)hipHostUnregister(p); (void)hipHostFree(c->failed); munmap(p, c->bytes); shm_unlink(c->name.c_str()); delete c;
             return 2;
         }
