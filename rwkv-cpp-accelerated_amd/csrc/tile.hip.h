@@ -1,22 +1,25 @@
-// tile.hip.h -- TILE-FORM decode kernel for ffn k/r (round 5; the gate the round-4 review set for "decode on the MFMA B-operand image":
-// built for k_ffn_rk first, measured against the row-form ring kernel on one box; see DESIGN.md 4.7 for the outcome and for why the tile
-// image cannot serve every model width).
+// tile.hip.h -- TILE-FORM decode kernels (round 5): the four per-layer kernels of a token on a TILE image of the matrices instead of the
+// row-per-output re-tiling of kernels.hip.h.  Built for k_ffn_rk first -- the gate the round-4 review set ("decode on the MFMA B-operand
+// image" against the row-form ring kernel on one box) --, then for all four classes; DESIGN.md 4.7 has the measurements, including those
+// that decide which class runs in which form at which width (engine.hip tile_cfg_for / rwkv_ctx::tile).
 //
-// The row-form decode kernels (kernels.hip.h) stream a matrix re-tiled to row-per-output order: a wave owns whole rows, a lane 16 bytes of
-// a row per step, every row ends in three 6-step DPP reductions and an epilogue on one lane.  This kernel consumes the image the chunk
-// path already holds (seq.hip.h k_bimage): [16-row tile][k-block of 64][lane][16 B], lane = 16 * (k-quarter) + row, bytes SIGNED (u - 128).
-//   * a wave instruction's 1 KiB is 64 inputs of 16 rows: lane l accumulates row l % 16 over quarter l / 16 of every k-block it meets --
-//     no cross-lane reduction per row at all; the four quarters of a row and the k-ranges of different waves meet as exact integer adds
-//     in LDS (ds_add_u32: the sums are integers, so the order they arrive in changes nothing);
-//   * the ring unit is S KiB = S k-blocks of ONE tile (contiguous in the image: one dma_unit), units go round-robin to the 7 consumer
-//     waves, every unit is freed as soon as its S ds_read_b128 are in the LDS queue: fine-grained turnover, all waves busy from the
-//     first unit on (row form: 5 groups of 20 KiB in the ring for 7 waves);
-//   * the wave whose add completes a tile runs that tile's 16 epilogues side by side on 16 lanes;
+// The row-form decode kernels stream a matrix re-tiled to row-per-output order: a wave owns whole rows, a lane 16 bytes of a row per
+// step, every row ends in three 6-step DPP reductions and an epilogue on one lane.  These kernels stream the image k_bimage (seq.hip.h)
+// makes: [TH-row tile][k-fragment of 1 KiB][lane][16 B], lane = TH * (piece along k) + row, bytes SIGNED (u - 128).  TH = 16 is the
+// chunk path's MFMA B-operand image itself (4096 channels: one tile per class and workgroup, 64 inputs per fragment); TH = 4 is the
+// same layout for widths where 16 channels per workgroup do not divide (5120: five tiles per class, 256 inputs per fragment; 2048: two).
+//   * a wave instruction's 1 KiB is 1024 / TH inputs of TH rows: lane l accumulates row l % TH over piece l / TH of every fragment it
+//     meets -- TH = 16: no cross-lane reduction per row at all, TH = 4: two DPP steps --; the pieces of a row and the k-ranges of
+//     different waves meet as exact integer adds in LDS (ds_add_u32: the sums are integers, so the order they arrive in changes nothing);
+//   * the ring unit is S KiB = S fragments of ONE tile (contiguous in the image: one dma_unit), units go to the 7 consumer waves round
+//     robin (or in runs, tile_run), every unit is freed as soon as its S ds_read_b128 are in the LDS queue: fine-grained turnover, all
+//     waves busy from the first unit on (row form: 5 groups of 20 KiB in the ring for 7 waves);
+//   * the wave whose add completes a tile runs that tile's TH epilogues side by side on TH lanes;
 //   * activations: the same 23-bit fixed point, limbs stored SIGNED (limb - 128) so that v_dot4_i32_i8 multiplies the image's bytes as
 //     they are: sum u l = dot + 128 rowsum(u) + 128 sum(l) - 16384 N, folded into one constant per vector (cA) and the row-sum
-//     coefficient 4227200 the chunk path uses (seq.hip.h SEQ_CU).  Every row value is the SAME exact integer as in row form: the
-//     kernel's hbuf / rgate are bit-identical to k_ffn_rk's.
-//   * staged vector layout [k-block][quarter][limb][16 B]: a lane's operand is one ds_read_b128, 16 lanes share an address (broadcast).
+//     coefficient 4227200 the chunk path uses (seq.hip.h SEQ_CU).  Every row value is the SAME exact integer as in row form: logits and
+//     state are bit-identical to the row-form kernels' for every mix of forms (tests/test_engine_gpu.py);
+//   * staged vector layout [16-byte piece along k][limb][16 B]: a lane's operand is one ds_read_b128, TH lanes share an address (broadcast).
 // Integer contraction on the VALU, like row form; MFMA stays where the north_star puts it (the batched mm8_seq case).
 #pragma once
 #include "kernels.hip.h"
