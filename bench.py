@@ -268,7 +268,10 @@ def main():
         dtc = (time.perf_counter() - t0) / args.prefill_chunks
         line["prefill"] = dict(tokens_per_chunk=len(prompt), ms_per_chunk=round(dtc * 1e3, 3), tokens_per_s=round(len(prompt) / dtc, 1),
                                **seq_roofline(L, D, mf.VOCAB, len(prompt), dtc),
-                               note="GPT-mode chunk (RWKV::loadContext path): v_mfma_i32_16x16x64_i8 over three activation limbs; includes logits for all 32 positions")
+                               hbm_traffic=prefill_traffic_lookup(args.model, "chunk32") if len(prompt) == 32 else None,
+                               note="GPT-mode chunk (RWKV::loadContext path): v_mfma_i32_16x16x64_i8 over three activation limbs; includes logits for all 32 positions.  "
+                                    "hbm_traffic: counter-measured HBM bytes of one weight pass (weights + activation images + the per-K-slice partial values written "
+                                    "by the GEMMs and read back by the element-wise kernels) over its weight bytes")
         if args.long_prompt >= 64:
             # a prompt of several chunks handed over in ONE call (RWKV::loadContext with maxContext >= the prompt, rwkv.h:395-413):
             # passes of 64 rows (two 32-row halves that share every weight fragment: weights read once per 64 rows, round 4) as a
@@ -288,6 +291,7 @@ def main():
             dtl = (time.perf_counter() - t0) / 2
             line["prefill"]["long_prompt"] = dict(prompt_tokens=len(lp), tokens_per_s=round(len(lp) / dtl, 1), ms=round(dtl * 1e3, 2),
                                                   **seq_roofline(L, D, mf.VOCAB, len(lp), dtl),
+                                                  hbm_traffic=prefill_traffic_lookup(args.model, "prompt512") if len(lp) == 512 else None,
                                                   note="one rwkv_forward call: passes of 64 rows (two halves per weight fragment; RWKV_SEQ_ROWS=32: the 32-row schedule, bit-identical "
                                                        "results) as a software pipeline over RWKV_SEQ_STAGES (default 3) streams on the one GPU (stage k on pass i while "
                                                        "stage k - 1 is on pass i + 1); RWKV_SEQ_STAGES=1 gives the one-stream schedule")
@@ -644,6 +648,31 @@ def decode_src_digest():
     for f in ("kernels.hip.h", "tile.hip.h", "engine.hip"):
         h.update(open(os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", f), "rb").read())
     return h.hexdigest()
+
+
+def seq_src_digest():
+    """sha256 over the sources that decide what a chunk-path pass moves: the mm8_seq kernels and the engine (pass size, GEMM forms, stage split)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("seq.hip.h", "engine.hip"):
+        h.update(open(os.path.join(ROOT, "rwkv-cpp-accelerated_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def prefill_traffic_lookup(model, key):
+    """counter-measured HBM bytes per weight pass of the chunk path (key "chunk32": one 32-token chunk per call, "prompt512": 64-row passes of
+    a 512-token call) from the newest profiles/rNN/prefill_traffic.json whose source digest matches this tree (tools/prefill_traffic.sh)"""
+    import glob
+    digest = seq_src_digest()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "prefill_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        v = d.get(model, {}).get(key)
+        if d.get("seq_src_sha256") == digest and v is not None:
+            return dict(v, source=f"{os.path.relpath(f, ROOT)} (rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE, own passes; same seq.hip.h + engine.hip as this run)")
+    return dict(source="no PMC pass on record for this seq.hip.h + engine.hip")
 
 
 def traffic_lookup(model, kernel):

@@ -67,26 +67,8 @@ json.dump({"7B": traffic, "decode_src_sha256": bench.decode_src_digest(), "_note
            "own rocprofv3 --pmc FETCH_SIZE pass of `bench.py --steps 8 --warmup 2` (tools/gpu_round.sh)"}, open(O + "/hbm_traffic.json", "w"), indent=1)
 PY
 rm -rf $O/kt $O/pmc
-# chunk path (BASELINE config 5): HBM read and write traffic of the k_seq_* kernels, one counter per pass
-cd /tmp
-for CTR in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $O/pmcs
-  timeout 300 rocprofv3 --pmc $CTR --output-format csv -d $O/pmcs -- python $R/tools/prefill_bench.py --chunks 2 > /dev/null 2>&1
-  python - "$O" $CTR <<'PY'
-import csv, glob, sys, collections
-O, ctr = sys.argv[1], sys.argv[2]
-agg = collections.defaultdict(list)
-for f in glob.glob(O + "/pmcs/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == ctr and "k_seq" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0][:90]].append(float(r["Counter_Value"]))
-with open(f"{O}/prefill7b_pmc_{ctr.lower()}.csv", "w") as fo:
-    fo.write(f"kernel,dispatches,mean_{ctr}_KB,total_{ctr}_MB_per_chunk_pass_uncorrected\n")
-    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-        fo.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.1f},{sum(v) / 1024 / 3:.1f}\n")      # 3 passes (warm-up + 2 chunks)
-print(open(f"{O}/prefill7b_pmc_{ctr.lower()}.csv").read()[:1500])
-PY
-done
-rm -rf $O/pmcs
+# chunk path: HBM read and write traffic per weight pass (32-token chunk; 512-token prompt), one counter per pass -> prefill_traffic.json + per-kernel tables
+cd $R
+bash tools/prefill_traffic.sh $TAG 2>&1 | tail -30
 cd $R
 ls $O
