@@ -67,6 +67,9 @@ json.dump({"7B": traffic, "decode_src_sha256": bench.decode_src_digest(), "_note
            "own rocprofv3 --pmc FETCH_SIZE pass of `bench.py --steps 8 --warmup 2` (tools/gpu_round.sh)"}, open(O + "/hbm_traffic.json", "w"), indent=1)
 PY
 rm -rf $O/kt $O/pmc
+# the same counter pass for the other BASELINE sizes (14B: the N > 1 line's model; 1B5: config 2), merged into hbm_traffic.json
+bash tools/pmc_traffic.sh $TAG 14B | tail -8
+bash tools/pmc_traffic.sh $TAG 1B5 | tail -8
 # chunk path: HBM read and write traffic per weight pass (32-token chunk; 512-token prompt), one counter per pass -> prefill_traffic.json + per-kernel tables
 cd $R
 bash tools/prefill_traffic.sh $TAG 2>&1 | tail -30
