@@ -546,6 +546,18 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     out = None
     if rank == 0:
         worst = min(per_stage)
+        # counter-measured HBM read bytes of ONE token through the quoted stage (its layers' four launches + the head on the last stage),
+        # from the per-launch FETCH_SIZE figures of the committed PMC pass for this model and these sources; None if there is none
+        qs = per_stage.index(worst)
+        ql0, ql1 = pipeline.partition_layers(L, world, D)[qs]
+        per_launch = {k: traffic_lookup(args.model, k) for k in ("att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head")}
+        if all(v.get("traffic") is not None for v in per_launch.values()):
+            stage_traffic = (ql1 - ql0) * sum(per_launch[k]["traffic"] for k in ("att_kvr_wkv", "att_out", "ffn_rk", "ffn_v")) + (per_launch["head"]["traffic"] if qs == world - 1 else 0)
+            stage_alg = (ql1 - ql0) * 13 * D * D + (mf.VOCAB * D if qs == world - 1 else 0)
+            traffic_note = dict(traffic=int(stage_traffic), traffic_unit="HBM read bytes per token through the quoted stage", algorithmic_weight_bytes=int(stage_alg),
+                                traffic_source=per_launch["ffn_rk"]["traffic_source"])
+        else:
+            traffic_note = dict(traffic=None, traffic_source=per_launch["ffn_rk"].get("traffic_source"))
         out = (dict(
             metric=f"tokens/sec RWKV-4 uint8 greedy decode, layers pipelined over {world} GPUs, AGGREGATE of {world} streams in flight (one per stage); "
                    "one_stream.tokens_per_s is the single-stream rate on the same pipeline",
@@ -559,7 +571,7 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
                         parallelism=f"pp{world}: layer pipeline, {transport} (f64[{D}] between stages, greedy id fed back last->first stage)",
                         layer_ranges=pipeline.partition_layers(L, world, D), bytes_per_token=B_tok),
             roofline=dict(bound="hbm", kernel="stage (all decode kernels of a rank's layers)", achieved=worst, peak=HBM_PEAK_GBPS, unit="GB/s",
-                          frac=round(worst / HBM_PEAK_GBPS, 4), traffic=None, per_stage_GBps=per_stage,
+                          frac=round(worst / HBM_PEAK_GBPS, 4), **traffic_note, quoted_stage=qs, per_stage_GBps=per_stage,
                           method="algorithmic bytes of the stage's layers per token x tokens through the stage / wall time of the timed region; "
                                  "the slowest stage is quoted"),
             end_to_end=dict(achieved_GBps=round(B_tok * tok_s / 1e9, 1), frac_of_aggregate_peak=round(B_tok * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)),
