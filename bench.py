@@ -37,7 +37,10 @@ def seq_roofline(L, D, V, rows, seconds):
     every layer matrix is read once per weight pass of up to RWKV_SEQ_ROWS (default 64) rows, the head once per 32-row half;
     every weight byte is multiplied with 3 activation limbs of every row of the pass (2 ops per MAC).  `bound` names the
     roofline that is closer to its peak, i.e. the one that would bind first if the path were perfect."""
-    seq_rows = 32 if os.environ.get("RWKV_SEQ_ROWS") == "32" else 64
+    try:      # the engine's own rule (engine.hip rwkv_create): any value <= 32 means 32-row passes
+        seq_rows = 64 if int(os.environ.get("RWKV_SEQ_ROWS", "64")) > 32 else 32
+    except ValueError:
+        seq_rows = 32       # (atoi of a non-number is 0)
     if rows <= 32:
         seq_rows = 32
     passes = (rows + seq_rows - 1) // seq_rows
@@ -140,13 +143,11 @@ def main():
         ids = m.decode_greedy(first, args.warmup)
         first = int(ids[-1])
 
-    m.carry_stats()                                   # (zeroes the carry counters: what is read below is the timed region's)
     sync_all()
     t0 = time.perf_counter()
     ids = m.decode_greedy(first, args.steps)          # synchronises the engine stream before returning
     sync_all()
     dt = time.perf_counter() - t0
-    c_hit, c_miss, c_rep = m.carry_stats()
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -193,10 +194,7 @@ def main():
                 method="algorithmic uint8 weight bytes of one launch / average launch duration; duration = one hipEvent pair "
                        "around a batch of back-to-back launches of the kernel (all layers x reps) on the engine stream, "
                        "right after the timed region; `traffic` is NOT a counter of this run: it is the committed figure of the "
-                       "separate rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), see traffic_source.  With the carry on "
-                       "(7B default, DESIGN.md 4.5) a launch's first 32-40 KiB per workgroup were streamed by its predecessor's loader "
-                       "and it streams as much for its successor: the batch chains launches of one class the same way, so a launch "
-                       "still moves its algorithmic bytes")
+                       "separate rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), see traffic_source")
     # `traffic`: HBM read bytes per launch of the dominant kernel from the round's own rocprofv3 --pmc FETCH_SIZE pass
     # (tools/gpu_round.sh writes profiles/<round>/hbm_traffic.json together with the sha256 of the kernel source it profiled);
     # a figure collected for ANOTHER kernels.hip.h / engine.hip is not quoted
@@ -226,14 +224,6 @@ def main():
         kernels={k: dict(us=round(v["us"], 3), GBps=round(v["gbps"], 1), us_event_pair=round(v["us_event_pair"], 3))
                  for k, v in per_launch.items()},
         load_s=round(load_s, 2),
-        carry=dict(RWKV_CARRY=os.environ.get("RWKV_CARRY", "default: off in a context with a tile-form class (7B, 14B); row form: 32 KiB per workgroup where rows are 4 KiB, 20 where they are 3 KiB (3B), else off"),
-                   timed_region=dict(found=c_hit, not_found=c_miss, reloaded_after_failed_check=c_rep,
-                                     hit_rate=(round(c_hit / (c_hit + c_miss), 6) if c_hit + c_miss else None)),
-                   note="row-form ring kernels leave the first rows of the next ring kernel in the CU's LDS across the kernel boundary; every "
-                        "carried group is checked against a position-weighted row sum as it is taken and re-loaded from memory if the check "
-                        "fails (DESIGN.md 4.5).  timed_region = workgroup launches of the TIMED decode that found / did not find their rows "
-                        "(one counter word per workgroup; all zero when the carry is off).  The carry changes no result (bit-identical logits "
-                        "with RWKV_CARRY=0, tests/test_engine_gpu.py); measured this round: +1 % at 3B, +-0 in row form at 7B"),
         hbm_resident_bytes=dict(total=m.resident_bytes(), weight_bytes_one_copy=13 * L * D * D + mf.VOCAB * D,
                                 note="device bytes of this context: weights + row-sum tables + embedding + state + scratch.  The matrices of a decode "
                                      "kernel class are resident in the ONE layout its kernel streams: the tile image (csrc/tile.hip.h) for the classes in "
@@ -384,6 +374,61 @@ def parity_failures(node, path=""):
     return out
 
 
+def pipeline_line(*, model, L, D, world, steps, warmup, dt, one_steps, dt1, per_stage, layer_ranges, transport, hop, parity, cpu, prefill,
+                  native_note, tinfo, resident, per_launch):
+    """The JSON line of the N > 1 run from what the ranks measured: a PURE function (no GPU, no torch.distributed), so that a CPU test can
+    feed it synthetic per-rank results for N = 2 / 4 / 8 -- the one hardware run must not be lost to a field typo (tests/test_bench_cpu.py).
+    dt: seconds of `steps` ticks with `world` streams in flight; dt1: seconds of `one_steps` tokens of ONE stream; per_stage: achieved GB/s of
+    every rank's stage; resident: device bytes of every rank's context; per_launch: traffic_lookup() per decode kernel class."""
+    from rwkv_cpp_accelerated_amd import modelfile as mf
+    B_tok = mf.bytes_per_token(L, D)
+    tok_s = world * steps / dt
+    worst = min(per_stage)
+    # counter-measured HBM read bytes of ONE token through the quoted stage (its layers' four launches + the head on the last stage),
+    # from the per-launch FETCH_SIZE figures of the committed PMC pass for this model and these sources; None if there is none
+    qs = per_stage.index(worst)
+    ql0, ql1 = layer_ranges[qs]
+    if all(v.get("traffic") is not None for v in per_launch.values()):
+        stage_traffic = (ql1 - ql0) * sum(per_launch[k]["traffic"] for k in ("att_kvr_wkv", "att_out", "ffn_rk", "ffn_v")) + (per_launch["head"]["traffic"] if qs == world - 1 else 0)
+        stage_alg = (ql1 - ql0) * 13 * D * D + (mf.VOCAB * D if qs == world - 1 else 0)
+        traffic_note = dict(traffic=int(stage_traffic), traffic_unit="HBM read bytes per token through the quoted stage", algorithmic_weight_bytes=int(stage_alg),
+                            traffic_source=per_launch["ffn_rk"]["traffic_source"])
+    else:
+        traffic_note = dict(traffic=None, traffic_source=per_launch["ffn_rk"].get("traffic_source"))
+    one_tok_s = one_steps / dt1
+    return dict(
+        metric=f"tokens/sec RWKV-4 uint8 greedy decode, layers pipelined over {world} GPUs, AGGREGATE of {world} streams in flight (one per stage); "
+               "one_stream.tokens_per_s is the single-stream rate on the same pipeline",
+        value=round(tok_s, 2), unit="tokens/s",
+        n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(1e3 * dt / steps, 5),
+        higher_is_better=True, scaling="weak", vs_baseline=None,
+        dtype="u8 weights x 23-bit fixed-point activations, exact 32-bit integer accumulate (v_dot4 on the VALU: i32_i8 on signed limbs in tile form, u32_u8 in row form); f32/f64 epilogues, f64 state",
+        data="synthetic",
+        config=dict(workload=f"RWKV-4-Raven-{model} uint8 greedy decode (L={L}, D={D}), layers pipelined over {world} GPUs, "
+                             f"{world} independent streams in flight (one per stage), {steps} tokens per stream",
+                    parallelism=f"pp{world}: layer pipeline, {transport} (f64[{D}] between stages, greedy id fed back last->first stage)",
+                    layer_ranges=layer_ranges, bytes_per_token=B_tok),
+        roofline=dict(bound="hbm", kernel="stage (all decode kernels of a rank's layers)", achieved=worst, peak=HBM_PEAK_GBPS, unit="GB/s",
+                      frac=round(worst / HBM_PEAK_GBPS, 4), **traffic_note, quoted_stage=qs, per_stage_GBps=per_stage,
+                      method="algorithmic bytes of the stage's layers per token x tokens through the stage / wall time of the timed region; "
+                             "the slowest stage is quoted"),
+        end_to_end=dict(achieved_GBps=round(B_tok * tok_s / 1e9, 1), frac_of_aggregate_peak=round(B_tok * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)),
+        per_stream_tokens_per_s=round(steps / dt, 2),
+        # north_star: "tokens/sec ... at 1 GPU and -- pipelined -- at 2/4/8 GPUs as absolute numbers and as achieved fraction of the HBM-read roofline":
+        # ONE stream through the N stages reads every weight byte of the model once per token whichever GPU holds it, so its roofline is ONE GPU's
+        one_stream=dict(tokens_per_s=round(one_tok_s, 2), ms_per_token=round(1e3 * dt1 / one_steps, 5), steps=one_steps,
+                        achieved_GBps=round(B_tok * one_tok_s / 1e9, 1), frac_of_8TBps=round(B_tok * one_tok_s / 1e9 / HBM_PEAK_GBPS, 4),
+                        roofline_tokens_per_s=round(HBM_PEAK_GBPS * 1e9 / B_tok, 1),
+                        note=f"ONE stream in flight through the {world} stages (rwkv_pipe_decode_streams, n_streams = 1): "
+                             "t_tok(1 GPU) + (N - 1) hops + the fed-back id per token (SURVEY 8e); N - 1 GPUs idle at any time; "
+                             "frac_of_8TBps = fraction of ONE GPU's HBM-read roofline (every weight byte is read once per token, on the GPU that holds it)"),
+        hbm_resident_bytes=dict(per_rank=[int(b) for b in resident], total=int(sum(resident)),
+                                note="device bytes of every rank's stage context (its layers' matrices in the layout their decode kernels stream, "
+                                     "the embedding on rank 0, the head on the last rank, state for 2 N slots, scratch)"),
+        hop=hop, parity_vs_single_gpu=parity, cpu_baseline=cpu,
+        prefill=prefill, transport_fallback=native_note, transport_info=tinfo)
+
+
 def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     """N > 1 (BASELINE config 4: RWKV-4-Raven-14B by default): the model's layers are pipelined across the N GPUs (stage s = rank s
     holds layers [l0_s, l1_s), stage 0 the embedding, the last stage the head).  The hop is INSIDE the engine: ncclSend / ncclRecv
@@ -511,8 +556,6 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
         hop = dict(per_rank_us=[dict(mean=round(float(v[0]), 2), min=round(float(v[1]), 2), max=round(float(v[2]), 2)) for v in allh],
                    note="hipEvent pair on the rank's engine stream around the tick's ncclGroupStart .. ncclGroupEnd {send x | send id | recv x | recv id}, "
                         f"{hs['n']} ticks with {world} streams in flight; min = the hop itself (the peer's data was waiting), mean includes waiting for the peer")
-    B_tok = mf.bytes_per_token(L, D)
-    tok_s = world * args.steps / dt
     # per-stage roofline: every token of every stream crosses every stage, so stage s streams its share of the bytes
     # world * K times in dt
     mine = torch.tensor([stage.m.bytes_per_token() * world * args.steps / dt / 1e9], device=dev, dtype=torch.float64)
@@ -522,6 +565,8 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
     par_box = [parity]
     dist.broadcast_object_list(par_box, src=world - 1)
     parity = par_box[0]
+    resident = [None] * world
+    dist.all_gather_object(resident, int(stage.m.resident_bytes()))
     prefill = None
     if native and args.prefill_chunks > 0:
         n_tok = 64 * max(args.prefill_chunks, 2 * world)
@@ -545,43 +590,10 @@ def bench_pipeline(args, dist, rank, local_rank, world, L, D, dev):
                  else "torch.distributed P2P ops (Python schedule)" + ("" if native_note is None else " -- FALLBACK: the engine-side RCCL transport did not come up"))
     out = None
     if rank == 0:
-        worst = min(per_stage)
-        # counter-measured HBM read bytes of ONE token through the quoted stage (its layers' four launches + the head on the last stage),
-        # from the per-launch FETCH_SIZE figures of the committed PMC pass for this model and these sources; None if there is none
-        qs = per_stage.index(worst)
-        ql0, ql1 = pipeline.partition_layers(L, world, D)[qs]
-        per_launch = {k: traffic_lookup(args.model, k) for k in ("att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head")}
-        if all(v.get("traffic") is not None for v in per_launch.values()):
-            stage_traffic = (ql1 - ql0) * sum(per_launch[k]["traffic"] for k in ("att_kvr_wkv", "att_out", "ffn_rk", "ffn_v")) + (per_launch["head"]["traffic"] if qs == world - 1 else 0)
-            stage_alg = (ql1 - ql0) * 13 * D * D + (mf.VOCAB * D if qs == world - 1 else 0)
-            traffic_note = dict(traffic=int(stage_traffic), traffic_unit="HBM read bytes per token through the quoted stage", algorithmic_weight_bytes=int(stage_alg),
-                                traffic_source=per_launch["ffn_rk"]["traffic_source"])
-        else:
-            traffic_note = dict(traffic=None, traffic_source=per_launch["ffn_rk"].get("traffic_source"))
-        out = (dict(
-            metric=f"tokens/sec RWKV-4 uint8 greedy decode, layers pipelined over {world} GPUs, AGGREGATE of {world} streams in flight (one per stage); "
-                   "one_stream.tokens_per_s is the single-stream rate on the same pipeline",
-            value=round(tok_s, 2), unit="tokens/s",
-            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 5),
-            higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype="u8 weights x 23-bit fixed-point activations, exact 32-bit integer accumulate (v_dot4 on the VALU: i32_i8 on signed limbs in tile form, u32_u8 in row form); f32/f64 epilogues, f64 state",
-            data="synthetic",
-            config=dict(workload=f"RWKV-4-Raven-{args.model} uint8 greedy decode (L={L}, D={D}), layers pipelined over {world} GPUs, "
-                                 f"{world} independent streams in flight (one per stage), {args.steps} tokens per stream",
-                        parallelism=f"pp{world}: layer pipeline, {transport} (f64[{D}] between stages, greedy id fed back last->first stage)",
-                        layer_ranges=pipeline.partition_layers(L, world, D), bytes_per_token=B_tok),
-            roofline=dict(bound="hbm", kernel="stage (all decode kernels of a rank's layers)", achieved=worst, peak=HBM_PEAK_GBPS, unit="GB/s",
-                          frac=round(worst / HBM_PEAK_GBPS, 4), **traffic_note, quoted_stage=qs, per_stage_GBps=per_stage,
-                          method="algorithmic bytes of the stage's layers per token x tokens through the stage / wall time of the timed region; "
-                                 "the slowest stage is quoted"),
-            end_to_end=dict(achieved_GBps=round(B_tok * tok_s / 1e9, 1), frac_of_aggregate_peak=round(B_tok * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)),
-            per_stream_tokens_per_s=round(args.steps / dt, 2),
-            one_stream=dict(tokens_per_s=round(one_steps / dt1, 2), ms_per_token=round(1e3 * dt1 / one_steps, 5), steps=one_steps,
-                            achieved_GBps=round(B_tok * one_steps / dt1 / 1e9, 1), frac_of_8TBps=round(B_tok * one_steps / dt1 / 1e9 / HBM_PEAK_GBPS, 4),
-                            note=f"ONE stream in flight through the {world} stages (rwkv_pipe_decode_streams, n_streams = 1): "
-                                 "t_tok(1 GPU) + (N - 1) hops + the fed-back id per token (SURVEY 8e); N - 1 GPUs idle at any time"),
-            hop=hop, parity_vs_single_gpu=parity, cpu_baseline=cpu,
-            prefill=prefill, transport_fallback=native_note, transport_info=tinfo))
+        out = pipeline_line(model=args.model, L=L, D=D, world=world, steps=args.steps, warmup=args.warmup, dt=dt, one_steps=one_steps, dt1=dt1,
+                            per_stage=per_stage, layer_ranges=pipeline.partition_layers(L, world, D), transport=transport, hop=hop, parity=parity,
+                            cpu=cpu, prefill=prefill, native_note=native_note, tinfo=tinfo, resident=resident,
+                            per_launch={k: traffic_lookup(args.model, k) for k in ("att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head")})
     # ---- two streams per stage in flight on two communicators: one parity's hop under the other's stage (rwkv_pipe_decode_dual) ----
     # LAST, and under its own watchdog: this schedule has never met real RCCL either; if it hangs, the line measured so far is printed
     # with the leg marked as timed out and the run exits non-zero -- a new leg must not cost the record of the established ones
@@ -654,7 +666,7 @@ def ref_kernel_leg(mf, tensors, L, D, prompt, engine_model, steps, budget_s, B_t
 
 def decode_src_digest():
     """sha256 over the sources that decide what a decode launch reads: the kernels (row form, tile form) AND the engine (grid, ring
-    geometry, which class runs in which form, carry plan)"""
+    geometry, which class runs in which form)"""
     import hashlib
     h = hashlib.sha256()
     for f in ("kernels.hip.h", "tile.hip.h", "engine.hip"):
@@ -815,7 +827,8 @@ def cpu_baseline(pkg, mf, tensors, L, D, prompt, budget_s, engine_model=None):
     import statistics
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    pkg.build.build_oracle()
+    import build_checkers
+    build_checkers.build_oracle()
     import oracle_lib
     usable, quota = USABLE_CPUS if USABLE_CPUS else usable_cpus()
     threads = int(os.environ.get("RWKV_BENCH_CPU_THREADS", usable))

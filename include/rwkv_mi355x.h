@@ -29,9 +29,12 @@ extern "C" {
  * not bump it).  3: rwkv_decode_typical / rwkv_sample_typical take `flags`; the one-launch-token hooks (rwkv_one_launch,
  * rwkv_debug_mega_timeline) are gone; bounded device-side waits report RWKV_E_DEVICE.  4: weight rows carried in LDS that fail
  * their check are re-loaded instead of failing the call (no more "arrived damaged" error); the carry counters are on by default
- * (rwkv_debug_carry_stats).  rwkv_abi_version() returns the value the
+ * (rwkv_debug_carry_stats).  5: the two-communicator pipeline schedule.  6: the weight rows carried in LDS across kernel boundaries
+ * are gone and with them rwkv_debug_carry_stats / rwkv_debug_carry_hits; the stand-alone GEMV entry point rwkv_mm8_one -- a kernel that only the tests launched -- is
+ * replaced by rwkv_debug_launch / rwkv_debug_read / rwkv_debug_write, which run and inspect the PRODUCTION decode kernels one at a time.
+ * rwkv_abi_version() returns the value the
  * library was built with: a binding compares it with the header it was compiled against. */
-#define RWKV_MI355X_ABI_VERSION 5
+#define RWKV_MI355X_ABI_VERSION 6
 int rwkv_abi_version(void);
 
 #define RWKV_VOCAB 50277u /* hard-wired in the reference: rwkv.h:126, rwkv.cu:471,589 */
@@ -156,7 +159,7 @@ int rwkv_sync(rwkv_ctx *ctx);
  *   rwkv_pipe_init       every rank joins (ncclCommInitRank); the rank must match the context's layer range.  The ranks then AGREE,
  *                        over the communicator, on the prefill micro-batch (64 or 32 rows: RWKV_SEQ_ROWS and max_ctx are per-rank
  *                        values) and on n_embed / n_layers / world; a mismatch fails every rank with RWKV_E_ARG.  One line describing
- *                        this rank's end of the transport goes to stderr (RWKV_PIPE_LOG=0: silent)
+ *                        this rank's end of the transport goes to stderr
  *   rwkv_pipe_info       that description as a JSON object: rank, world, layer range, device ordinal, PCI bus id, arch, RCCL version
  *                        code + path of the shared object holding ncclSend, HIP runtime version, agreed prefill rows
  *   rwkv_pipe_decode     greedy decode of `world` independent streams (one per stage in flight, state slot = stream),
@@ -215,13 +218,6 @@ uint64_t rwkv_resident_bytes(const rwkv_ctx *ctx);
  * class's matrices are resident in the one layout its kernel streams (15 at 4096 channels on 256 CUs, 4 at 5120, 0 otherwise;
  * RWKV_TILE=<mask> before the load overrides).  -1 without a loaded model. */
 int rwkv_decode_form(const rwkv_ctx *ctx);
-/* Carry counters since the previous call: out3[0] / out3[1] = workgroup launches of the decode kernels that found /
- * did not find, in their CU's LDS, the first weight rows their predecessor was asked to leave there; out3[2] = carried row groups
- * whose position-weighted checksum failed and that were re-loaded from memory before use (0 unless something else wrote the CU's
- * LDS in between).  One counter word per workgroup, so counting is on whenever the context carries (RWKV_CARRY_COUNT=0: off).
- * rwkv_debug_carry_hits = the first two (ABI 3 entry point). */
-int rwkv_debug_carry_stats(rwkv_ctx *ctx, uint64_t *out3);
-int rwkv_debug_carry_hits(rwkv_ctx *ctx, uint64_t *out2);
 /* Algorithmic HBM bytes of one token (13*L*D^2 + V*D uint8 weight bytes
  * + 168*L*D + 40*D bytes of vectors/state). */
 uint64_t rwkv_bytes_per_token(const rwkv_ctx *ctx);
@@ -244,11 +240,32 @@ int rwkv_profile_batched(rwkv_ctx *ctx, uint64_t token, int reps, double *ms, ui
  * kernel; out receives grid*8*8 stamps of the 100 MHz device wall clock ([workgroup][wave][phase]). */
 int rwkv_debug_timeline(rwkv_ctx *ctx, uint64_t token, unsigned long long *out, uint64_t cap);
 
-/* Standalone launch of the engine's dequant-GEMV on caller-provided device buffers
- * (the kernel behind cudac_mm8_one(), rwkv.cu:297-311): w is FILE layout [N][M] u8 (one layer),
- * x f32[N], r/o f32[N]; y f32[M] is overwritten with x . (w*r + o).  Used by the unit tests. */
-int rwkv_mm8_one(rwkv_ctx *ctx, uint64_t N, uint64_t M, const float *x_dev, const uint8_t *w_dev,
-                 const float *r_dev, const float *o_dev, float *y_dev);
+/* ---- per-kernel parity hooks: the production decode kernels one launch at a time ----
+ * rwkv_debug_launch runs ONE launch of decode kernel class `cls` -- 0 k_first (embedding + ln0, rwkv.cu:513-524; opens the first ln1
+ * site), 1 k_att (ln1, mixatt, mm8_threec, wkv_forward: rwkv.cu:535-545), 2 k_attout (mm8_one att_out + residual, :548-553),
+ * 3 k_ffn_rk (ln2, mixffn, mm8_one ffn_r + sigmoid, mm8_one ffn_k + relu^2, :557-573), 4 k_ffnv (mm8_one<float> ffn_v + blockout,
+ * :574-577), 5 k_head (ln_out + mm8_one head, :585-589), 6 the greedy pick -- of layer `layer`, eagerly, in the form (row / tile) the
+ * context runs that class in, on whatever its buffers hold, and waits for it.  cls 0 also sets the token's control block (token id, state
+ * slot); the other classes take the slot from the last cls-0 call.  A token is 0, then 1..4 per layer, then 5: the launches of the
+ * captured token graph, one at a time, so that a test can read every hand-over between two kernels and check each kernel against the
+ * oracle's piece for it on that kernel's OWN inputs (tests/test_kernels_gpu.py).
+ * rwkv_debug_read / rwkv_debug_write copy an intermediate vector of the decode path to / from host memory (sizes in bytes; n_embed = D,
+ * grid = rwkv_debug_grid() workgroups per launch). */
+enum rwkv_debug_buf {
+    RWKV_DBG_X = 0,        /* f64[D]     residual stream */
+    RWKV_DBG_YBUF = 1,     /* f32[D]     k_att -> k_attout: gated wkv output (rwkv.cu:250, cast to f32 as :290 does) times att_out's scale r[j] */
+    RWKV_DBG_PART_ATT = 2, /* f64[grid]  k_att -> k_attout: per-workgroup partial sums of (gated wkv) * att_out's offset o[j] */
+    RWKV_DBG_PMAX_ATT = 3, /* f32[grid]  k_att -> k_attout: per-workgroup max |YBUF| */
+    RWKV_DBG_HBUF = 4,     /* f32[4 D]   k_ffn_rk -> k_ffnv: relu(k)^2 (rwkv.cu:189-190) times ffn_v's scale r[j] */
+    RWKV_DBG_RGATE = 5,    /* f32[D]     k_ffn_rk -> k_ffnv: sigmoid(r) (rwkv.cu:212) */
+    RWKV_DBG_PART_FFN = 6, /* f64[grid]  k_ffn_rk -> k_ffnv: per-workgroup partial sums of relu(k)^2 * ffn_v's offset o[j] */
+    RWKV_DBG_PMAX_FFN = 7, /* f32[grid]  k_ffn_rk -> k_ffnv: per-workgroup max |HBUF| */
+    RWKV_DBG_LNSTAT = 8    /* f64[3][2]  mean, rstd of the last ln1 / ln2 / ln_out site */
+};
+int rwkv_debug_launch(rwkv_ctx *ctx, int cls, uint64_t layer, uint64_t token, uint32_t slot);
+int rwkv_debug_read(rwkv_ctx *ctx, int which, void *dst, uint64_t cap_bytes);
+int rwkv_debug_write(rwkv_ctx *ctx, int which, const void *src, uint64_t bytes);
+uint64_t rwkv_debug_grid(const rwkv_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -146,6 +146,7 @@ struct Pipe {
     double *xin[2] = {nullptr, nullptr}, *xout[2] = {nullptr, nullptr};
     unsigned long long *idbuf[2] = {nullptr, nullptr};
     hipEvent_t ev_rx[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
+    bool dual_ready = false;     // every resource of the two-communicator schedule AND comm2 exist (pipe_dual_setup)
     uint64_t ch = 0;             // rows per prefill micro-batch every rank of this pipeline agreed on (rwkv_pipe_init)
     std::string info;            // one JSON object describing this rank's end of the transport (rwkv_pipe_info)
 };
@@ -175,23 +176,12 @@ struct rwkv_ctx {
     uint64_t l0 = 0, l1 = UINT64_MAX;   // pipeline stage: this context owns layers [l0, l1) (whole model by default)
     int S = 0;               // ceil(D / 1024): 1 KiB row pieces per lane
     int seq_rows = SEQ_TM;   // chunk path: rows per weight pass, 64 (two halves, round 4) or 32 (env RWKV_SEQ_ROWS)
-    int seq_small = 8;       // chunk path, passes of <= 32 rows (default: ffn_v only, 3.36 -> 3.30 ms per 7B chunk; K/V/R loses, att_out and ffn k/r +-0: profiles/r04/seq_small_ab.txt): GEMM kinds whose activation image is staged per 2 (ffn_v: 4) k-blocks into alternating LDS
-                             // buffers instead of per slice, so that the first MFMA does not wait for the whole slice's image (env RWKV_SEQ_SMALL)
     int seq_b = -1;          // 64-row passes: GEMM kinds (bit 0 K/V/R, bit 2 ffn k/r) that run as k_seq_gemm_b -- one vector's image of the whole slice resident,
                              // a wave's tiles in batches, one round of workgroups (env RWKV_SEQ_B; 0: k_seq_gemm_p<.., true, 2>; -1: ffn k/r always, K/V/R at D >= 4096:
                              // +1-2 % there, -1.5 % at D = 2048, profiles/r04/gemm_b_ab2.txt)
-    int seq_pipe = 15;       // chunk path: GEMM kinds (bit 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v) that run as k_seq_gemm_p (env RWKV_SEQ_PIPE)
-    int carry_kib = -1;      // ring kernels: KiB of the NEXT ring kernel's rows a workgroup's loader leaves in LDS (kernels.hip.h "CARRY"; env RWKV_CARRY, 0 = off;
-                             // default: where it pays -- 32 at 4 KiB rows (7B: +1.3 %), 20 at 3 KiB rows (3B: +3.3 %; 32: -0.7 %) -- else 0 (14B: -2.2 %;
-                             // profiles/r03/carry.txt))
-    int carry_edges = 15;    //   which boundaries, by CONSUMER: bit 0 into k_ffn_rk, 1 into k_ffnv, 2 into k_att (of the next layer), 3 into k_attout (env RWKV_CARRY_EDGES)
-    unsigned nonce[2] = {0u, 0u};   //   stamp of this context's carried rows
-    bool carry_active = true;       //   this context is the only one of the process on its device (carry_policy)
-    unsigned carry_epoch = 0u;      //   g_ctx_epoch when that was last looked at
-    unsigned *carry_hits = nullptr; //   debug counters (env RWKV_CARRY_COUNT=1; rwkv_debug_carry_hits)
     int tile = -1;           // decode kernel classes that run in TILE form (tile.hip.h; bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv; env RWKV_TILE; -1 = auto: 15 where a
                              // workgroup owns exactly one 16-channel block -- D = 4096 on 256 CUs --, else 0).  15: the context holds ONLY the tile image of the per-layer
-                             // matrices; a partial mask keeps both layouts (tuning); tile form turns the row-form loaders' carry off
+                             // matrices; a partial mask keeps both layouts (tuning)
     int ring = RWKV_RING;    // decode kernels that stream their weights through the LDS ring (bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv, 4 k_head; env RWKV_RING)
 
     // weights (device)
@@ -212,7 +202,6 @@ struct rwkv_ctx {
     double *lnstat = nullptr;                         // [3][2] mean, rstd per site
     uint8_t *w_kvr = nullptr, *w_att = nullptr, *w_frk = nullptr, *w_fv = nullptr, *w_head = nullptr;
     unsigned *rs_kvr = nullptr, *rs_att = nullptr, *rs_frk = nullptr, *rs_fv = nullptr, *rs_head = nullptr;   // row sums
-    unsigned *rw_kvr = nullptr, *rw_att = nullptr, *rw_frk = nullptr, *rw_fv = nullptr;                       // position-weighted row sums (kernels.hip.h carry_verify)
     // state + scratch (device)
     double *state[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double *x = nullptr, *partA = nullptr, *partF = nullptr;
@@ -245,6 +234,7 @@ struct rwkv_ctx {
     struct SeqGraphKey { uint64_t la, lb, row0; int buf, n; bool operator<(const SeqGraphKey &o) const { return std::tie(la, lb, row0, buf, n) < std::tie(o.la, o.lb, o.row0, o.buf, o.n); } };
     std::map<SeqGraphKey, hipGraphExec_t> sq_graphs;
     bool seq_graph = true;
+    int graphs = 3;                               // env RWKV_GRAPH: bit 0 = a decode token is a hipGraph replay, bit 1 = so is a GPT-mode pass of the chunk path (0: direct launches)
     double *sq_x[4] = {nullptr, nullptr, nullptr, nullptr};   // residual stream [SEQ_T][D]; two buffers: a pipeline stage receives chunk c + 1 while chunk c is sent on; [2], [3]: more chunks in flight in rwkv_forward's pipeline
     hipEvent_t xs_ev[2] = {nullptr, nullptr};     // rwkv_xseq_copy: "source chunk done" / "copied"
     // long prompts on one GPU: the chunk path as a two-stage software pipeline (layers [l0, mid) on `stream`, [mid, l1) + head on
@@ -306,11 +296,9 @@ int ring_slots(size_t fixed, int, int S)
     return (int)((LDS_BYTES - fixed - sizeof(GldsCtl)) / ((size_t)S * 1024));
 }
 size_t smem_ring(size_t fixed, int R, int S) { return fixed + sizeof(GldsCtl) + (size_t)ring_slots(fixed, R, S) * S * 1024; }
-// k_att / k_ffn_rk / k_ffnv in ring form: [scratch][control block][ring][nv staged vectors]; `common`: the geometry all three share
-// when rows are carried across their boundaries (sized for k_ffnv's four vectors)
-int ring_units(int nv, int S, bool common) { return (int)((LDS_BYTES - RED_BYTES - sizeof(GldsCtl) - (size_t)(common ? 4 : nv) * S * 3072) / ((size_t)S * 1024)); }
-int ring_xq_bytes(int nv, int S, bool common) { return (common ? 4 : nv) * S * 3072; }
-size_t smem_ring3(int nv, int S, bool common) { return RED_BYTES + (size_t)ring_xq_bytes(nv, S, common) + sizeof(GldsCtl) + (size_t)ring_units(nv, S, common) * S * 1024; }
+// k_att / k_ffn_rk / k_ffnv in ring form: [scratch][nv staged vectors][control block][ring]
+int ring_units(int nv, int S) { return (int)((LDS_BYTES - RED_BYTES - sizeof(GldsCtl) - (size_t)nv * S * 3072) / ((size_t)S * 1024)); }
+size_t smem_ring3(int nv, int S) { return RED_BYTES + (size_t)nv * S * 3072 + sizeof(GldsCtl) + (size_t)ring_units(nv, S) * S * 1024; }
 
 // tile-form decode kernels (tile.hip.h; classes 1 att, 2 att_out, 3 ffn_rk, 4 ffn_v): ring of S KiB units behind each kernel's fixed LDS.
 // Which widths have a tile form: those whose channels split into whole TH-row tiles per workgroup on this grid --
@@ -384,99 +372,13 @@ template <typename K> int allow_smem(K kernel, size_t bytes)
 }
 
 
-// ---- argument blocks of the decode kernels (shared by the per-class launches and the one-launch token) ----
+// ---- argument blocks of the decode kernels ----
 // (the stage's first ln1 site is opened by k_first's few workgroups, every other site by the full grid)
 struct ArgMaker {
     rwkv_ctx *c;
     int D, grid, n_first;
     size_t LD;
-    bool chain;      // profiling batches: launches of ONE class, layer after layer (each carries rows for the same class of the next layer)
-    bool common;     // the ring kernels share one ring geometry: rows are carried across their boundaries (kernels.hip.h "CARRY")
-    explicit ArgMaker(rwkv_ctx *c_, bool chain_ = false) : c(c_), D((int)c_->D), grid(c_->grid), LD((size_t)c_->L * c_->D), chain(chain_)
-    {
-        n_first = grid < 32 ? grid : 32;
-        common = c->carry_kib > 0 && c->carry_active && c->carry_edges != 0 && D % grid == 0 && D / grid >= 2 && (c->ring & 13) != 0;
-    }
-    // ---- the carry plan: who streams the first rows of whom.  Ring kernels of a layer in launch order: 1 k_att, 2 k_attout (only when
-    // it is on the ring), 3 k_ffn_rk, 4 k_ffnv; a k_attout in register form is stepped over (it stays below the ring's LDS) ----
-    static int rows_of(int cls) { return cls == 1 ? 3 : cls == 2 ? ATTOUT_R : cls == 3 ? 5 : 4; }
-    static int nv_of(int cls) { return cls == 1 ? 3 : cls == 2 ? 1 : cls == 3 ? 2 : 4; }
-    int groups_of(int cls) const { return cls == 2 ? D / ATTOUT_R : D; }               // groups the class splits over the workgroups
-    bool ring_cls(int cls) const
-    {
-        if (cls == 2) return (c->ring & 2) != 0 && D % (ATTOUT_R * grid) == 0;
-        return cls == 1 ? (c->ring & 1) != 0 : cls == 3 ? (c->ring & 4) != 0 : cls == 4 ? (c->ring & 8) != 0 : false;
-    }
-    static int edge_bit(int to_cls) { return to_cls == 3 ? 1 : to_cls == 4 ? 2 : to_cls == 1 ? 4 : 8; }      // RWKV_CARRY_EDGES: by consumer
-    int units() const { return ring_units(0, c->S, true); }
-    // the ring kernel that runs behind (cls, l) and takes rows from it
-    bool next_of(int cls, uint64_t l, bool as_chain, int &cls2, uint64_t &l2) const
-    {
-        if (!common || !ring_cls(cls)) return false;
-        if (as_chain) { cls2 = cls; l2 = l + 1; }
-        else if (cls == 1) { cls2 = (c->ring & 2) ? 2 : 3; l2 = l; }
-        else if (cls == 2) { cls2 = 3; l2 = l; }
-        else if (cls == 3) { cls2 = 4; l2 = l; }
-        else { cls2 = 1; l2 = l + 1; }
-        return (c->carry_edges & edge_bit(cls2)) && l2 < c->l1 && ring_cls(cls2);
-    }
-    bool prev_of(int cls, uint64_t l, bool as_chain, int &cls0, uint64_t &l0_) const
-    {
-        if (!common || !ring_cls(cls)) return false;
-        if (as_chain) { cls0 = cls; l0_ = l - 1; }
-        else if (cls == 1) { cls0 = 4; l0_ = l - 1; }
-        else if (cls == 2) { cls0 = 1; l0_ = l; }
-        else if (cls == 3) { cls0 = (c->ring & 2) ? 2 : 1; l0_ = l; }
-        else { cls0 = 3; l0_ = l; }
-        if ((cls0 == 4 || as_chain) && l == c->l0) return false;
-        int cb; uint64_t lb;
-        return next_of(cls0, l0_, as_chain, cb, lb) && cb == cls && lb == l;
-    }
-    int carry_groups(int cls) const      // groups of class `cls` that travel: ~carry_kib, at least one, at most half a workgroup's share and half the ring
-    {
-        const int per = rows_of(cls) * c->S, G = groups_of(cls) / grid;
-        int n = (c->carry_kib + per / 2) / per;
-        n = std::max(n, 1);
-        n = std::min(n, std::min(G / 2, units() / (2 * rows_of(cls))));
-        n = std::min(n, GLDS_FQ / 2);            // RingLoader::adopt books them in gend[] / freeq[] (GLDS_FQ entries)
-        n = std::min(n, 64 / nrs_of(cls));       // their expected sums travel in GldsCtl::csum (64 words)
-        return std::max(n, 0);
-    }
-    static int nrs_of(int cls) { return cls == 1 ? 3 : cls == 2 ? ATTOUT_R : cls == 3 ? 5 : 1; }      // words of the position-weighted sum table per group
-    const unsigned *sums_of(int cls, uint64_t l) const
-    {
-        const size_t lr = (size_t)(l - c->l0);
-        return cls == 1 ? c->rw_kvr + lr * 3 * D : cls == 2 ? c->rw_att + lr * D : cls == 3 ? c->rw_frk + lr * 5 * D : c->rw_fv + lr * D;
-    }
-    const uint8_t *weights_of(int cls, uint64_t l) const
-    {
-        const size_t lr = (size_t)(l - c->l0);
-        return cls == 1 ? c->w_kvr + lr * 3 * D * D : cls == 2 ? c->w_att + lr * D * D : cls == 3 ? c->w_frk + lr * 5 * D * D : c->w_fv + lr * 4 * D * D;
-    }
-    RingCarry carry(int cls, uint64_t l) const
-    {
-        RingCarry cy{};
-        cy.xq_bytes = ring_xq_bytes(nv_of(cls), c->S, common);
-        cy.hits = c->carry_hits;
-        if (!common) return cy;
-        const int Gw = D / grid, nu = units();                        // rows per workgroup of a D-row matrix
-        const uint64_t lr = l - c->l0;
-        const int ao = ring_cls(2) ? Gw : 0;                            // units per workgroup: k_att 3 Gw, k_attout Gw, k_ffn_rk 5 Gw, k_ffnv 4 Gw
-        const uint64_t own = (uint64_t)Gw * (cls == 1 ? 3 : cls == 2 ? 1 : cls == 3 ? 5 : 4);
-        const uint64_t before = chain ? lr * own : lr * (uint64_t)(12 * Gw + ao) + (cls == 1 ? 0 : cls == 2 ? 3 * Gw : cls == 3 ? 3 * Gw + ao : 8 * Gw + ao);
-        cy.pos0 = (int)(before % (uint64_t)nu);
-        int c2; uint64_t l2;
-        if (next_of(cls, l, chain, c2, l2) && carry_groups(c2) > 0) {
-            cy.w_next = weights_of(c2, l2); cy.rows_next = rows_of(c2); cy.n_out = carry_groups(c2); cy.groups_next = groups_of(c2);
-            cy.tag_out[0] = c->nonce[0]; cy.tag_out[1] = c->nonce[1] ^ (unsigned)(l2 * 8 + (uint64_t)c2);
-            cy.rw_next = sums_of(c2, l2); cy.nrs_next = nrs_of(c2);
-        }
-        if (prev_of(cls, l, chain, c2, l2) && carry_groups(cls) > 0) {
-            cy.n_in = carry_groups(cls);
-            cy.tag_in[0] = c->nonce[0]; cy.tag_in[1] = c->nonce[1] ^ (unsigned)(l * 8 + (uint64_t)cls);
-        }
-        return cy;
-    }
+    explicit ArgMaker(rwkv_ctx *c_) : c(c_), D((int)c_->D), grid(c_->grid), LD((size_t)c_->L * c_->D) { n_first = grid < 32 ? grid : 32; }
     unsigned long long *tl_of(int k, uint64_t l) const { return (c->tl_on && k == c->tl_cls && l == (c->l0 + c->l1) / 2) ? c->tl : nullptr; }
     SiteStatic site_static(int k, uint64_t ll) const
     {
@@ -505,22 +407,22 @@ struct ArgMaker {
         const size_t lo = (size_t)l * D;
         AttArgs aa;
         aa.x = c->x; aa.st = site_static(0, l); aa.dy = site_dyn(0, l == c->l0 ? n_first : grid);
-        aa.w = c->w_kvr ? c->w_kvr + (size_t)(l - c->l0) * 3 * D * D : nullptr; aa.rs = c->rs_kvr + (size_t)(l - c->l0) * D * 3; aa.rw = c->rw_kvr ? c->rw_kvr + (size_t)(l - c->l0) * D * 3 : nullptr;
+        aa.w = c->w_kvr ? c->w_kvr + (size_t)(l - c->l0) * 3 * D * D : nullptr; aa.rs = c->rs_kvr + (size_t)(l - c->l0) * D * 3;
         aa.uw = c->uw + lo; aa.ew = c->ew + lo;
         aa.r_att = c->attr + lo; aa.o_att = c->atto + lo;
         aa.saa = c->state[1] + lo; aa.sbb = c->state[2] + lo;
         aa.slot_stride = LD; aa.ybuf = c->ybuf; aa.partS = c->partA; aa.partM = c->partMA;
-        aa.ctl = c->ctl; aa.D = D; aa.ns = 0; aa.tl = tl_of(1, l); aa.herr = c->d_herr; aa.cy = carry(1, l);
+        aa.ctl = c->ctl; aa.D = D; aa.ns = 0; aa.tl = tl_of(1, l); aa.herr = c->d_herr;
         return aa;
     }
     AttOutArgs attout(uint64_t l) const
     {
         const size_t lo = (size_t)l * D;
         AttOutArgs ao;
-        ao.w = c->w_att ? c->w_att + (size_t)(l - c->l0) * D * D : nullptr; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.rw = c->rw_att ? c->rw_att + (size_t)(l - c->l0) * D : nullptr; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
+        ao.w = c->w_att ? c->w_att + (size_t)(l - c->l0) * D * D : nullptr; ao.rs = c->rs_att + (size_t)(l - c->l0) * D; ao.ybuf = c->ybuf; ao.partS = c->partA; ao.partM = c->partMA; ao.n_part = grid;
         ao.x = c->x; ao.lnw = c->ln + (4 * l + 2) * D; ao.lnb = c->ln + (4 * l + 3) * D; ao.lnstat = c->lnstat + 0;
         ao.sxy = c->state[0] + lo; ao.st = site_static(1, l); ao.dy = site_dyn(1, grid); ao.sdd = c->state[4] + lo;
-        ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.ns = 0; ao.tl = tl_of(2, l); ao.herr = c->d_herr; ao.cy = carry(2, l);
+        ao.slot_stride = LD; ao.ctl = c->ctl; ao.D = D; ao.ns = 0; ao.tl = tl_of(2, l); ao.herr = c->d_herr;
         return ao;
     }
     FfnRKArgs frk(uint64_t l) const
@@ -528,10 +430,10 @@ struct ArgMaker {
         const size_t lo = (size_t)l * D;
         FfnRKArgs fa;
         fa.x = c->x; fa.st = site_static(1, l); fa.dy = site_dyn(1, grid);
-        fa.w = c->w_frk ? c->w_frk + (size_t)(l - c->l0) * 5 * D * D : nullptr; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5; fa.rw = c->rw_frk ? c->rw_frk + (size_t)(l - c->l0) * D * 5 : nullptr;
+        fa.w = c->w_frk ? c->w_frk + (size_t)(l - c->l0) * 5 * D * D : nullptr; fa.rs = c->rs_frk + (size_t)(l - c->l0) * D * 5;
         fa.r_fv = c->fvr + 4 * lo; fa.o_fv = c->fvo + 4 * lo;
         fa.hbuf = c->hbuf; fa.rgate = c->rgate; fa.partS = c->partF; fa.partM = c->partMF; fa.ctl = c->ctl; fa.D = D;
-        fa.ns = 0; fa.tl = tl_of(3, l); fa.herr = c->d_herr; fa.cy = carry(3, l);
+        fa.ns = 0; fa.tl = tl_of(3, l); fa.herr = c->d_herr;
         return fa;
     }
     // the site ffn_v opens: ln1 of layer l + 1 (3 vectors), or ln_out -> head after the stage's last layer (on a non-final
@@ -541,10 +443,10 @@ struct ArgMaker {
     {
         const size_t lo = (size_t)l * D;
         FfnVArgs fv;
-        fv.w = c->w_fv ? c->w_fv + (size_t)(l - c->l0) * 4 * D * D : nullptr; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.rw = c->rw_fv ? c->rw_fv + (size_t)(l - c->l0) * D : nullptr; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
+        fv.w = c->w_fv ? c->w_fv + (size_t)(l - c->l0) * 4 * D * D : nullptr; fv.rs = c->rs_fv + (size_t)(l - c->l0) * D; fv.hbuf = c->hbuf; fv.partS = c->partF; fv.partM = c->partMF; fv.n_part = grid;
         fv.rgate = c->rgate; fv.x = c->x; fv.lnw = c->ln + (4 * l + 4) * D; fv.lnb = c->ln + (4 * l + 5) * D; fv.lnstat = c->lnstat + 2;
         fv.sdd = c->state[4] + lo; fv.slot_stride = LD; fv.ctl = c->ctl; fv.D = D; fv.tl = tl_of(4, l);
-        fv.ns = 0; fv.herr = c->d_herr; fv.cy = carry(4, l);
+        fv.ns = 0; fv.herr = c->d_herr;
         if (fv_next_att(l)) { fv.st = site_static(0, l + 1); fv.dy = site_dyn(0, grid); fv.sprev = c->state[0] + lo + D; }
         else { fv.st = site_static(2, 0); fv.dy = site_dyn(2, grid); fv.sprev = nullptr; }
         return fv;
@@ -559,10 +461,10 @@ struct ArgMaker {
 };
 
 // ---- one launch helper per kernel class (0 embed, 1 att, 2 att_out, 3 ffn_rk, 4 ffn_v, 5 head, 6 argmax) ----
-void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
+void launch_class(rwkv_ctx *c, int cls, uint64_t l)
 {
     const int S = c->S, grid = c->grid;
-    const ArgMaker mk(c, chain);
+    const ArgMaker mk(c);
     switch (cls) {
     case 0: {
         FirstArgs fa = mk.first();
@@ -572,7 +474,7 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
         AttArgs aa = mk.att(l);
         if (tile_ok(c, 1)) {
             AttTArgs ta;
-            ta.a = aa; ta.a.ns = tile_units(c, 1); ta.a.cy = RingCarry{};
+            ta.a = aa; ta.a.ns = tile_units(c, 1);
             ta.im.CB = mk.D / c->tile_th; ta.im.bimg = c->t_kvr + (size_t)(l - c->l0) * 3 * (size_t)mk.D * mk.D;
             const size_t sm = tile_smem(c, 1);
             TILE_DISPATCH(c, (k_att_t<4, 4, 64, 16, 1><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
@@ -580,9 +482,8 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
                           (k_att_t<2, 4, 8, 4, 2><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)));
         }
         else if (c->ring & 1) {
-            aa.ns = ring_units(3, S, mk.common);
-            if (mk.common) DISPATCH_S(S, k_att<S_, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(3, S, true), c->stream>>>(aa))
-            else DISPATCH_S(S, k_att<S_, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(3, S, false), c->stream>>>(aa));
+            aa.ns = ring_units(3, S);
+            DISPATCH_S(S, k_att<S_, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(3, S), c->stream>>>(aa));
         }
         else DISPATCH_S(S, k_att<S_, nb_att(S_)><<<dim3(grid), dim3(NT), smem_att(S), c->stream>>>(aa));
     } break;
@@ -590,16 +491,12 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
         AttOutArgs ao = mk.attout(l);
         if (tile_ok(c, 2)) {
             AttOutTArgs ta;
-            ta.a = ao; ta.a.ns = tile_units(c, 2); ta.a.cy = RingCarry{};
+            ta.a = ao; ta.a.ns = tile_units(c, 2);
             ta.im.CB = mk.D / c->tile_th; ta.im.bimg = c->t_att + (size_t)(l - c->l0) * (size_t)mk.D * mk.D;
             const size_t sm = tile_smem(c, 2);
             TILE_DISPATCH(c, (k_attout_t<4, 4, 64, 16, 1><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
                           (k_attout_t<5, 5, 20, 4, 5><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
                           (k_attout_t<2, 4, 8, 4, 2><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)));
-        }
-        else if ((c->ring & 2) && mk.common && mk.ring_cls(2)) {
-            ao.ns = ring_units(1, S, true);
-            DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(1, S, true), c->stream>>>(ao));
         }
         else if (c->ring & 2) { ao.ns = ring_slots(smem_attout(S), ATTOUT_R, S); DISPATCH_S(S, k_attout<S_, ATTOUT_R, 1, 1><<<dim3(grid), dim3(NT), smem_ring(smem_attout(S), ATTOUT_R, S), c->stream>>>(ao)); }
         else DISPATCH_S(S, k_attout<S_, ATTOUT_R, nb_attout(S_)><<<dim3(grid), dim3(NT), smem_attout(S), c->stream>>>(ao));
@@ -608,7 +505,7 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
         FfnRKArgs fa = mk.frk(l);
         if (tile_ok(c, 3)) {
             FfnRKTArgs ta;
-            ta.a = fa; ta.a.ns = tile_units(c, 3); ta.a.cy = RingCarry{};
+            ta.a = fa; ta.a.ns = tile_units(c, 3);
             ta.im.CB = mk.D / c->tile_th; ta.im.bimg = c->t_frk + (size_t)(l - c->l0) * 5 * (size_t)mk.D * mk.D;
             const size_t sm = tile_smem(c, 3);
             TILE_DISPATCH(c, (k_ffn_rk_t<4, 4, 64, 16, 1><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)),
@@ -616,18 +513,17 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
                           (k_ffn_rk_t<2, 4, 8, 4, 2><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)));
         }
         else if (c->ring & 4) {
-            fa.ns = ring_units(2, S, mk.common);
-            if (mk.common) DISPATCH_S(S, k_ffn_rk<S_, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(2, S, true), c->stream>>>(fa))
-            else DISPATCH_S(S, k_ffn_rk<S_, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(2, S, false), c->stream>>>(fa));
+            fa.ns = ring_units(2, S);
+            DISPATCH_S(S, k_ffn_rk<S_, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(2, S), c->stream>>>(fa));
         }
         else DISPATCH_S(S, k_ffn_rk<S_, nb_frk(S_)><<<dim3(grid), dim3(NT), smem_frk(S), c->stream>>>(fa));
     } break;
     case 4: {
         FfnVArgs fv = mk.fv(l);
-        fv.ns = ring_units(4, S, mk.common);
+        fv.ns = ring_units(4, S);
         if (tile_ok(c, 4)) {
             FfnVTArgs ta;
-            ta.a = fv; ta.a.ns = tile_units(c, 4); ta.a.cy = RingCarry{};
+            ta.a = fv; ta.a.ns = tile_units(c, 4);
             ta.im.CB = mk.D / c->tile_th; ta.im.bimg = c->t_fv + (size_t)(l - c->l0) * 4 * (size_t)mk.D * mk.D;
             const size_t sm = tile_smem(c, 4);
             if (mk.fv_next_att(l))
@@ -640,16 +536,10 @@ void launch_class(rwkv_ctx *c, int cls, uint64_t l, bool chain = false)
                               (k_ffnv_t<2, 4, 32, 4, 2, 1><<<dim3(grid), dim3(NT), sm, c->stream>>>(ta)));
         }
         else if (mk.fv_next_att(l)) {
-            if (c->ring & 8) {
-                if (mk.common) DISPATCH_S(S, k_ffnv<S_, 3, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(4, S, true), c->stream>>>(fv))
-                else DISPATCH_S(S, k_ffnv<S_, 3, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(4, S, false), c->stream>>>(fv));
-            }
+            if (c->ring & 8) DISPATCH_S(S, k_ffnv<S_, 3, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(4, S), c->stream>>>(fv))
             else DISPATCH_S(S, k_ffnv<S_, 3, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
         } else {
-            if (c->ring & 8) {
-                if (mk.common) DISPATCH_S(S, k_ffnv<S_, 1, 1, 2><<<dim3(grid), dim3(NT), smem_ring3(4, S, true), c->stream>>>(fv))
-                else DISPATCH_S(S, k_ffnv<S_, 1, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(4, S, false), c->stream>>>(fv));
-            }
+            if (c->ring & 8) DISPATCH_S(S, k_ffnv<S_, 1, 1, 1><<<dim3(grid), dim3(NT), smem_ring3(4, S), c->stream>>>(fv))
             else DISPATCH_S(S, k_ffnv<S_, 1, nb_fv(S_)><<<dim3(grid), dim3(NT), smem_fv(S), c->stream>>>(fv));
         }
     } break;
@@ -695,7 +585,6 @@ int enqueue_token(rwkv_ctx *c, bool with_argmax, hipEvent_t *ev)
     return 0;
 }
 
-int carry_policy(rwkv_ctx *c);
 int build_graph(rwkv_ctx *c, bool with_argmax, hipGraphExec_t *out)
 {
     hipGraph_t g = nullptr;
@@ -747,18 +636,11 @@ template <typename T> int upload(rwkv_ctx *c, Source &src, int slot, T **dst)
 int seq_smem_limits()
 {
     int rc = 0;
-#define SEQ_ALLOW(TAG, NTW, NKB, MTS, NVS) if (!rc) rc = allow_smem(k_seq_gemm<TAG, NTW, NKB, MTS, NVS>, seq_gemm_smem(NTW, NKB, MTS, NVS))
-    SEQ_ALLOW(0, 3, 8, false, 3); SEQ_ALLOW(0, 3, 10, false, 2);
-    SEQ_ALLOW(1, 1, 8, false, 1); SEQ_ALLOW(1, 1, 10, false, 1);
-    SEQ_ALLOW(2, 5, 8, true, 2); SEQ_ALLOW(2, 4, 10, true, 2);
-    SEQ_ALLOW(3, 1, 8, false, 1); SEQ_ALLOW(3, 1, 10, false, 1);
-#undef SEQ_ALLOW
 #define SEQ_ALLOW_P(TAG, NTW, NKB, NVS, DEPTH, MULTI) if (!rc) rc = allow_smem(k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI>, seq_gemm_p_smem(NKB, NVS, MULTI))
     SEQ_ALLOW_P(0, 3, 8, 3, RWKV_SEQ_DEPTH0, false); SEQ_ALLOW_P(0, 3, 10, 2, 2, false);
     SEQ_ALLOW_P(1, 1, 8, 1, 8, false); SEQ_ALLOW_P(1, 1, 10, 1, 10, false);
     SEQ_ALLOW_P(2, 5, 8, 2, RWKV_SEQ_DEPTH2, false); SEQ_ALLOW_P(2, 4, 10, 2, 2, false);
-    SEQ_ALLOW_P(3, 1, 8, 1, 8, true); SEQ_ALLOW_P(3, 1, 10, 1, 10, true);
-    SEQ_ALLOW_P(0, 3, 2, 3, 2, true); SEQ_ALLOW_P(1, 1, 2, 1, 2, true); SEQ_ALLOW_P(2, 5, 2, 2, 2, true); SEQ_ALLOW_P(2, 4, 2, 2, 2, true); SEQ_ALLOW_P(3, 1, 4, 1, 4, true);
+    SEQ_ALLOW_P(3, 1, 4, 1, 4, true);
 #undef SEQ_ALLOW_P
 #define SEQ_ALLOW_P2(TAG, NTW, NKB, NVS, DEPTH, MULTI) if (!rc) rc = allow_smem(k_seq_gemm_p<TAG, NTW, NKB, NVS, DEPTH, MULTI, 2>, seq_gemm_p_smem(NKB, NVS, MULTI, 2))
     SEQ_ALLOW_P2(0, 3, 2, 3, 2, true); SEQ_ALLOW_P2(1, 1, 8, 1, 8, false); SEQ_ALLOW_P2(1, 1, 10, 1, 10, false);
@@ -780,16 +662,11 @@ int set_smem_limits(rwkv_ctx *c)
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, nb_fv(S_)>, smem_fv(S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, nb_fv(S_)>, smem_fv(S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_head<S_, nb_head(S_)>, smem_head(S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_att<S_, 1, 1>, smem_ring3(3, S, false))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_att<S_, 1, 2>, smem_ring3(3, S, true))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_att<S_, 1, 1>, smem_ring3(3, S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R, 1, 1>, smem_ring(smem_attout(S), ATTOUT_R, S))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_attout<S_, ATTOUT_R, 1, 2>, smem_ring3(1, S, true))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_, 1, 1>, smem_ring3(2, S, false))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_, 1, 2>, smem_ring3(2, S, true))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, 1, 1>, smem_ring3(4, S, false))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, 1, 2>, smem_ring3(4, S, true))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, 1>, smem_ring3(4, S, false))); if (rc) return rc;
-    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, 2>, smem_ring3(4, S, true))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffn_rk<S_, 1, 1>, smem_ring3(2, S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 3, 1, 1>, smem_ring3(4, S))); if (rc) return rc;
+    DISPATCH_S(S, rc = allow_smem(k_ffnv<S_, 1, 1, 1>, smem_ring3(4, S))); if (rc) return rc;
     DISPATCH_S(S, rc = allow_smem(k_head<S_, 1, 1>, smem_ring(smem_head(S), RWKV_HEAD_RR, S))); if (rc) return rc;
     if (c->tile_th) {
 #define TILE_ALLOW(K16, K45, K42, CLS)                                                                   \
@@ -821,18 +698,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     HIPCHK(hipSetDevice(c->device));
     c->L = L; c->D = D; c->maxT = max_ctx; c->S = (int)((D + 1023) / 1024);
     if (c->ring < 0) c->ring = c->S >= 3 ? 13 : 0;      // (5 KiB rows: k_ffnv joined the ring in round 4, with the early take: 21.4 -> 20.8 us, profiles/r04/early_take_ab.txt)
-    if (c->carry_kib < 0) c->carry_kib = c->S == 4 ? 32 : c->S == 3 ? 20 : 0;
     if (c->l1 == UINT64_MAX) c->l1 = L;
-    {   // carry counters, one set per workgroup (found / not found / groups re-loaded after a failed check): a fire-and-forget atomic on the
-        // workgroup's own word per launch (RWKV_CARRY_COUNT=0: none).  Round 3 counted on ONE word and paid 6 % for it: 256 arrivals on a
-        // word are a 3 us chain of memory-side atomics (profiles/r04/atomicbench.txt)
-        const char *e = getenv("RWKV_CARRY_COUNT");
-        if (!(e && e[0] == '0') && c->carry_kib > 0 && !c->carry_hits) {
-            int rcc = dalloc(c, &c->carry_hits, (size_t)c->grid * 4);
-            if (rcc) return rcc;
-            HIPCHK(hipMemset(c->carry_hits, 0, (size_t)c->grid * 16));
-        }
-    }
     if (c->l0 >= c->l1 || c->l1 > L) return fail(RWKV_E_ARG, "layer range [%llu, %llu) does not fit a %llu-layer model", (unsigned long long)c->l0, (unsigned long long)c->l1, (unsigned long long)L);
     const uint64_t l0 = c->l0, l1 = c->l1, nl = l1 - l0;
     const bool first = l0 == 0, last = l1 == L;
@@ -913,7 +779,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if (c->tile < 0) c->tile = tcfg.th == 16 ? 15 : tcfg.tpc == 5 ? 4 : 0;
     if (tcfg.th == 0) c->tile = 0;
     c->tile &= 15;
-    if (c->tile) { c->carry_kib = 0; c->tile_th = tcfg.th; c->tile_s = tcfg.s; c->tile_tpc = tcfg.tpc; }      // (the row-form loaders' carry has no tile-form counterpart)
+    if (c->tile) { c->tile_th = tcfg.th; c->tile_s = tcfg.s; c->tile_tpc = tcfg.tpc; }
     auto in_tile = [&](int cls) { return ((c->tile >> (cls - 1)) & 1) != 0; };
     const bool own_t = tcfg.th != 16;                         // the decode kernels' tile image is not the chunk path's
     auto need_b = [&](int cls) { return want_seq || (in_tile(cls) && !own_t); };
@@ -927,10 +793,6 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     if (!rc) rc = dalloc(c, &c->rs_frk, nl * 5 * D);
     if (!rc) rc = dalloc(c, &c->rs_fv, nl * D);
     if (!rc) rc = dalloc(c, &c->rs_head, V);
-    if (!rc && !in_tile(1)) rc = dalloc(c, &c->rw_kvr, nl * 3 * D);
-    if (!rc && !in_tile(2)) rc = dalloc(c, &c->rw_att, nl * D);
-    if (!rc && !in_tile(3)) rc = dalloc(c, &c->rw_frk, nl * 5 * D);
-    if (!rc && !in_tile(4)) rc = dalloc(c, &c->rw_fv, nl * D);
     if (rc) return rc;
     // tile images (+ octant row sums for the chunk path): per = bytes of one layer's image
     const uint64_t cbD = (D + 15) / 16;
@@ -956,8 +818,8 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         if (in_tile(3)) c->t_frk = c->b_frk;
         if (in_tile(4)) c->t_fv = c->b_fv;
     }
-    auto rowsum = [&](const uint8_t *w, unsigned *rs, unsigned *rw, uint64_t rows, uint64_t N) {
-        k_rowsum<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream>>>(w, rs, rw, (size_t)rows, (int)N, (int)D);
+    auto rowsum = [&](const uint8_t *w, unsigned *rs, uint64_t rows, uint64_t N) {
+        k_rowsum<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream>>>(w, rs, (size_t)rows, (int)N);
     };
     // one layer's matrix in row form (w_t[N][K]) -> its tile image (and octant row sums)
     auto image = [&](const uint8_t *w_t, uint8_t *bdst, unsigned *r8dst, uint64_t N, uint64_t K, int Q, uint64_t per, int TH = 16) {
@@ -979,14 +841,14 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         if (!rc) rc = retile(c, src, VM, l, D, D, kvr, 1, 3, 1, staging);
         if (!rc) rc = retile(c, src, RM, l, D, D, kvr, 1, 3, 2, staging);
         if (!rc) {
-            rowsum(kvr, c->rs_kvr + lr * 3 * D, in_tile(1) ? nullptr : c->rw_kvr + lr * 3 * D, 3 * D, D);
+            rowsum(kvr, c->rs_kvr + lr * 3 * D, 3 * D, D);
             if (need_b(1)) image(kvr, c->b_kvr + lr * per_kvr, want_seq ? c->r8_kvr + lr * SEQ_O * 3 * D : nullptr, 3 * D, D, 3, per_kvr);
             if (own_t && in_tile(1)) image(kvr, c->t_kvr + lr * 3 * D * D, nullptr, 3 * D, D, 3, 3 * D * D, tcfg.th);
         }
         uint8_t *att = in_tile(2) ? rowtmp : c->w_att + lr * D * D;
         if (!rc) rc = retile(c, src, ATTOUT, l, D, D, att, 1, 1, 0, staging);
         if (!rc) {
-            rowsum(att, c->rs_att + lr * D, in_tile(2) ? nullptr : c->rw_att + lr * D, D, D);
+            rowsum(att, c->rs_att + lr * D, D, D);
             if (need_b(2)) image(att, c->b_att + lr * per_att, want_seq ? c->r8_att + lr * SEQ_O * D : nullptr, D, D, 1, per_att);
             if (own_t && in_tile(2)) image(att, c->t_att + lr * D * D, nullptr, D, D, 1, D * D, tcfg.th);
         }
@@ -994,21 +856,21 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
         if (!rc) rc = retile(c, src, FFNK, l, D, 4 * D, frk, 4, 5, 0, staging);
         if (!rc) rc = retile(c, src, FFNR, l, D, D, frk, 1, 5, 4, staging);
         if (!rc) {
-            rowsum(frk, c->rs_frk + lr * 5 * D, in_tile(3) ? nullptr : c->rw_frk + lr * 5 * D, 5 * D, D);
+            rowsum(frk, c->rs_frk + lr * 5 * D, 5 * D, D);
             if (need_b(3)) image(frk, c->b_frk + lr * per_frk, want_seq ? c->r8_frk + lr * SEQ_O * 5 * D : nullptr, 5 * D, D, 5, per_frk);
             if (own_t && in_tile(3)) image(frk, c->t_frk + lr * 5 * D * D, nullptr, 5 * D, D, 5, 5 * D * D, tcfg.th);
         }
         uint8_t *fvm = in_tile(4) ? rowtmp : c->w_fv + lr * 4 * D * D;
         if (!rc) rc = retile(c, src, FFNV, l, 4 * D, D, fvm, 1, 1, 0, staging);
         if (!rc) {
-            rowsum(fvm, c->rs_fv + lr * D, in_tile(4) ? nullptr : c->rw_fv + lr * D, D, 4 * D);
+            rowsum(fvm, c->rs_fv + lr * D, D, 4 * D);
             if (need_b(4)) image(fvm, c->b_fv + lr * per_fv, want_seq ? c->r8_fv + lr * SEQ_O * D : nullptr, D, 4 * D, 1, per_fv);
             if (own_t && in_tile(4)) image(fvm, c->t_fv + lr * 4 * D * D, nullptr, D, 4 * D, 1, 4 * D * D, tcfg.th);
         }
     }
     if (!rc && last) {
         rc = retile(c, src, HEAD, 0, D, V, c->w_head, 1, 1, 0, staging);
-        if (!rc) rowsum(c->w_head, c->rs_head, nullptr, V, D);
+        if (!rc) rowsum(c->w_head, c->rs_head, V, D);
         if (!rc && want_seq) {
             const uint64_t cbV = (V + 15) / 16, per_head = cbV * 16 * D;
             rc = dalloc(c, &c->b_head, per_head);
@@ -1094,9 +956,7 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     HIPCHK(hipStreamSynchronize(c->stream));
     if ((rc = set_smem_limits(c))) return rc;
     if (c->seq_ok && (rc = seq_smem_limits())) return rc;
-    const char *nograph = getenv("RWKV_NO_GRAPH");
-    if (!(nograph && nograph[0] == '1')) {
-        if ((rc = carry_policy(c))) return rc;      // (no graphs yet: only decides whether this context carries)
+    if (c->graphs & 1) {
         if ((rc = build_graph(c, false, &c->g_fwd))) return rc;
         if ((rc = build_graph(c, true, &c->g_greedy))) return rc;
     }
@@ -1239,27 +1099,15 @@ int enqueue_chunk(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, boo
             return;
         }
 #undef SEQ_LAUNCH_P2
-        if (c->seq_small & (1 << kind)) {
-            if (kind == 0) SEQ_LAUNCH_P(0, 3, 2, 3, 2, true);
-            else if (kind == 1) SEQ_LAUNCH_P(1, 1, 2, 1, 2, true);
-            else if (kind == 2) { if (big) SEQ_LAUNCH_P(2, 4, 2, 2, 2, true); else SEQ_LAUNCH_P(2, 5, 2, 2, 2, true); }
-            else SEQ_LAUNCH_P(3, 1, 4, 1, 4, true);
-            return;
-        }
-        if (c->seq_pipe & (1 << kind)) {       // the GEMM as a software pipeline over k-blocks (seq.hip.h k_seq_gemm_p; RWKV_SEQ_PIPE bit per kind)
-            if (kind == 0) { if (big) SEQ_LAUNCH_P(0, 3, 10, 2, 2, false); else SEQ_LAUNCH_P(0, 3, 8, 3, RWKV_SEQ_DEPTH0, false); }
-            else if (kind == 1) { if (big) SEQ_LAUNCH_P(1, 1, 10, 1, 10, false); else SEQ_LAUNCH_P(1, 1, 8, 1, 8, false); }
-            else if (kind == 2) { if (big) SEQ_LAUNCH_P(2, 4, 10, 2, 2, false); else SEQ_LAUNCH_P(2, 5, 8, 2, RWKV_SEQ_DEPTH2, false); }
-            else { if (big) SEQ_LAUNCH_P(3, 1, 10, 1, 10, true); else SEQ_LAUNCH_P(3, 1, 8, 1, 8, true); }
-            return;
-        }
+        // passes of <= 32 rows: ffn_v's activation image (K = 4 D) is staged per 4 k-blocks into alternating LDS buffers instead of per slice, so that
+        // the first MFMA does not wait for the whole slice's image (3.36 -> 3.30 ms per 7B chunk; for the other kinds it measured +-0 or a loss:
+        // profiles/r04/seq_small_ab.txt)
+        if (kind == 3) { SEQ_LAUNCH_P(3, 1, 4, 1, 4, true); return; }
+        // the GEMM as a software pipeline over k-blocks, the slice's whole image resident (seq.hip.h k_seq_gemm_p)
+        if (kind == 0) { if (big) SEQ_LAUNCH_P(0, 3, 10, 2, 2, false); else SEQ_LAUNCH_P(0, 3, 8, 3, RWKV_SEQ_DEPTH0, false); }
+        else if (kind == 1) { if (big) SEQ_LAUNCH_P(1, 1, 10, 1, 10, false); else SEQ_LAUNCH_P(1, 1, 8, 1, 8, false); }
+        else { if (big) SEQ_LAUNCH_P(2, 4, 10, 2, 2, false); else SEQ_LAUNCH_P(2, 5, 8, 2, RWKV_SEQ_DEPTH2, false); }
 #undef SEQ_LAUNCH_P
-#define SEQ_LAUNCH(TAG, NTW, NKB, MTS, NVS) k_seq_gemm<TAG, NTW, NKB, MTS, NVS><<<grid, blk, seq_gemm_smem(NTW, NKB, MTS, NVS), st>>>(g)
-        if (kind == 0) { if (big) SEQ_LAUNCH(0, 3, 10, false, 2); else SEQ_LAUNCH(0, 3, 8, false, 3); }
-        else if (kind == 1) { if (big) SEQ_LAUNCH(1, 1, 10, false, 1); else SEQ_LAUNCH(1, 1, 8, false, 1); }
-        else if (kind == 2) { if (big) SEQ_LAUNCH(2, 4, 10, true, 2); else SEQ_LAUNCH(2, 5, 8, true, 2); }
-        else { if (big) SEQ_LAUNCH(3, 1, 10, false, 1); else SEQ_LAUNCH(3, 1, 8, false, 1); }
-#undef SEQ_LAUNCH
     };
     auto resid = [&](int mode, const SeqPart *qpart) {
         SeqResidArgs r{};
@@ -1342,7 +1190,6 @@ int split_setup(rwkv_ctx *c)
     if (c->n_split) return 0;
     int want = 3;
     if (const char *e = getenv("RWKV_SEQ_STAGES")) want = atoi(e);
-    if (const char *e = getenv("RWKV_SEQ_SPLIT")) if (e[0] == '0') want = 1;
     if (want > rwkv_ctx::SPLIT_MAX) want = rwkv_ctx::SPLIT_MAX;
     if ((uint64_t)want > c->L) want = (int)c->L;
     if (want < 2 || !c->seq_ok || c->l0 != 0 || c->l1 != c->L) { c->n_split = 1; return 0; }
@@ -1443,34 +1290,13 @@ int enqueue_pass(rwkv_ctx *c, const uint64_t *tokens, int n, uint64_t row0, int 
     return 0;
 }
 
-// Rows carried in LDS across kernel boundaries pay only while THIS context's kernels follow each other on the CUs: with two contexts
-// decoding at once (two models, two streams of one model) nearly every workgroup finds that the other context's kernel has had its
-// CU (hits 1.2 %, profiles/r03/carry.txt) and the rows left for it were streamed for nothing -- 678 -> 656 tokens/s aggregate.  So
-// the carry is on only while a context is alone on its device in this process (RWKV_CARRY_SHARED=1: always); the token graphs are
-// re-captured at the next call after that changed.
-std::atomic<int> g_ctx_live[64];
-std::atomic<unsigned> g_ctx_epoch{1u};
-int carry_policy(rwkv_ctx *c)
-{
-    const unsigned e = g_ctx_epoch.load(std::memory_order_acquire);
-    if (e == c->carry_epoch) return 0;
-    c->carry_epoch = e;
-    const bool shared = getenv("RWKV_CARRY_SHARED") != nullptr;
-    const bool want = shared || g_ctx_live[c->device & 63].load(std::memory_order_acquire) <= 1;
-    if (want == c->carry_active) return 0;
-    c->carry_active = want;
-    if (!c->loaded || (!c->g_fwd && !c->g_greedy)) return 0;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return rebuild_graphs(c);
-}
-
 // Start of every entry point that launches kernels: the device error word belongs to ONE call.  An entry point that left early
 // (a failed HIP call) never consumed it, and a code raised then would surface -- attributed to the wrong operation -- from whatever
-// synchronises next; so it is cleared here, then the carry policy is brought up to date.
+// synchronises next; so it is cleared here.
 int begin_call(rwkv_ctx *c)
 {
     if (c->herr) *c->herr = 0u;
-    return carry_policy(c);
+    return 0;
 }
 
 int run_token(rwkv_ctx *c, bool with_argmax)
@@ -1502,20 +1328,10 @@ int rwkv_create(rwkv_ctx **out, int device)
     const char *g = getenv("RWKV_GRID");
     if (g && atoi(g) > 0) c->grid = atoi(g);
     { const char *e = getenv("RWKV_RING"); if (e) c->ring = atoi(e); }
-    { const char *e = getenv("RWKV_CARRY"); if (e) c->carry_kib = atoi(e); }
-    { const char *e = getenv("RWKV_SEQ_PIPE"); if (e) c->seq_pipe = atoi(e); }
-    { const char *e = getenv("RWKV_SEQ_SMALL"); if (e) c->seq_small = atoi(e); }
     { const char *e = getenv("RWKV_SEQ_B"); if (e) c->seq_b = atoi(e); }
-    { const char *e = getenv("RWKV_SEQ_GRAPH"); if (e) c->seq_graph = atoi(e) != 0; }
+    { const char *e = getenv("RWKV_GRAPH"); if (e) { c->graphs = atoi(e); c->seq_graph = (c->graphs & 2) != 0; } }
     { const char *e = getenv("RWKV_SEQ_ROWS"); if (e) c->seq_rows = atoi(e) > SEQ_T ? SEQ_TM : SEQ_T; }
-    { const char *e = getenv("RWKV_CARRY_EDGES"); if (e) c->carry_edges = atoi(e); }
     { const char *e = getenv("RWKV_TILE"); if (e) c->tile = atoi(e); }
-    {
-        static std::atomic<unsigned> serial{0u};
-        const unsigned long long t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((unsigned long long)(uintptr_t)c << 17);
-        c->nonce[0] = 0x52574b56u ^ (unsigned)(t * 0x9e3779b97f4a7c15ull >> 32) ^ (++serial << 24);
-        c->nonce[1] = (unsigned)((t ^ (unsigned long long)getpid()) * 0xbf58476d1ce4e5b9ull >> 29);
-    }
     if (c->grid > NT / 2) c->grid = NT / 2;   // consumers sum one partial per thread of the prologue waves (half the workgroup)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(RWKV_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -1528,8 +1344,6 @@ int rwkv_create(rwkv_ctx **out, int device)
     }
     *c->herr = 0u;
     c->d_herr = static_cast<unsigned *>(dp);
-    g_ctx_live[device & 63].fetch_add(1, std::memory_order_acq_rel);
-    g_ctx_epoch.fetch_add(1u, std::memory_order_acq_rel);
     *out = c;
     return 0;
 }
@@ -1592,8 +1406,6 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
         const uint64_t CH = (T > (uint64_t)SEQ_T && c->seq_rows > SEQ_T) ? (uint64_t)SEQ_TM : (uint64_t)SEQ_T;
         const uint64_t nchunks = (T + CH - 1) / CH;
         int rc = 0;
-        static const bool host_time = getenv("RWKV_SEQ_HOSTTIME") != nullptr;     // diagnostics: is a long call bound by the host's launch rate?
-        const auto h0 = std::chrono::steady_clock::now();
         if (nchunks >= 2 && (rc = split_setup(c)) == 0 && c->n_split >= 2) {
             // Software pipeline over the chunks: stage k = an equal share of the layers (the last one with the head) on its
             // own stream with its own scratch, stage k on chunk i while stage k - 1 is on chunk i + 1.  Every launch of this path
@@ -1641,13 +1453,7 @@ int rwkv_forward(rwkv_ctx *c, const uint64_t *tokens, uint64_t T, int mode)
                 if (rc) return rc;
             }
         }
-        const auto h1 = std::chrono::steady_clock::now();
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (host_time) {
-            const auto h2 = std::chrono::steady_clock::now();
-            fprintf(stderr, "[rwkv] forward T=%llu: host enqueue %.2f ms, waited %.2f ms more for the device\n", (unsigned long long)T,
-                    std::chrono::duration<double, std::milli>(h1 - h0).count(), std::chrono::duration<double, std::milli>(h2 - h1).count());
-        }
         return 0;
     }
     for (uint64_t t = 0; t < T; t++) {
@@ -1811,8 +1617,6 @@ void rwkv_free(rwkv_ctx *c)
     if (c->g_fwd) { (void)hipGraphExecDestroy(c->g_fwd); c->g_fwd = nullptr; }
     if (c->g_greedy) { (void)hipGraphExecDestroy(c->g_greedy); c->g_greedy = nullptr; }
     rwkv_pipe_free(c);        // (no graphs left to re-capture)
-    g_ctx_live[c->device & 63].fetch_sub(1, std::memory_order_acq_rel);
-    g_ctx_epoch.fetch_add(1u, std::memory_order_acq_rel);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->herr) (void)hipHostFree(c->herr);
@@ -1835,32 +1639,6 @@ void *rwkv_stream(rwkv_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int rwkv_abi_version(void) { return RWKV_MI355X_ABI_VERSION; }
 uint64_t rwkv_resident_bytes(const rwkv_ctx *c) { return c ? (uint64_t)c->alloc_bytes : 0; }
 int rwkv_decode_form(const rwkv_ctx *c) { return c && c->loaded ? (c->tile > 0 ? c->tile : 0) : -1; }
-
-// carry counters since the last call: [0] workgroup launches that found the rows their predecessor was asked to leave in LDS, [1] that
-// did not (they stream the rows themselves), [2] carried groups whose check failed and that were re-loaded from memory (kernels.hip.h
-// carry_verify).  All zero when the context does not carry (RWKV_CARRY=0, rows other than 3-4 KiB, RWKV_CARRY_COUNT=0).
-int rwkv_debug_carry_stats(rwkv_ctx *c, uint64_t *out3)
-{
-    if (!c || !out3) return fail(RWKV_E_ARG, "NULL argument");
-    out3[0] = out3[1] = out3[2] = 0;
-    if (!c->carry_hits) return 0;
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    std::vector<unsigned> h((size_t)c->grid * 4, 0u);
-    HIPCHK(hipMemcpy(h.data(), c->carry_hits, h.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(c->carry_hits, 0, h.size() * 4));
-    for (int b = 0; b < c->grid; b++)
-        for (int k = 0; k < 3; k++) out3[k] += h[(size_t)b * 4 + k];
-    return 0;
-}
-int rwkv_debug_carry_hits(rwkv_ctx *c, uint64_t *out2)      // the first two of the above (round-3 entry point)
-{
-    uint64_t t[3];
-    if (!out2) return fail(RWKV_E_ARG, "NULL argument");
-    const int rc = rwkv_debug_carry_stats(c, t);
-    out2[0] = t[0]; out2[1] = t[1];
-    return rc;
-}
 
 uint64_t rwkv_bytes_per_token(const rwkv_ctx *c)
 {
@@ -1939,14 +1717,14 @@ int rwkv_profile_batched(rwkv_ctx *c, uint64_t token, int reps, double *ms, uint
         float t = 0.f, t0 = 0.f;
         uint32_t cnt = 0;
         for (int pass = flush ? 0 : 1; pass < 2; pass++) {      // pass 0: the flushing launches alone
-            launch_class(c, cls, per_layer ? c->l0 : 0, per_layer);
+            launch_class(c, cls, per_layer ? c->l0 : 0);
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipEventRecord(a, c->stream));
             cnt = 0;
             for (int r = 0; r < nrep; r++)
                 for (uint64_t l = (per_layer ? c->l0 : 0); l < (per_layer ? c->l1 : 1); l++) {
                     if (flush) for (int q = 0; q < 4; q++) launch_class(c, 4, c->l0 + (uint64_t)(4 * r + q) % nl);
-                    if (pass == 1) launch_class(c, cls, l, per_layer);
+                    if (pass == 1) launch_class(c, cls, l);
                     cnt++;
                 }
             HIPCHK(hipEventRecord(b, c->stream));
@@ -1981,12 +1759,12 @@ int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, ui
     { const char *e = getenv("RWKV_TL_CLASS"); c->tl_cls = e ? atoi(e) : 3; }
     c->tl_on = true;
     int rc;
-    if (c->tl_cls >= 10) {          // a GEMM of the chunk path: one 32-row GPT chunk of this token
+    if (c->tl_cls >= 10) {          // a GEMM of the chunk path (10 + kind: one 32-row GPT chunk of this token; 20 + kind: a 64-row pass, the two-half GEMMs)
         if (!c->seq_ok) { c->tl_on = false; return fail(RWKV_E_STATE, "the chunk path is not loaded (max_ctx 1)"); }
         uint64_t toks[SEQ_TM];
         for (int t = 0; t < SEQ_TM; t++) toks[t] = token;
-        int rows = SEQ_T;                // RWKV_TL_ROWS=64: a 64-row pass (the two-half GEMMs)
-        { const char *e = getenv("RWKV_TL_ROWS"); if (e && atoi(e) > SEQ_T && c->seq_rows > SEQ_T && c->maxT >= (uint64_t)SEQ_TM) rows = SEQ_TM; }
+        int rows = SEQ_T;
+        if (c->tl_cls >= 20) { c->tl_cls -= 10; if (c->seq_rows > SEQ_T && c->maxT >= (uint64_t)SEQ_TM) rows = SEQ_TM; }
         rc = enqueue_chunk(c, toks, rows, 0, false);
     } else rc = enqueue_token(c, false, nullptr);
     c->tl_on = false;
@@ -1996,41 +1774,78 @@ int rwkv_debug_timeline(rwkv_ctx *c, uint64_t token, unsigned long long *out, ui
     return device_check(c);
 }
 
-int rwkv_mm8_one(rwkv_ctx *c, uint64_t N, uint64_t M, const float *x, const uint8_t *w, const float *r,
-                 const float *o, float *y)
+// ---- per-kernel parity hooks (tests/test_kernels_gpu.py): the PRODUCTION launch of one decode kernel class, eagerly, on whatever the
+// context's buffers hold, and access to the intermediate vectors the kernels hand to each other.  A token is rwkv_debug_launch(0),
+// then (1, 2, 3, 4) per layer, then 5: exactly what enqueue_token launches, one kernel at a time. ----
+int rwkv_debug_launch(rwkv_ctx *c, int cls, uint64_t layer, uint64_t token, uint32_t slot)
 {
-    if (!c || !x || !w || !r || !o || !y) return fail(RWKV_E_ARG, "NULL argument");
-    if (N == 0 || M < 4 || N % 16 != 0) return fail(RWKV_E_ARG, "N must be a positive multiple of 16, M >= 4");
-    const bool quarters = N > 5120;
-    if (quarters && (N % 64 != 0 || N / 4 > 5120)) return fail(RWKV_E_ARG, "N > 5120 must be 4*Dq with Dq <= 5120, Dq %% 16 == 0");
+    if (!c) return fail(RWKV_E_ARG, "NULL ctx");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    if (cls < 0 || cls > 6) return fail(RWKV_E_ARG, "kernel class %d out of range (0 first, 1 att, 2 att_out, 3 ffn r+k, 4 ffn_v, 5 head, 6 argmax)", cls);
+    if (cls >= 1 && cls <= 4 && (layer < c->l0 || layer >= c->l1)) return fail(RWKV_E_ARG, "layer %llu is not one of this context's", (unsigned long long)layer);
+    if (cls >= 5 && c->l1 != c->L) return fail(RWKV_E_STATE, "this context does not hold the head");
+    if (slot >= c->maxT) return fail(RWKV_E_ARG, "state slot %u out of range", slot);
+    if (c->l0 == 0 && token >= RWKV_VOCAB) return fail(RWKV_E_ARG, "token id out of range");
     HIPCHK(hipSetDevice(c->device));
-    uint8_t *wt = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&wt), N * M));
-    dim3 rg((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
-    hipLaunchKernelGGL(k_retile, rg, dim3(256), 0, c->stream, w, wt, (int)N, (int)M, 1, 1, 0);
-    unsigned *rsum = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&rsum), M * sizeof(unsigned)) != hipSuccess) { (void)hipFree(wt); return fail(RWKV_E_DEVICE, "hipMalloc failed"); }
-    k_rowsum<<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, c->stream>>>(wt, rsum, nullptr, (size_t)M, (int)N, (int)N);
-    Mm8Args a{wt, rsum, x, r, o, y, (int)N, (int)M};
-    const int S = (int)(((quarters ? N / 4 : N) + 1023) / 1024);
-    const size_t smem = RED_BYTES + (size_t)(quarters ? 4 : 1) * S * 3072;
-    int rc = 0;
-    if (quarters) {
-        DISPATCH_S(S, rc = allow_smem(k_mm8<S_, true>, smem));
-        if (!rc) DISPATCH_S(S, k_mm8<S_, true><<<dim3(c->grid), dim3(NT), smem, c->stream>>>(a));
-    } else {
-        DISPATCH_S(S, rc = allow_smem(k_mm8<S_, false>, smem));
-        if (!rc) DISPATCH_S(S, k_mm8<S_, false><<<dim3(c->grid), dim3(NT), smem, c->stream>>>(a));
+    { const int rcp = begin_call(c); if (rcp) return rcp; }
+    if (cls == 0) {      // the token's control block: every later launch of the token reads slot / out_row from it
+        c->h_ctl[0].token = token; c->h_ctl[0].slot = slot; c->h_ctl[0].out_row = slot; c->h_ctl[0].step = 0; c->h_ctl[0].pad = 0;
+        HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl[0], sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     }
-    hipError_t e1 = hipGetLastError();
-    hipError_t e2 = hipStreamSynchronize(c->stream);
-    (void)hipFree(wt);
-    (void)hipFree(rsum);
-    if (rc) return rc;
-    HIPCHK(e1);
-    HIPCHK(e2);
+    launch_class(c, cls, layer);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return device_check(c);
+}
+
+namespace {
+// device address and byte size of intermediate buffer `which` (enum rwkv_debug_buf)
+int debug_buf(rwkv_ctx *c, int which, void **p, size_t *bytes)
+{
+    const size_t D = (size_t)c->D, G = (size_t)c->grid;
+    switch (which) {
+    case RWKV_DBG_X: *p = c->x; *bytes = D * 8; break;
+    case RWKV_DBG_YBUF: *p = c->ybuf; *bytes = D * 4; break;
+    case RWKV_DBG_PART_ATT: *p = c->partA; *bytes = G * 8; break;
+    case RWKV_DBG_PMAX_ATT: *p = c->partMA; *bytes = G * 4; break;
+    case RWKV_DBG_HBUF: *p = c->hbuf; *bytes = 4 * D * 4; break;
+    case RWKV_DBG_RGATE: *p = c->rgate; *bytes = D * 4; break;
+    case RWKV_DBG_PART_FFN: *p = c->partF; *bytes = G * 8; break;
+    case RWKV_DBG_PMAX_FFN: *p = c->partMF; *bytes = G * 4; break;
+    case RWKV_DBG_LNSTAT: *p = c->lnstat; *bytes = 6 * 8; break;
+    default: return fail(RWKV_E_ARG, "no such debug buffer: %d", which);
+    }
     return 0;
 }
+} // namespace
+
+int rwkv_debug_read(rwkv_ctx *c, int which, void *dst, uint64_t cap)
+{
+    if (!c || !dst) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    void *p = nullptr; size_t n = 0;
+    { const int rc = debug_buf(c, which, &p, &n); if (rc) return rc; }
+    if (cap < n) return fail(RWKV_E_ARG, "debug buffer %d holds %zu bytes", which, n);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rwkv_debug_write(rwkv_ctx *c, int which, const void *src, uint64_t bytes)
+{
+    if (!c || !src) return fail(RWKV_E_ARG, "NULL argument");
+    if (!c->loaded) return fail(RWKV_E_STATE, "RWKV not loaded");
+    void *p = nullptr; size_t n = 0;
+    { const int rc = debug_buf(c, which, &p, &n); if (rc) return rc; }
+    if (bytes != n) return fail(RWKV_E_ARG, "debug buffer %d holds %zu bytes", which, n);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+uint64_t rwkv_debug_grid(const rwkv_ctx *c) { return c ? (uint64_t)c->grid : 0; }
 
 } // extern "C"
 
@@ -2213,8 +2028,7 @@ int rwkv_pipe_init(rwkv_ctx *c, const void *id128, int rank, int world)
                  rank, world, (unsigned long long)c->l0, (unsigned long long)c->l1, c->device, bus, prop.gcnArchName, prop.multiProcessorCount, ver, path, rt,
                  (unsigned long long)p->ch, getenv("HSA_ENABLE_IPC_MODE_LEGACY") ? getenv("HSA_ENABLE_IPC_MODE_LEGACY") : "");
         p->info = buf;
-        const char *lg = getenv("RWKV_PIPE_LOG");
-        if (!(lg && lg[0] == '0')) fprintf(stderr, "[rwkv_mi355x] pipeline transport up: %s\n", buf);
+        fprintf(stderr, "[rwkv_mi355x] pipeline transport up: %s\n", buf);
     }
     c->pipe = p;
     return 0;
@@ -2334,10 +2148,28 @@ int rwkv_pipe_decode_streams(rwkv_ctx *c, const uint64_t *first_tokens, uint64_t
 // the comm streams against the compute stream: ev_rx[k] (the group's receives have landed) and ev_cp[k] (the stage's output is in
 // xout[k], xin[k] has been consumed).  Results are those of 2 x world independent greedy decodes (stream g on state slot g).
 namespace {
+// streams, hop buffers and events of the two-communicator schedule (not the communicator itself): idempotent, also the clean-up of a set-up
+// that failed half way
+void pipe_dual_teardown(Pipe *p)
+{
+    for (int k = 0; k < 2; k++) {
+        if (p->cs[k]) { (void)hipStreamSynchronize(p->cs[k]); (void)hipStreamDestroy(p->cs[k]); p->cs[k] = nullptr; }
+        if (p->xin[k]) { (void)hipFree(p->xin[k]); p->xin[k] = nullptr; }
+        if (p->xout[k]) { (void)hipFree(p->xout[k]); p->xout[k] = nullptr; }
+        if (p->idbuf[k]) { (void)hipFree(p->idbuf[k]); p->idbuf[k] = nullptr; }
+        if (p->ev_rx[k]) { (void)hipEventDestroy(p->ev_rx[k]); p->ev_rx[k] = nullptr; }
+        if (p->ev_cp[k]) { (void)hipEventDestroy(p->ev_cp[k]); p->ev_cp[k] = nullptr; }
+    }
+    p->dual_ready = false;
+}
+// Re-entrant: `dual_ready` is set only when every resource AND the second communicator exist; a call that fails half way
+// frees what it made and the next call starts over.  The id exchange always completes on every rank: if rank 0 cannot make an id it sends
+// an all-zero one, which every rank (rank 0 included) treats as the failure it is -- nobody is left blocked in a receive.
 int pipe_dual_setup(rwkv_ctx *c)
 {
     Pipe *p = c->pipe;
-    if (p->cs[0]) return 0;
+    if (p->dual_ready) return 0;
+    pipe_dual_teardown(p);
     const int S = p->world, rank = p->rank;
     if (S > 1 && !p->comm2) {
         // the second communicator's id is made by rank 0 and travels over the first one (16 x u64)
@@ -2345,33 +2177,46 @@ int pipe_dual_setup(rwkv_ctx *c)
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), sizeof(Pipe::Id)));
         Pipe::Id id;
         memset(&id, 0, sizeof(id));
-        int r = 0;
+        int r = 0, r_id = 0;
         if (rank == 0) {
-            NCHK(p->GetUniqueId(&id));
-            HIPCHK(hipMemcpyAsync(d, id.b, sizeof(id.b), hipMemcpyHostToDevice, c->stream));
-            r = p->GroupStart();
-            for (int q = 1; q < S && !r; q++) r = p->Send(d, sizeof(id.b) / 8, kNcclUint64, q, p->comm, c->stream);
-            const int r2 = p->GroupEnd();
-            if (!r) r = r2;
+            r_id = p->GetUniqueId(&id);
+            if (r_id) memset(&id, 0, sizeof(id));               // the peers learn of the failure from the id itself
+            if (hipMemcpyAsync(d, id.b, sizeof(id.b), hipMemcpyHostToDevice, c->stream) != hipSuccess) r = -1;
+            if (!r) {
+                r = p->GroupStart();
+                for (int q = 1; q < S && !r; q++) r = p->Send(d, sizeof(id.b) / 8, kNcclUint64, q, p->comm, c->stream);
+                const int r2 = p->GroupEnd();
+                if (!r) r = r2;
+            }
         } else {
             r = p->Recv(d, sizeof(id.b) / 8, kNcclUint64, 0, p->comm, c->stream);
             if (!r && hipMemcpyAsync(id.b, d, sizeof(id.b), hipMemcpyDeviceToHost, c->stream) != hipSuccess) r = -1;
         }
         const hipError_t e = hipStreamSynchronize(c->stream);
         (void)hipFree(d);
+        if (r_id) return pipe_fail(p, r_id, "ncclGetUniqueId (second communicator)");
         if (r) return pipe_fail(p, r > 0 ? r : 1, "exchange of the second communicator's id");
         HIPCHK(e);
+        bool zero = true;
+        for (size_t q = 0; q < sizeof(id.b); q++) zero = zero && id.b[q] == 0;
+        if (zero) return fail(RWKV_E_DEVICE, "rank 0 could not make the second communicator's id (it sent the all-zero id)");
         r = p->CommInitRank(&p->comm2, S, id, rank);
         if (r) { p->comm2 = nullptr; return pipe_fail(p, r, "ncclCommInitRank (second communicator)"); }
     }
-    for (int k = 0; k < 2; k++) {
-        HIPCHK(hipStreamCreateWithFlags(&p->cs[k], hipStreamNonBlocking));
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&p->xin[k]), c->D * sizeof(double)));
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&p->xout[k]), c->D * sizeof(double)));
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&p->idbuf[k]), 64));
-        HIPCHK(hipEventCreateWithFlags(&p->ev_rx[k], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&p->ev_cp[k], hipEventDisableTiming));
-    }
+    auto make = [&]() -> int {
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(hipStreamCreateWithFlags(&p->cs[k], hipStreamNonBlocking));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&p->xin[k]), c->D * sizeof(double)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&p->xout[k]), c->D * sizeof(double)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&p->idbuf[k]), 64));
+            HIPCHK(hipEventCreateWithFlags(&p->ev_rx[k], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&p->ev_cp[k], hipEventDisableTiming));
+        }
+        return 0;
+    };
+    const int rm = make();
+    if (rm) { pipe_dual_teardown(p); return rm; }
+    p->dual_ready = true;
     return 0;
 }
 } // namespace
@@ -2589,14 +2434,7 @@ void rwkv_pipe_free(rwkv_ctx *c)
 {
     if (!c || !c->pipe) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (int k = 0; k < 2; k++) {
-        if (c->pipe->cs[k]) { (void)hipStreamSynchronize(c->pipe->cs[k]); (void)hipStreamDestroy(c->pipe->cs[k]); }
-        if (c->pipe->xin[k]) (void)hipFree(c->pipe->xin[k]);
-        if (c->pipe->xout[k]) (void)hipFree(c->pipe->xout[k]);
-        if (c->pipe->idbuf[k]) (void)hipFree(c->pipe->idbuf[k]);
-        if (c->pipe->ev_rx[k]) (void)hipEventDestroy(c->pipe->ev_rx[k]);
-        if (c->pipe->ev_cp[k]) (void)hipEventDestroy(c->pipe->ev_cp[k]);
-    }
+    pipe_dual_teardown(c->pipe);
     if (c->pipe->comm2 && c->pipe->CommDestroy) (void)c->pipe->CommDestroy(c->pipe->comm2);
     if (c->pipe->comm && c->pipe->CommDestroy) (void)c->pipe->CommDestroy(c->pipe->comm);
     delete c->pipe;

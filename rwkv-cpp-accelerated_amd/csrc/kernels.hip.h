@@ -873,7 +873,7 @@ constexpr int GLDS_SPIN = 1 << 18;    // bound of every wait loop (a lost hand-o
 // kernel's closing barrier (ring_report), to the context's error word (mapped host memory; engine.hip device_check reads it after
 // the stream synchronisation and fails the call with RWKV_E_DEVICE): the kernel still ends, but nobody is handed its results.
 // codes: 1 loader found no room, 2 a group never landed, 3 the prologue never staged (or the carried rows were never verified),
-// 4 the loader's own DMA never completed.  (5, "carried rows damaged", is gone: round 4 repairs them in place, carry_verify.)
+// 4 the loader's own DMA never completed.  
 __device__ __forceinline__ void wait_count(const unsigned *p, unsigned least, unsigned &fail)
 {
     bool ok = false;
@@ -908,73 +908,23 @@ constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
 #ifndef RWKV_TEST_DROP_GROUP
 #define RWKV_TEST_DROP_GROUP 0
 #endif
-// TEST build only (-DRWKV_TEST_CORRUPT_CARRY=1): the loader flips one bit of the rows it carries for the next kernel, whose consumers
-// must notice (code 5) and fail the call
-#ifndef RWKV_CARRY_VERIFY
-#define RWKV_CARRY_VERIFY 1      // A/B knob: check carried rows against their row sums (0: no check; 2: checked, but nobody waits for the verdict -- timing experiment only)
-#endif
-#ifndef RWKV_TEST_CORRUPT_CARRY
-#define RWKV_TEST_CORRUPT_CARRY 0
-#endif
 #ifndef RWKV_LOADER_PRIO
 #define RWKV_LOADER_PRIO 0        // s_setprio of the loader wave (0..3)
 #endif
 #ifndef RWKV_RING_PRE_DEPTH
 #define RWKV_RING_PRE_DEPTH 16
 #endif
-struct GldsCtl {            // LDS control block of the ring (80 dwords)
+struct GldsCtl {            // LDS control block of the ring
     unsigned staged;        // prologue waves that have staged their part of the vector
     unsigned landed;        // ring units (rows of S KiB) whose DMA has completed: loader -> consumers, monotonic
-    unsigned carried;       // groups at the head of the workgroup's share that the PREVIOUS kernel's loader left in the ring (carry)
-    unsigned verified;      // consumer waves that have checked (and, where damaged, re-loaded) the carried groups they are responsible for
+    unsigned pad[2];
     unsigned freeq[GLDS_FQ];   // freeq[k % FQ] = k + 1: group k has been copied out of the ring
     unsigned gend[GLDS_FQ];    // the loader's own: end unit of group k
-    unsigned stamp[4];         // carry (below): what the previous ring kernel left in the ring for this workgroup
-    unsigned pad2[8];
-    unsigned csum[64];         // carry: the expected position-weighted sums of the carried groups (nrs per group), left by the PREVIOUS kernel beside
-                               // its stamp; NOT zeroed at entry (GLDS_CTL_ZERO words are): read by this kernel's verifying waves, rewritten at the
-                               // end of this kernel's consumer loop for the next one
 };
-constexpr int GLDS_CTL_ZERO = (int)(offsetof(GldsCtl, csum) / 4);
-// CARRY: the weight stream does not stop at the kernel boundary.  Weights do not depend on activations, a CU's LDS keeps its content
-// from one kernel to the next, and with one whole-LDS workgroup per CU block b of launch N + 1 lands on the CU block b of launch N
-// ran on (tools/ldskeep.hip, profiles/r03/ldskeep.txt: 256 / 256 blocks, every word intact, launch after launch and inside a
-// hipGraph; a kernel with a small allocation in between overwrites exactly its own allocation at the bottom of the LDS).  So the
-// loader of ring kernel N, behind its own last row, goes on with the first `n_out` groups of the NEXT ring kernel's share of this
-// workgroup -- the rows land in the ring while this workgroup's consumers finish their last groups and the slower workgroups
-// their streams, i.e. in the microseconds in which HBM used to idle -- and, when they have landed, leaves a stamp in the control
-// block: {context nonce, launch id of the consumer, block, groups}.  The loader of kernel N + 1 reads the stamp before it clears
-// the control block: if it is the one it expects, the ring already holds its first groups (all ring kernels of a model share ONE
-// ring geometry: same control block address -- behind room for the LARGEST set of staged vectors --, same unit size and count; the ring position simply carries on), it announces
-// them as landed and starts its stream behind them; if not -- another kernel ran on the CU in between, the block landed elsewhere
-// -- it loads everything as before.  Every ring kernel clears the stamp on entry, so one is only ever alive between two adjacent
-// kernels of one graph replay; the weights behind it are immutable for the life of the context.
-// A kernel of this engine that is NOT part of the decode chain but whose LDS allocation reaches past a ring kernel's control block
-// (the chunk path's GEMMs: another context, another process of the same engine sharing the GPU) may run on a CU between two decode
-// kernels and write over carried rows WITHOUT writing over the stamp (its allocation is not written everywhere).  It clears the
-// stamp of every row size first, so the consumer loads its rows itself instead of failing the row-sum check.
-__device__ __forceinline__ void carry_kill_stamps(unsigned char *smem, unsigned alloc_bytes)
-{
-    if (threadIdx.x < 20) {
-        const unsigned S = threadIdx.x / 4 + 1;
-        const unsigned off = (unsigned)RED_BYTES + 4u * S * 3072u + (unsigned)offsetof(GldsCtl, stamp) + 4u * (threadIdx.x & 3);
-        if (off + 4u <= alloc_bytes) *reinterpret_cast<unsigned *>(smem + off) = 0u;
-    }
-}
-struct RingCarry {
-    const uint8_t *w_next;      // the next ring kernel's weights: its group g = rows_next rows of D bytes from w_next + g * rows_next * D
-    int rows_next, n_out;       // prefetch n_out groups of rows_next rows for it (0: none)
-    int groups_next;            // its rows are split over the workgroups in groups_next groups (block_lo / block_hi)
-    int n_in;                   // groups the previous ring kernel was asked to leave for this one
-    unsigned tag_in[2], tag_out[2];
-    int pos0;                   // ring position of this kernel's first unit
-    unsigned *hits;             // counters per workgroup, [block][4]: launches that found their rows / did not / carried groups re-loaded after a failed check
-    int xq_bytes;               // LDS reserved for the staged vectors in front of the control block (the same for all kernels that carry)
-    const unsigned *rw_next;    // the next ring kernel's table of position-weighted sums: nrs_next words per group, its group g at rw_next[g * nrs_next]
-    int nrs_next;               //   (this kernel leaves the sums of the n_out groups it carries in GldsCtl::csum: n_out * nrs_next <= 64)
-};
+static_assert(sizeof(GldsCtl) % 16 == 0, "the ring behind the control block stays 16-byte aligned");
+constexpr int GLDS_CTL_ZERO = (int)(sizeof(GldsCtl) / 4);
 constexpr int NC = NW - 1;              // consumer waves of a ring kernel
-// LDS of k_att / k_ffn_rk / k_ffnv in ring form: [reduction scratch RED_BYTES][staged vectors: cy.xq_bytes][GldsCtl][ring: ns units of S KiB]
+// LDS of a row-form kernel in ring form: [reduction scratch RED_BYTES][staged vectors: nv x S x 3 KiB][GldsCtl][ring: ns units of S KiB]
 
 // The loader wave.  The ring is made of `nu` UNITS of one row (S KiB) each; a group of R rows takes the next R units (wrapping),
 // so slots of every group size share one ring and the LDS is used to the last 4 KiB.  Round 2's first loader handed out whole
@@ -995,13 +945,13 @@ template <int S> struct RingLoader {
     unsigned issued = 0, pub = 0;       // units issued / announced as landed
     unsigned k = 0, tail = 0;           // groups issued / groups known to be copied out
     unsigned tailu = 0;                 // first unit still in use
-    unsigned pos;                       // ring position of the next unit
+    unsigned pos = 0;                   // ring position of the next unit
     int lane;
     bool dead = false;
     unsigned fail = 0;                  // see wait_count
 
-    __device__ __forceinline__ RingLoader(GldsCtl *mc_, unsigned ring_, int nu_, int chunks, int lane_, int pos0 = 0)
-        : mc(mc_), ring((unsigned)__builtin_amdgcn_readfirstlane((int)ring_)), nu((unsigned)nu_), pos((unsigned)pos0), lane(lane_)
+    __device__ __forceinline__ RingLoader(GldsCtl *mc_, unsigned ring_, int nu_, int chunks, int lane_)
+        : mc(mc_), ring((unsigned)__builtin_amdgcn_readfirstlane((int)ring_)), nu((unsigned)nu_), lane(lane_)
     {
         asm volatile("" : "+s"(ring));      // an opaque SGPR value (else the generic -> LDS address conversion is redone at every use)
         whole = chunks == 64 * S;
@@ -1073,35 +1023,6 @@ template <int S> struct RingLoader {
         k++;
         poll_landed();
     }
-    // the first n groups of R rows are in the ring already (carry): book them as issued and landed.  Before the order barrier.
-    template <int R> __device__ __forceinline__ void adopt(unsigned n)
-    {
-        if ((unsigned)lane < n) mc->gend[lane] = ((unsigned)lane + 1u) * R;
-        issued = n * R; pub = issued; k = n;
-        pos = (pos + issued) % nu;
-        if (lane == 0) { mc->landed = issued; mc->carried = n; }
-    }
-    // one more row behind the workgroup's own groups (carry): a unit that no consumer of THIS kernel takes
-    __device__ __forceinline__ void row(const uint8_t *src)
-    {
-        for (int it = 0; !room<1>() && !dead; it++) {
-            advance_tail();
-            if (room<1>()) break;
-            poll_landed();
-            if (it >= GLDS_SPIN) { dead = true; fail = 1u; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        wait_vm<(RWKV_RING_DEPTH < 63 ? RWKV_RING_DEPTH : 63) - S>();
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring + pos * (unsigned)(S * 1024)));
-        if (whole) dma_unit<S>(src, dst);
-        else {
-#pragma unroll
-            for (int s = 0; s < S; s++) dma_piece(src + (off[s] - off[0]), dst + s * 1024);
-        }
-        pos = pos + 1 == nu ? 0u : pos + 1;
-        issued += 1;
-        poll_landed();
-    }
     __device__ __forceinline__ void finish()
     {
         int it = 0;
@@ -1112,57 +1033,28 @@ template <int S> struct RingLoader {
     }
 };
 // the loader wave of a launch kernel: groups [g0, g1) of the workgroup in order; base(g) = address of group g's first row
-// CARRY: compiled with the stream across the kernel boundary (the kernels' RING == 2 instances); without it `cy` is not looked at
-template <int R, int S, bool CARRY = false, class Base>
-__device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int nu, unsigned ring, GldsCtl *ctl, int lane,
-                                                const RingCarry &cy = RingCarry{})
+template <int R, int S, class Base>
+__device__ __forceinline__ unsigned glds_loader(Base base, int g0, int g1, size_t stride, int chunks, int nu, unsigned ring, GldsCtl *ctl, int lane)
 {
     loader_clean_slate();
 #if RWKV_LOADER_PRIO
     __builtin_amdgcn_s_setprio(RWKV_LOADER_PRIO);     // the loader's instruction issue IS the stream's ceiling: let it win the SIMD's arbitration
 #endif
-    // carry: did the previous ring kernel leave this workgroup's first groups in the ring?  (read before the block is cleared)
-    unsigned have = 0u;
-    if (CARRY && cy.n_in > 0) {
-        const unsigned got = ctl->stamp[lane & 3];
-        const unsigned want = (lane & 3) == 0 ? cy.tag_in[0] : (lane & 3) == 1 ? cy.tag_in[1] : (lane & 3) == 2 ? (unsigned)blockIdx.x : (unsigned)cy.n_in;
-        have = __builtin_amdgcn_ballot_w64(got != want) == 0ull ? (unsigned)cy.n_in : 0u;
-        have = (int)have <= g1 - g0 ? have : 0u;
-    }
     // the control block is this wave's to zero: nobody else touches it before the order barrier
     for (int i = lane; i < GLDS_CTL_ZERO; i += 64) reinterpret_cast<unsigned *>(ctl)[i] = 0u;
-    RingLoader<S> ld(ctl, ring, nu, chunks, lane, CARRY ? cy.pos0 : 0);
-    if (CARRY && have) ld.template adopt<R>(have);
-    int g = g0 + (int)have;
+    RingLoader<S> ld(ctl, ring, nu, chunks, lane);
+    int g = g0;
     const int pre = RWKV_RING_PRE < nu - R ? RWKV_RING_PRE : nu - R;      // never wait for room before the barrier: the consumers are behind it
     for (; g < g1 && (int)ld.issued < pre; g++) ld.template group<R>(base(g) + ld.off[0], stride, true);
     __syncthreads();   // order: the control block is zero, the prologue's requests are in the pipe
+    // (TEST build -DRWKV_TEST_DROP_GROUP=1: the loader "loses" the workgroup's last group)
     for (; g < g1 - (RWKV_TEST_DROP_GROUP ? 1 : 0); g++) ld.template group<R>(base(g) + ld.off[0], stride);
-    const unsigned cpos = ld.pos;
-    if (CARRY && cy.n_out > 0 && !RWKV_TEST_DROP_GROUP) {
-        const uint8_t *src = cy.w_next + (size_t)block_lo(cy.groups_next) * cy.rows_next * stride + ld.off[0];
-        const int rows = cy.n_out * cy.rows_next;
-        for (int r = 0; r < rows; r++) ld.row(src + (size_t)r * stride);
-    }
     ld.finish();
-    // carry counters: a word per workgroup (256 arrivals on ONE word are a 3 us chain of memory-side atomics, profiles/r04/atomicbench.txt),
-    // and only HERE, behind the loader's last DMA: the loader reads its own vmcnt to tell what has landed, and any other vector memory
-    // operation of this wave in flight would be counted as a DMA piece (round 4 found it the hard way: with the counter at the head of
-    // the loader, a workgroup that did NOT find its rows announced `issued * S - in_flight` = -1 = everything as landed)
-    if (CARRY && cy.n_in > 0 && cy.hits != nullptr && lane == 0)
-        __hip_atomic_fetch_add(cy.hits + (size_t)blockIdx.x * 4 + (have ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if RWKV_TEST_CORRUPT_CARRY
-    if (CARRY && cy.n_out > 0 && lane == 0) *reinterpret_cast<__attribute__((address_space(3))) unsigned *>(ring + cpos * (unsigned)(S * 1024) + 64u) ^= 0x00010000u;
-#else
-    (void)cpos;
-#endif
-    if (CARRY && cy.n_out > 0 && !RWKV_TEST_DROP_GROUP && ld.fail == 0u && lane < 4)
-        ctl->stamp[lane] = lane == 0 ? cy.tag_out[0] : lane == 1 ? cy.tag_out[1] : lane == 2 ? (unsigned)blockIdx.x : (unsigned)cy.n_out;
     return ld.fail;
 }
 // consumer side of one group (kl = its index in the workgroup): wait, copy its R units into registers, hand them back
 template <int R, int S>
-__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, const unsigned char *ring, GldsCtl *ctl, int lane, unsigned &fail, int pos0 = 0)
+__device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, const unsigned char *ring, GldsCtl *ctl, int lane, unsigned &fail)
 {
     const unsigned uend = (unsigned)(kl + 1) * R;
     bool ok = false;
@@ -1171,7 +1063,7 @@ __device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, cons
         __builtin_amdgcn_s_sleep(1);
     }
     fail = ok ? fail : 2u;
-    unsigned p0 = ((unsigned)pos0 + uend - R) % (unsigned)nu;
+    unsigned p0 = (uend - R) % (unsigned)nu;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const u32x4 *p = reinterpret_cast<const u32x4 *>(ring + (size_t)p0 * (S * 1024)) + lane;
@@ -1181,84 +1073,6 @@ __device__ __forceinline__ void glds_take(u32x4 (&w)[R][S], int kl, int nu, cons
     }
     if (lane == 0) __hip_atomic_store(&ctl->freeq[kl % GLDS_FQ], (unsigned)kl + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// Rows that were CARRIED into this kernel (the first ctl->carried groups of the workgroup: they have been sitting in LDS since the
-// previous kernel, across a boundary at which another process's kernel may have had the CU) are checked before they are used, and
-// RE-LOADED where the check fails (round 4; round 3 failed the call): LDS content across a kernel boundary is not something the
-// programming model promises, so a damaged row must cost a reload, not the token.  The check is a POSITION-WEIGHTED sum of the row's
-// bytes -- sum over 16-byte pieces c of (c + 1) * sum_i (1 + i) u[16 c + i], modulo 2^32 -- against the table the engine builds at load
-// next to the row sums (`rw`, k_rowsum: nrs entries per group); a plain byte sum (round 3) passes any permutation and any pair of
-// compensating changes.
-//
-// WHO checks, WHEN, against WHAT decides whether the check is free (round 5; profiles/r05/r04_regression_bisect.txt, carry_verify_timeline*.txt).
-// Round 4 had the idle consumer waves check the carried groups in the ring while waves 0..3 staged the vector, and every consumer waited
-// for their verdict behind "staged".  Measured, that wait cost exactly what the carry gains (7B: 567 tokens/s with it, 568 with the carry
-// off, 581 with the check compiled out): the verdict on a 20 KiB group came in 2-2.4 us behind the order barrier -- AFTER the vectors were
-// staged -- (a) because its expected sum was a cold 4-byte load from the table, queued behind the DMA stream and the prologue's 100 KB
-// (requested at kernel entry or behind the barrier alike, it returned at 3.9-4.4 us), and (b) because twenty LDS round trips under the
-// loader's stream are slow whoever makes them.  So:
-//   * the expected sums travel WITH the rows: a consumer wave of the PRODUCING kernel fetches the next kernel's sums from the table while
-//     it has nothing to wait for (carry_next_sums) and leaves them in GldsCtl::csum behind the kernel's closing barrier; the check compares
-//     LDS against LDS.  What it defends against is unchanged: rows damaged while they sat in LDS do not match the table's sums (a copy our
-//     own kernel made, under the same stamp); a damaged copy of the sums fails the check too and costs a reload, never a wrong row;
-//   * the wave that TAKES a carried group checks it, in the registers glds_take has just filled (the reads are the take's own): 6 VALU
-//     instructions per 16 weight bytes on the first group of at most `carried` waves, no pass over the ring, no verdict anybody waits for;
-//     a group that fails is loaded again from memory straight into those registers (cold path, compiler-visible loads).
-constexpr unsigned CK_PAT0 = 0x04030201u, CK_PAT1 = 0x08070605u, CK_PAT2 = 0x0c0b0a09u, CK_PAT3 = 0x100f0e0du;
-__device__ __forceinline__ unsigned ck_piece(const u32x4 &w, int c)
-{
-    unsigned t = __builtin_amdgcn_udot4(w[0], CK_PAT0, 0u, false);
-    t = __builtin_amdgcn_udot4(w[1], CK_PAT1, t, false);
-    t = __builtin_amdgcn_udot4(w[2], CK_PAT2, t, false);
-    t = __builtin_amdgcn_udot4(w[3], CK_PAT3, t, false);
-    return t * (unsigned)(c + 1);
-}
-struct CarryCheck { int chunks, g0, nrs; const uint8_t *w; unsigned *hits; };
-// k = the group's index in the workgroup (< ctl->carried); w = its rows as glds_take left them
-template <int R, int S>
-__device__ __forceinline__ void carry_check_taken(u32x4 (&w)[R][S], int k, const CarryCheck &ck, const GldsCtl *ctl, int lane)
-{
-    const unsigned want = lane < ck.nrs ? ctl->csum[(k * ck.nrs + lane) & 63] : 0u;
-    // (the weight of a piece depends on its place in the row only: the rows' pieces of one step are summed first, one multiply per step)
-    unsigned t = 0u;
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        unsigned a = 0u;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            a = __builtin_amdgcn_udot4(w[r][s][0], CK_PAT0, a, false);
-            a = __builtin_amdgcn_udot4(w[r][s][1], CK_PAT1, a, false);
-            a = __builtin_amdgcn_udot4(w[r][s][2], CK_PAT2, a, false);
-            a = __builtin_amdgcn_udot4(w[r][s][3], CK_PAT3, a, false);
-        }
-        if (lane + 64 * s < ck.chunks) t += a * (unsigned)(lane + 64 * s + 1);
-    }
-    if (wave_sum_dpp(t) != wave_sum_dpp(want)) {
-        const uint8_t *src = ck.w + (size_t)(ck.g0 + k) * R * ((size_t)ck.chunks << 4);
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                int c = lane + 64 * s;
-                c = c < ck.chunks ? c : ck.chunks - 1;
-                w[r][s] = *reinterpret_cast<const u32x4 *>(src + (size_t)r * ((size_t)ck.chunks << 4) + ((size_t)c << 4));
-            }
-        if (ck.hits != nullptr && lane == 0) __hip_atomic_fetch_add(ck.hits + (size_t)blockIdx.x * 4 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-// the producing side of the sums: requested by ONE consumer wave once the vectors are staged (nothing waits for them), stored behind the
-// kernel's closing barrier (every wave of this kernel is past the check of the sums IT was left)
-__device__ __forceinline__ unsigned carry_next_sums(const RingCarry &cy, int lane)
-{
-    unsigned v = 0u;
-    if (cy.n_out > 0 && lane < cy.n_out * cy.nrs_next) v = cy.rw_next[(size_t)block_lo(cy.groups_next) * cy.nrs_next + lane];
-    return v;
-}
-__device__ __forceinline__ void carry_leave_sums(const RingCarry &cy, GldsCtl *ctl, int lane, unsigned v)
-{
-    if (cy.n_out > 0 && lane < cy.n_out * cy.nrs_next) ctl->csum[lane] = v;
-}
-constexpr int CARRY_SUMS_WAVE = NT / 2 / 64 + 2;      // wave 6: the verifying wave with the fewest groups
-
 // EARLY TAKE (round 4).  The ring holds what HBM delivers while waves 0..3 run the prologue; when the prologue outlasts the ring --
 // 14B: vectors staged at 6.5 us, the ring (110-125 KiB) full at 4.4-5 us, the loader idle for ~2 us of every k_att / k_ffn_rk launch
 // (profiles/r04/timelines_14B_1B5.txt) -- the stream waits for the consumers.  The consumer waves that do NOT stage (4..6) therefore take
@@ -1268,21 +1082,16 @@ constexpr int CARRY_SUMS_WAVE = NT / 2 / 64 + 2;      // wave 6: the verifying w
 // wave w is (w + 3) mod 7.  The first group's epilogue inputs are still requested right in front of its dot products (an early
 // scattered global load would sit in the CU's in-order return queue in front of the stream).
 // Measured (profiles/r04/early_take_ab.txt, A/B on one box): 14B k_att 19.0 -> 18.0 us, token +1.5 %; at 3-4 KiB rows, where the ring
-// covers the prologue anyway and the first groups are the CARRIED ones, it loses 0.5 % (7B) / 3 % (3B) -- so: on for rows >= 5 KiB.
+// covers the prologue anyway, it loses 0.5 % (7B) / 3 % (3B) -- so: on for rows >= 5 KiB.
 #ifndef RWKV_EARLY_TAKE
 #define RWKV_EARLY_TAKE 2       // 0 off, 1 on, 2 by row size
 #endif
 template <int S> __device__ __forceinline__ constexpr bool early_take() { return RWKV_EARLY_TAKE == 1 || (RWKV_EARLY_TAKE == 2 && S >= 5); }
 // the consumer waves' streaming loop (wave < NC): same pre / epi contract as stream_groups; ready() = wait until the vectors are staged
 // and fetch the scalars the epilogues need (called once, by every wave)
-// CARRIED = the kernel's carry instance: its first groups may have been sitting in LDS since the previous kernel and are only to be used
-// once carry_verify has checked (and repaired) them -- which the staging waves learn in ready(), BEHIND an early take.  The two are
-// never combined by the defaults (carry at 3-4 KiB rows, early take from 5 KiB), and a build that forces both (-DRWKV_EARLY_TAKE=1
-// with RWKV_CARRY > 0) gets the early take switched off in the carry instances instead of unverified rows.
-template <int R, int S, int PAT, bool CARRIED = false, class Pre, class Epi, class Ready>
+template <int R, int S, int PAT, class Pre, class Epi, class Ready>
 __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsigned char *ring, GldsCtl *ctl, const unsigned *xq, int lane, int wave,
-                                            int chunks, Pre pre, Epi epi, Ready ready, unsigned &fail, unsigned long long *g_tl_groups = nullptr, int pos0 = 0,
-                                            const CarryCheck &ck = CarryCheck{})
+                                            int chunks, Pre pre, Epi epi, Ready ready, unsigned &fail, unsigned long long *g_tl_groups = nullptr)
 {
 #ifdef RWKV_TL_GROUPS
     // debug build (tools/timeline.py): where a consumer wave's time goes.  Stamps of the wave: 1 inputs of its first group requested,
@@ -1290,13 +1099,9 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
     int rr = 0;
 #endif
     constexpr int NWP = NT / 2 / 64;
-    constexpr bool ET = early_take<S>() && !CARRIED;
+    constexpr bool ET = early_take<S>();
     bool first = true;
     if (!ET) { ready(); first = false; }
-    // (`carried` was set by the loader in front of the order barrier, ready() is behind it; read ONCE: a look into LDS per group would put a
-    // round trip under the loader's stream on every group's path)
-    int ncar = 0;
-    if constexpr (CARRIED && RWKV_CARRY_VERIFY == 1) ncar = __builtin_amdgcn_readfirstlane((int)ctl->carried);
     const bool late_pre = ET && wave >= NWP;       // the waves that take their first group before the vectors are staged
     for (int g = g0 + (ET ? (wave + NC - NWP) % NC : wave); g < g1; g += NC) {
         decltype(pre(g)) in;
@@ -1305,37 +1110,19 @@ __device__ __forceinline__ void ring_groups(int g0, int g1, int nu, const unsign
         if (rr == 0) tl_stamp(g_tl_groups, 1);
 #endif
         u32x4 w[R][S];
-        glds_take<R, S>(w, g - g0, nu, ring, ctl, lane, fail, pos0);
+        glds_take<R, S>(w, g - g0, nu, ring, ctl, lane, fail);
         if (first) { ready(); if (late_pre) in = pre(g); first = false; }
-        if constexpr (CARRIED && RWKV_CARRY_VERIFY == 1) {
-            if (g - g0 < ncar) carry_check_taken<R, S>(w, g - g0, ck, ctl, lane);
-        }
 #ifdef RWKV_TL_GROUPS
         asm volatile("" : "+v"(w[R - 1][S - 1]));
         if (rr < 1) tl_stamp(g_tl_groups, 2);
 #endif
         unsigned long long T[R];
-#ifdef RWKV_RING_NODOT      // experiment (WRONG results): what the dot products and reductions cost
-#pragma unroll
-        for (int r = 0; r < R; r++) T[r] = (unsigned long long)__builtin_amdgcn_readfirstlane((int)w[r][0][0]);
-#elif defined(RWKV_RING_TAILSKIP)   // experiment (WRONG results): an upper bound on what ANY shortening of the last groups' work could buy --
-        // the last RWKV_RING_TAILSKIP groups of the workgroup are taken but not multiplied
-        if (g >= g1 - RWKV_RING_TAILSKIP) {
-#pragma unroll
-            for (int r = 0; r < R; r++) T[r] = (unsigned long long)__builtin_amdgcn_readfirstlane((int)w[r][0][0]);
-        } else group_dot<R, S, PAT, false>(w, xq, lane, T, nullptr, 0, chunks, false);
-#else
         group_dot<R, S, PAT, false>(w, xq, lane, T, nullptr, 0, chunks, false);
-#endif
 #ifdef RWKV_TL_GROUPS
         asm volatile("" : "+s"(T[R - 1]));
         if (rr < 1) tl_stamp(g_tl_groups, 4);
 #endif
-#if defined(RWKV_RING_TAILSKIP) && RWKV_RING_TAILSKIP_EPI
-        if (g < g1 - RWKV_RING_TAILSKIP) epi(g, T, in);
-#elif !defined(RWKV_RING_NOEPI)     // experiment (WRONG results): what the epilogues cost
         epi(g, T, in);
-#endif
 #ifdef RWKV_TL_GROUPS
         if (rr < 1) tl_stamp(g_tl_groups, 3);
         rr++;
@@ -1350,7 +1137,7 @@ __device__ __forceinline__ void ring_init(GldsCtl *gc)
 }
 // LayerNorm-site prologue of a ring kernel, called by the consumer waves (wave < NC): waves 0..3 stage the NV vectors and
 // publish the scalars, the others wait; contains the workgroup's order barrier, which the loader executes once as well
-template <int NV, int S, int RC = 0>
+template <int NV, int S>
 __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &dy, const double *x, int D, double *red, unsigned *xq,
                                           bool publish_stats, GldsCtl *gc, unsigned long long *tl, unsigned &fail)
 {
@@ -1394,9 +1181,9 @@ __device__ __forceinline__ void ring_site(const SiteStatic &st, const SiteDyn &d
         __syncthreads();   // order
     }
 }
-// ... and its second half, run by every consumer wave inside its first group (ring_groups' ready()): the vectors are staged, the
-// carried rows checked (and repaired); the scalars of the site come out of LDS
-template <int NV, int RC>
+// ... and its second half, run by every consumer wave inside its first group (ring_groups' ready()): the vectors are staged; the
+// scalars of the site come out of LDS
+template <int NV>
 __device__ __forceinline__ void ring_site_ready(double *red, GldsCtl *gc, SiteRed<NV> &sr, unsigned &fail, unsigned long long *tl)
 {
     constexpr int NWP = NT / 2 / 64;
@@ -1408,7 +1195,7 @@ __device__ __forceinline__ void ring_site_ready(double *red, GldsCtl *gc, SiteRe
     tl_stamp(tl, 5);
 }
 // plain-vector prologue of a ring kernel (k_attout, k_ffnv), same roles
-template <int NVEC, int S, int RC = 0>
+template <int NVEC, int S>
 __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, const float *partM, int n_part, int D, double *red, unsigned *xq,
                                          GldsCtl *gc, unsigned long long *tl, unsigned &fail)
 {
@@ -1457,7 +1244,6 @@ __device__ __forceinline__ void ring_vec(const float *vec, const double *partS, 
         __syncthreads();   // order
     }
 }
-template <int RC>
 __device__ __forceinline__ void ring_vec_ready(double *red, GldsCtl *gc, float &Sf, float &amax, unsigned &fail, unsigned long long *tl)
 {
     constexpr int NWP = NT / 2 / 64;
@@ -1519,7 +1305,6 @@ struct AttArgs {
     SiteDyn dy;
     const uint8_t *w;                     // [D][3][D] u8: rows K_i, V_i, R_i of channel i
     const unsigned *rs;                   // [D][3] row sums of w (for the 2^22 limb offset)
-    const unsigned *rw;                   // [D][3] position-weighted row sums (check of rows carried in LDS, carry_verify)
     const double *uw, *ew;                // precomputed bonus+decay and exp(decay), [D]
     const float *r_att, *o_att;           // att_out scale / offset (to pre-scale the gated wkv)
     double *saa, *sbb;                    // state arrays [slots][L][D], already offset to this layer
@@ -1532,7 +1317,6 @@ struct AttArgs {
     int ns;                               // ring kernels: LDS slots
     unsigned long long *tl;               // optional phase timeline (see tl_stamp)
     unsigned *herr;                       // ring kernels: the context's error word (raise_error)
-    RingCarry cy;                         // ring kernels: the stream across the kernel boundary
 };
 
 // ln1 site -> K,V,R dequant-GEMV -> WKV (rwkv.cu:535-545; kernels :351-392, :58-100, :221-259)
@@ -1594,23 +1378,16 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
         }
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
-    GldsCtl *gcc = nullptr;    // carry instances: the ring's control block and the next ring kernel's expected sums (carry_next_sums), left there
-    unsigned nx = 0u;          // behind the closing barrier
     if constexpr (RING) {
-        constexpr bool CARRY = RING == 2;      // the stream crosses the kernel boundaries (kernels.hip.h "CARRY"): common ring geometry
-        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : 3 * S * 3072));
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 3 * S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            fail = glds_loader<3, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
+            fail = glds_loader<3, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
-            constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 3 : 0;
-            ring_site<3, S, RC>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail);
-            const CarryCheck ck{chunks, g0, 3, a.w, a.cy.hits};
-            gcc = gc;
-            if (CARRY && wave == CARRY_SUMS_WAVE) nx = carry_next_sums(a.cy, lane);      // the next ring kernel's expected sums: nothing waits for them
-            auto ready = [&]() { SiteRed<3> sr; ring_site_ready<3, RC>(red, gc, sr, fail, a.tl); scalars(sr); };
-            ring_groups<3, S, PAT_PER_ROW, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0, ck);
+            ring_site<3, S>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail);
+            auto ready = [&]() { SiteRed<3> sr; ring_site_ready<3>(red, gc, sr, fail, a.tl); scalars(sr); };
+            ring_groups<3, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl);
         }
     } else {
         u32x4 wA[3][S], wB[3][S];
@@ -1624,7 +1401,6 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
     }
     tl_stamp(a.tl, 6);
     __syncthreads();   // every wave is past its last read of the reduction scratch
-    if constexpr (RING == 2) { if (wave == CARRY_SUMS_WAVE) carry_leave_sums(a.cy, gcc, lane, nx); }
     block_sum_max(part, pmax, red + RED_PART);
     if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
     if constexpr (RING) ring_report(fail, a.herr);
@@ -1635,7 +1411,6 @@ __global__ __launch_bounds__(NT) void k_att(AttArgs a)
 struct AttOutArgs {
     const uint8_t *w;      // [D][D] u8 rows = output channels
     const unsigned *rs;    // [D] row sums
-    const unsigned *rw;    // [D] position-weighted row sums (carry_verify)
     const float *ybuf;     // [D] pre-scaled input vector
     const double *partS;   // [n_part] partial offset sums (n_part <= NT)
     const float *partM;    // [n_part] partial max |ybuf|
@@ -1653,7 +1428,6 @@ struct AttOutArgs {
     int ns;                // ring kernels: LDS slots
     unsigned long long *tl;
     unsigned *herr;
-    RingCarry cy;
 };
 
 // att_out dequant-GEMV + residual through f32 (rwkv.cu:548-553), R rows per group; commits state xy;
@@ -1709,23 +1483,16 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
         }
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
-    GldsCtl *gcc = nullptr;    // carry instances: the ring's control block and the next ring kernel's expected sums (carry_next_sums), left there
-    unsigned nx = 0u;          // behind the closing barrier
     if constexpr (RING) {
-        constexpr bool CARRY = RING == 2;      // (needs D % R == 0: no overlapping last group)
-        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : S * 3072));
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            fail = glds_loader<R, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
+            fail = glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
-            constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? R : 0;
-            ring_vec<1, S, RC>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail);
-            const CarryCheck ck{chunks, g0, R, a.w, a.cy.hits};
-            gcc = gc;
-            if (CARRY && wave == CARRY_SUMS_WAVE) nx = carry_next_sums(a.cy, lane);      // the next ring kernel's expected sums: nothing waits for them
-            auto ready = [&]() { ring_vec_ready<RC>(red, gc, Sf, amax, fail, a.tl); sc = scale_of(amax); };
-            ring_groups<R, S, PAT_SHARED, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, nullptr, CARRY ? a.cy.pos0 : 0, ck);
+            ring_vec<1, S>(a.ybuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail);
+            auto ready = [&]() { ring_vec_ready(red, gc, Sf, amax, fail, a.tl); sc = scale_of(amax); };
+            ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, nullptr);
         }
     } else {
         u32x4 wA[R][S], wB[R][S];
@@ -1737,7 +1504,6 @@ __global__ __launch_bounds__(NT) void k_attout(AttOutArgs a)
         stream_groups<R, S, PAT_SHARED, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base, pre, epi);
     }
     __syncthreads();   // every wave is past its last read of the reduction scratch (and of the staged vector / the ring)
-    if constexpr (RING == 2) { if (wave == CARRY_SUMS_WAVE) carry_leave_sums(a.cy, gcc, lane, nx); }
     tl_stamp(a.tl, 6);
     site_publish<2, R>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
     if constexpr (RING) ring_report(fail, a.herr);
@@ -1751,7 +1517,6 @@ struct FfnRKArgs {
     SiteDyn dy;
     const uint8_t *w;                 // [D][5][D]: rows ffn_k out 4i..4i+3, then ffn_r out i
     const unsigned *rs;               // [D][5] row sums
-    const unsigned *rw;               // [D][5] position-weighted row sums (carry_verify)
     const float *r_fv, *o_fv;         // ffn_v scale / offset [4D]
     float *hbuf;                      // [4D] relu^2(k) * r_fv
     float *rgate;                     // [D] sigmoid(r)
@@ -1762,7 +1527,6 @@ struct FfnRKArgs {
     int ns;                           // ring kernels: LDS slots
     unsigned long long *tl;           // optional phase timeline (see tl_stamp)
     unsigned *herr;
-    RingCarry cy;
 };
 
 // ln2 site -> ffn_r GEMV + sigmoid, ffn_k GEMV + relu^2 (rwkv.cu:557-573)
@@ -1814,23 +1578,16 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
         }
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
-    GldsCtl *gcc = nullptr;    // carry instances: the ring's control block and the next ring kernel's expected sums (carry_next_sums), left there
-    unsigned nx = 0u;          // behind the closing barrier
     if constexpr (RING) {
-        constexpr bool CARRY = RING == 2;      // the stream crosses the kernel boundaries (kernels.hip.h "CARRY"): common ring geometry
-        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : 2 * S * 3072));
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 2 * S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            fail = glds_loader<5, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
+            fail = glds_loader<5, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
-            constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 5 : 0;
-            ring_site<2, S, RC>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail);
-            const CarryCheck ck{chunks, g0, 5, a.w, a.cy.hits};
-            gcc = gc;
-            if (CARRY && wave == CARRY_SUMS_WAVE) nx = carry_next_sums(a.cy, lane);      // the next ring kernel's expected sums: nothing waits for them
-            auto ready = [&]() { SiteRed<2> sr; ring_site_ready<2, RC>(red, gc, sr, fail, a.tl); scalars(sr); };
-            ring_groups<5, S, PAT_FFN_RK, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0, ck);
+            ring_site<2, S>(a.st, a.dy, a.x, D, red, xq, true, gc, a.tl, fail);
+            auto ready = [&]() { SiteRed<2> sr; ring_site_ready<2>(red, gc, sr, fail, a.tl); scalars(sr); };
+            ring_groups<5, S, PAT_FFN_RK>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl);
         }
     } else {
         u32x4 wA[5][S], wB[5][S];
@@ -1844,7 +1601,6 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
     }
     tl_stamp(a.tl, 6);
     __syncthreads();   // every wave is past its last read of the reduction scratch
-    if constexpr (RING == 2) { if (wave == CARRY_SUMS_WAVE) carry_leave_sums(a.cy, gcc, lane, nx); }
     block_sum_max(part, pmax, red + RED_PART);
     if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
     if constexpr (RING) ring_report(fail, a.herr);
@@ -1855,7 +1611,6 @@ __global__ __launch_bounds__(NT) void k_ffn_rk(FfnRKArgs a)
 struct FfnVArgs {
     const uint8_t *w;      // [D][4D] u8: row i = output channel i, as 4 quarter-rows of D bytes
     const unsigned *rs;    // [D] row sums (whole 4D row)
-    const unsigned *rw;    // [D] position-weighted sums of the row's four quarter-rows (carry_verify)
     const float *hbuf;     // [4D] pre-scaled hidden vector
     const double *partS;
     const float *partM;    // [n_part] partial max |hbuf|
@@ -1874,7 +1629,6 @@ struct FfnVArgs {
     int ns;                // ring kernels: LDS slots
     unsigned long long *tl;
     unsigned *herr;
-    RingCarry cy;
 };
 
 // ffn_v dequant-GEMV, x += v * sigmoid(r) (rwkv.cu:574-577); commits state dd; opens the next site
@@ -1919,23 +1673,16 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
         }
     };
     unsigned fail = 0u;        // a bounded wait of this wave gave up (wait_count)
-    GldsCtl *gcc = nullptr;    // carry instances: the ring's control block and the next ring kernel's expected sums (carry_next_sums), left there
-    unsigned nx = 0u;          // behind the closing barrier
     if constexpr (RING) {
-        constexpr bool CARRY = RING == 2;      // the stream crosses the kernel boundaries (kernels.hip.h "CARRY"): common ring geometry
-        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + (CARRY ? a.cy.xq_bytes : 4 * S * 3072));
+        GldsCtl *gc = reinterpret_cast<GldsCtl *>(smem + RED_BYTES + 4 * S * 3072);
         unsigned char *ring = reinterpret_cast<unsigned char *>(gc + 1);
         if (wave == NC) {
-            fail = glds_loader<4, S, CARRY>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane, a.cy);
+            fail = glds_loader<4, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
             tl_stamp(a.tl, 2);
         } else {
-            constexpr int RC = CARRY && RWKV_CARRY_VERIFY ? 4 : 0;
-            ring_vec<4, S, RC>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail);
-            const CarryCheck ck{chunks, g0, 1, a.w, a.cy.hits};
-            gcc = gc;
-            if (CARRY && wave == CARRY_SUMS_WAVE) nx = carry_next_sums(a.cy, lane);      // the next ring kernel's expected sums: nothing waits for them
-            auto ready = [&]() { ring_vec_ready<RC>(red, gc, Sf, amax, fail, a.tl); sc = scale_of(amax); };
-            ring_groups<4, S, PAT_PER_ROW, CARRY>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl, CARRY ? a.cy.pos0 : 0, ck);
+            ring_vec<4, S>(a.hbuf, a.partS, a.partM, a.n_part, D, red, xq, gc, a.tl, fail);
+            auto ready = [&]() { ring_vec_ready(red, gc, Sf, amax, fail, a.tl); sc = scale_of(amax); };
+            ring_groups<4, S, PAT_PER_ROW>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail, a.tl);
         }
     } else {
         u32x4 wA[4][S], wB[4][S];
@@ -1947,7 +1694,6 @@ __global__ __launch_bounds__(NT) void k_ffnv(FfnVArgs a)
         stream_groups<4, S, PAT_PER_ROW, NB>(wA, wB, gA, gB, g0, g1, gctr, xq, lane, (size_t)D, chunks, base, pre, epi);
     }
     __syncthreads();   // every wave is past its last read of the reduction scratch
-    if constexpr (RING == 2) { if (wave == CARRY_SUMS_WAVE) carry_leave_sums(a.cy, gcc, lane, nx); }
     tl_stamp(a.tl, 6);
     site_publish<NVN, 1>(acc, a.dy, xq);   // the staged vector is dead: its LDS is the scratch
     if constexpr (RING) ring_report(fail, a.herr);
@@ -2025,7 +1771,7 @@ __global__ __launch_bounds__(NT) void k_head(HeadArgs a)
             fail = glds_loader<R, S>(base, g0, g1, (size_t)D, chunks, a.ns, lds_addr(ring), gc, lane);
         } else {
             ring_site<1, S>(a.st, a.dy, a.x, D, red, xq, false, gc, nullptr, fail);
-            auto ready = [&]() { SiteRed<1> sr; ring_site_ready<1, 0>(red, gc, sr, fail, nullptr); Sf = (float)sr.S[0]; sc = scale_of(sr.amax[0]); };
+            auto ready = [&]() { SiteRed<1> sr; ring_site_ready<1>(red, gc, sr, fail, nullptr); Sf = (float)sr.S[0]; sc = scale_of(sr.amax[0]); };
             ring_groups<R, S, PAT_SHARED>(g0, g1, a.ns, ring, gc, xq, lane, wave, chunks, pre, epi, ready, fail);
         }
     } else {
@@ -2079,84 +1825,6 @@ __global__ void k_argmax_finish(const float *blk_val, const unsigned *blk_idx, i
 }
 
 // ------------------------------------------------------------------------------------------
-// Stand-alone dequant-GEMV on the same row engine (unit tests; the kernel behind
-// cudac_mm8_one, rwkv.cu:267-311).  w_t is the re-tiled [M][N] matrix, rs its row sums.
-// N <= 5120: rows whole; otherwise N = 4*Dq and rows are processed as 4 quarter-rows (ffn_v shape).
-struct Mm8Args {
-    const uint8_t *w_t;
-    const unsigned *rs;
-    const float *x, *r, *o;
-    float *y;
-    int N, M;
-};
-template <int S, bool QUARTERS>
-__global__ __launch_bounds__(NT) void k_mm8(Mm8Args a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XVD = xvd<S>();
-    constexpr int NQ = nquads<S>();
-    constexpr int R = 4;
-    constexpr int NVQ = QUARTERS ? 4 : 1;
-    double *red = reinterpret_cast<double *>(smem);
-    unsigned *xq = reinterpret_cast<unsigned *>(smem + RED_BYTES);
-    const int lane = threadIdx.x & 63, wave = wave_id();
-    const int Dq = QUARTERS ? a.N / 4 : a.N;
-    const int chunks = Dq >> 4, nqd = Dq >> 2;
-    const int M = a.M;
-    const int G = QUARTERS ? M : (M + R - 1) / R;
-    const int g0 = block_lo(G);
-    const int g1 = block_hi(G);
-
-    double Ssum[1] = {0.0};
-    float amax[1] = {0.f};
-    float xr[NVQ][NQ][4];
-#pragma unroll
-    for (int q = 0; q < NVQ; q++)
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-            const int qd = threadIdx.x + i * NT;
-            const bool real = qd < nqd;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int j = q * Dq + (real ? qd : 0) * 4 + e;
-                const float f = a.x[j];
-                xr[q][i][e] = f * a.r[j];
-                if (real) { Ssum[0] += (double)(f * a.o[j]); amax[0] = fmaxf(amax[0], fabsf(xr[q][i][e])); }
-            }
-        }
-    block_max<1>(amax, red + RED_MAX);
-#pragma unroll
-    for (int q = 0; q < NVQ; q++)
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-            const int qd = threadIdx.x + i * NT;
-            if (qd < S * 256) stage_quad(xq + q * XVD, qd, xr[q][i], inv_scale(amax[0]), qd < nqd);
-        }
-    block_sum<1>(Ssum, red + RED_OFFS);
-    const float Sf = (float)Ssum[0];
-    const double sc = scale_of(amax[0]);
-
-    for (int g = g0 + wave; g < g1; g += NW) {
-        u32x4 w[R][S];
-        unsigned long long T[R];
-        if (QUARTERS) {
-            group_load<R, S, 0, S>(w, a.w_t + (size_t)g * a.N, (size_t)Dq, chunks, lane);
-            group_dot<R, S, PAT_PER_ROW>(w, xq, lane, T, a.w_t, 0, chunks, false);
-            if (lane == 0) a.y[g] = row_value((T[0] + T[1]) + (T[2] + T[3]), a.rs[g], sc) + Sf;
-        } else {
-            int row0 = g * R;
-            const int shift = (row0 > M - R) ? row0 - (M - R) : 0;
-            row0 -= shift;
-            group_load<R, S, 0, S>(w, a.w_t + (size_t)row0 * a.N, (size_t)a.N, chunks, lane);
-            group_dot<R, S, PAT_SHARED>(w, xq, lane, T, a.w_t, 0, chunks, false);
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                if (lane == r && r >= shift) a.y[row0 + r] = row_value(T[r], a.rs[row0 + r], sc) + Sf;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Load-time re-tile: file layout src[N][M] (output index k contiguous, rwkv.cu:290 indexing
 // w[j*M + k]) -> row-per-output dst[row(k)][N] with row(k) = (k/G)*RS + k%G + off.
 __global__ void k_retile(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int N, int M,
@@ -2179,26 +1847,22 @@ __global__ void k_retile(const uint8_t *__restrict__ src, uint8_t *__restrict__ 
     }
 }
 
-// row sums of a re-tiled matrix: rs[row] = sum_j w_t[row][j]; one wave per row (load time).  rw != nullptr: also the
-// position-weighted sum that carry_verify checks rows carried in LDS against -- over the row's units of `unit` bytes (the ring's
-// unit: D bytes; an ffn_v row is four of them), piece c of a unit weighted (c + 1), byte i of a piece (1 + i), modulo 2^32
-__global__ void k_rowsum(const uint8_t *__restrict__ w_t, unsigned *__restrict__ rs, unsigned *__restrict__ rw, size_t rows, int N, int unit)
+// row sums of a re-tiled matrix: rs[row] = sum_j w_t[row][j]; one wave per row (load time)
+__global__ void k_rowsum(const uint8_t *__restrict__ w_t, unsigned *__restrict__ rs, size_t rows, int N)
 {
     const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const u32x4 *p = reinterpret_cast<const u32x4 *>(w_t + row * (size_t)N);
-    const int upc = unit >> 4;
-    unsigned acc = 0, wacc = 0;
+    unsigned acc = 0;
     for (int c = lane; c < (N >> 4); c += 64) {
         const u32x4 v = p[c];
 #pragma unroll
         for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_udot4(v[q], 0x01010101u, acc, false);
-        wacc += ck_piece(v, c % upc);
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { acc += __shfl_xor(acc, m, 64); wacc += __shfl_xor(wacc, m, 64); }
-    if (lane == 0) { rs[row] = acc; if (rw) rw[row] = wacc; }
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) rs[row] = acc;
 }
 
 // uw = bonus + decay, ew = exp(decay)   (constants of rwkv.cu:247-252, hoisted out of the token loop)

@@ -16,7 +16,7 @@
 //     so a wave's weight load is one contiguous 1 KiB and needs no cross-lane transposition (7 GB more at 7B of 288 GB);
 //   * every row of an activation vector is quantised per OCTANT (an eighth of K, whole k-blocks) with the octant's own
 //     exact max|.|: no workgroup needs a row-wide maximum, and the scales are finer than one per row;
-//   * k_seq_gemm (K/V/R, att_out, ffn k/r, ffn_v): K-SLICE j = octant j runs on XCD j (blockIdx % 8, so the 32 workgroups
+//   * k_seq_gemm_p / k_seq_gemm_b (K/V/R, att_out, ffn k/r, ffn_v): K-SLICE j = octant j runs on XCD j (blockIdx % 8, so the 32 workgroups
 //     of an XCD read the SAME slice of the activation image through their L2 and every workgroup reads an eighth of it);
 //     a workgroup = a block of row tiles x one slice, each wave owns NTW row tiles for the whole slice, ALL its weight
 //     loads (NTW x k-blocks KiB) are requested up front, the slice's activation image goes through LDS once for all 8 waves;
@@ -555,10 +555,10 @@ struct SeqGemmArgs {
     int vec_of_q[5];             // activation vector each class multiplies (non-decreasing in q)
     const u32x4 *img[3];         // A-operand images of the vectors
     const SeqPart *part;         // quantisation records [NV][T][SEQ_O]
-    float *pk;                   // k_seq_gemm: per-slice partial values, accumulator image (pk_index)
+    float *pk;                   // k_seq_gemm_p / _b: per-slice partial values, accumulator image (pk_index)
     float *out;                  // k_seq_gemm_ks: [T][N]
     int T;
-    int ntw;                     // k_seq_gemm: row tiles per wave in use (<= the template's NTW)
+    int ntw;                     // k_seq_gemm_p: row tiles per wave in use (<= the template's NTW)
     const double *cp_src;        // piggy-back copy (stream-ordered behind the site kernel that produced it): the chunk's
     double *cp_dst;              // last LayerNorm output -> recurrent state; cp_n == 0: none
     int cp_n;
@@ -569,7 +569,6 @@ struct SeqGemmArgs {
 };
 constexpr int SEQ_NT = 512;      // GEMM workgroup: 8 waves, two per SIMD
 // dynamic LDS of the GEMM kernels
-constexpr size_t seq_gemm_smem(int ntw, int nkb, bool mts, int nvs) { return (size_t)((!mts && ntw * nkb <= 16) ? 2 : 1) * nvs * nkb * 384 * 16 + (size_t)nvs * SEQ_T * 16; }
 constexpr size_t seq_gemm_p_smem(int nkb, int nvs, bool multi, int nh = 1) { return (size_t)(multi ? 2 : 1) * nh * nvs * nkb * 384 * 16 + (size_t)nh * nvs * SEQ_T * 16; }
 constexpr int SEQ_TB = 5;        // weight tiles (16 rows each) per workgroup pass of k_seq_gemm_ks
 constexpr size_t SEQ_KS_SMEM = sizeof(float) * SEQ_O * SEQ_TB * 2 * 4 * 64 + sizeof(float) * SEQ_T;
@@ -581,234 +580,16 @@ __device__ __forceinline__ double seq_slice_value(const SeqPart &rc, double M, u
     return scale_of(rc.amax) * (M + rc.cA + SEQ_CU * (double)rs);
 }
 
-// "tile per wave, K over the XCDs": workgroup (rb, j): j = blockIdx % 8 = K-slice = octant (and the XCD the workgroup is
-// dispatched to), rb = block of 8 * ntw row tiles; wave w owns tiles (rb * 8 + w) * ntw + i for the whole slice.
-// NTW: tiles per wave (registers), NKB: k-blocks of a slice per chunk (registers, LDS); MTS: the two row tiles of the chunk one
-// after the other (halves the accumulators; single-chunk slices only), else both at once; NVS: activation vectors the
-// tiles of one workgroup may span (LDS).
-// Slices longer than NKB k-blocks (ffn_v: K = 4D) run in chunks: the activation image of chunk c + 1 is requested while
-// chunk c multiplies and the weights of chunk c + 1 go into a second register set.
-template <int TAG, int NTW, int NKB, bool MTS, int NVS>
-__global__ __launch_bounds__(SEQ_NT) void k_seq_gemm(SeqGemmArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    carry_kill_stamps(smem, (unsigned)seq_gemm_smem(NTW, NKB, MTS, NVS));
-    __syncthreads();      // (in front of this kernel's own copies into the same places)
-    constexpr bool DB = !MTS && NTW * NKB <= 16;        // second weight register set + second LDS buffer
-    constexpr int CHU = NVS * NKB * 384;                // units of one LDS buffer: [vector][k][row tile][limb][lane]
-    u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
-    double *recl = reinterpret_cast<double *>(smem + (size_t)(DB ? 2 : 1) * CHU * 16);   // [NVS][SEQ_T]{scale, cA} of this slice
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    tl_stamp(a.tl, 0);
-    // in flight per wave at the worst moment: record + row sums, the wave's share of the activation DMA, its weight loads
-    // (x 2 register sets when double-buffered) -- the vmcnt counter has 6 bits
-    static_assert(1 + NTW + (NVS * NKB * 6 + SEQ_NW - 1) / SEQ_NW + (DB ? 2 : 1) * NTW * NKB <= 63, "k_seq_gemm: more than 63 vector memory operations in flight");
-    const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
-    const int nch = (N + Q - 1) / Q, CB = (nch + 15) >> 4, ntiles = Q * CB;
-    const int j = blockIdx.x % SEQ_O, rb = blockIdx.x / SEQ_O;
-    const int kb0 = (int)(((long long)j * KB) / SEQ_O), kb1 = (int)(((long long)(j + 1) * KB) / SEQ_O);
-    const int nkb = kb1 - kb0, nchunk = (nkb + NKB - 1) / NKB;
-    if (blockIdx.x == gridDim.x - 1)
-        for (int q = threadIdx.x; q < a.cp_n; q += SEQ_NT) a.cp_dst[q] = a.cp_src[q];
-    const int ntw = a.ntw;
-    const int id0 = (rb * SEQ_NW + wave) * ntw;          // this wave's tiles: id0 .. id0 + ntw - 1
-    const int wg0 = rb * SEQ_NW * ntw, wg1 = min(wg0 + SEQ_NW * ntw, ntiles) - 1;
-    const int vlo = a.vec_of_q[min(wg0, ntiles - 1) / CB], vhi = a.vec_of_q[max(wg1, 0) / CB];
-
-    // Nothing below waits for memory until the operands of the first MFMA are due: the kernel used to be a chain of ~25
-    // dependent round trips (record, row sums, the weights, then the activation image 16 bytes per thread at a time).
-    // the slice's quantisation records of the vectors this workgroup multiplies: requested now, written to LDS behind the
-    // activation image, used by the epilogue
-    SeqPart rc;
-    {
-        const int tr = threadIdx.x < NVS * SEQ_T ? (int)threadIdx.x : 0;
-        const int v = min(vlo + tr / SEQ_T, vhi), t = tr % SEQ_T;
-        rc = a.part[((size_t)v * SEQ_T + t) * SEQ_O + j];
-    }
-    const u32x4 *wt[NTW];
-    int vi[NTW];
-    bool tv[NTW];
-    unsigned rsv[NTW];          // row sum (this octant) of the row this lane finishes in tile i (rows past the end: some row's; never read back)
-#pragma unroll
-    for (int i = 0; i < NTW; i++) {
-        const int id = id0 + i;
-        tv[i] = i < ntw && id < ntiles;
-        const int idc = tv[i] ? id : 0;
-        {
-            const int q = idc / CB, ch = 16 * (idc % CB) + (lane & 15), row = Q * ch + q;
-            rsv[i] = a.rs8[(size_t)j * N + ((ch < nch && row < N) ? row : 0)];     // branch-free: a predicated load is waited for where it joins
-        }
-        wt[i] = a.bimg + ((size_t)idc * KB) * 64 + lane;
-        vi[i] = a.vec_of_q[idc / CB] - vlo;
-        vi[i] = vi[i] < 0 ? 0 : (vi[i] >= NVS ? NVS - 1 : vi[i]);
-        vi[i] = __builtin_amdgcn_readfirstlane(vi[i]);   // wave-uniform by construction
-    }
-    auto kclamp = [&](int c, int k) { const int n = min(NKB, nkb - c * NKB); return kb0 + c * NKB + (k < n ? k : (n > 0 ? n - 1 : 0)); };
-    u32x4 bw[DB ? 2 : 1][NTW][NKB];
-    // MTS kernels (ffn k/r: two passes over the row tiles with the weights resident) work through their tiles in TWO BATCHES,
-    // [0, TB0) and [TB0, NTW): the loads are requested batch-major, so batch 0's second pass, epilogue and partial-value stores run
-    // under batch 1's weight stream instead of behind the whole stream (RWKV_SEQ_BATCH=0: one batch, as in round 2)
-#ifndef RWKV_SEQ_BATCH
-#define RWKV_SEQ_BATCH 1
-#endif
-    constexpr int TB0 = (RWKV_SEQ_BATCH && NTW >= 3) ? (NTW + 1) / 2 : NTW;        // (K/V/R, three tiles per wave and both row tiles at once: 2 + 1)
-    auto load_b = [&](int set, int c) {
-#pragma unroll
-        for (int bt = 0; bt < 2; bt++)
-#pragma unroll
-            for (int k = 0; k < NKB; k++)
-#pragma unroll
-                for (int i = 0; i < NTW; i++)
-                    if ((i < TB0) == (bt == 0)) bw[set][i][k] = __builtin_nontemporal_load(wt[i] + (size_t)min(kclamp(c, k), KB - 1) * 64);
-    };
-    // activation image of chunk c, vectors vlo .. vhi: units [(kb0 + c NKB) * 384, + n * 384) of each image are contiguous --
-    // a straight copy, done by the DMA path (global_load_lds_dwordx4: 1 KiB per wave instruction, no registers, nothing to wait
-    // for until the barrier in front of the MFMAs).  Every workgroup of an XCD copies the same image slice: each starts at
-    // its own offset so that they do not all hit the same L2 channel at the same moment.
-    const unsigned abuf_lds = lds_addr(abuf);
-    auto stage_a = [&](int c, int buf) {
-        const int kbs = kb0 + c * NKB, n = min(NKB, nkb - c * NKB);
-        const int np = n * 6, rot = np > 0 ? (int)(((long long)(rb % 32) * np) / 32) : 0;      // pieces of 1 KiB per vector
-        for (int v = vlo; v <= vhi && v - vlo < NVS; v++) {
-            const uint8_t *src = reinterpret_cast<const uint8_t *>(a.img[v] + (size_t)kbs * 384) + lane * 16;
-            const unsigned dst = abuf_lds + (unsigned)(((size_t)buf * CHU + (size_t)(v - vlo) * NKB * 384) * 16);
-            for (int p0 = wave; p0 < np; p0 += SEQ_NW) {
-                int pc = p0 + rot;
-                pc = pc >= np ? pc - np : pc;
-                dma_piece(src + (size_t)pc * 1024, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)pc * 1024u)));
-            }
-        }
-    };
-    // the DMA above is older than the (<= NTW * NKB) weight loads issued after it: once no more than those are outstanding it
-    // has landed (loads complete in order); then the records go to LDS and the workgroup meets
-    auto staged = [&]() {
-        wait_vm<NTW * NKB>();
-        __syncthreads();
-    };
-    // unconditional (an empty slice copies nothing and loads clamped addresses): a branch here would make the compiler wait for
-    // the weights where the record is used -- its count of what may be in flight is the minimum over the paths that join
-    stage_a(0, 0); load_b(0, 0);
-    tl_stamp(a.tl, 1);
-    wait_vm<NTW * NKB>();
-    if (threadIdx.x < NVS * SEQ_T) { recl[2 * threadIdx.x] = scale_of(rc.amax); recl[2 * threadIdx.x + 1] = rc.cA; }
-    __syncthreads();
-    tl_stamp(a.tl, 2);
-
-    i32x4 acc[NTW][MTS ? 1 : 2][3];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < NTW; i++)
-#pragma unroll
-            for (int mt = 0; mt < (MTS ? 1 : 2); mt++)
-#pragma unroll
-                for (int b = 0; b < 3; b++) acc[i][mt][b] = i32x4{0, 0, 0, 0};
-    };
-    // per-slice value of tile i, row tile mt (accumulator set ms) -> pk, one coalesced 256-byte store per register
-    auto emit = [&](int mt, int ms, int i0 = 0, int i1 = NTW) {
-#pragma unroll
-        for (int i = 0; i < NTW; i++) {
-            if (i < i0 || i >= i1) continue;
-            if (!tv[i]) continue;
-            const int id = id0 + i;
-            const double *rl = recl + 2 * ((size_t)vi[i] * SEQ_T + mt * 16 + 4 * (lane >> 4));
-            float *dst = a.pk + pk_lane_base(ntiles, j, id, mt, lane);
-            const size_t rst = pk_rstride(ntiles);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double M = (double)acc[i][ms][0][r] + 256.0 * (double)acc[i][ms][1][r] + 65536.0 * (double)acc[i][ms][2][r];
-                dst[r * rst] = (float)(rl[2 * r] * (M + rl[2 * r + 1] + SEQ_CU * (double)rsv[i]));   // scale_o (M + cA_o + CU rowsum_o); rows / columns past the end are never read
-            }
-        }
-    };
-    // the MFMAs of chunk c (weights in register set `set`, activation image in LDS buffer `buf`) for row tile(s) mt0 ..
-    // The A fragments of a k-block are read from LDS once and kept while consecutive tiles use the same activation vector
-    // (a wave's tiles are class-ordered; the re-read at a class change is a wave-uniform branch).
-    auto mult = [&](int set, int buf, int c, int mt0, int i0 = 0, int i1 = NTW) {
-        const int n = min(NKB, nkb - c * NKB);
-        const u32x4 *ab = abuf + (size_t)buf * CHU + lane;
-#pragma unroll
-        for (int k = 0; k < NKB; k++) {
-            const bool kv = k < n;
-            u32x4 av[MTS ? 1 : 2][3];
-            auto read_a = [&](int vv) {
-#pragma unroll
-                for (int ms = 0; ms < (MTS ? 1 : 2); ms++)
-#pragma unroll
-                    for (int b = 0; b < 3; b++) av[ms][b] = ab[(((size_t)vv * NKB + k) * 2 + (MTS ? mt0 : ms)) * 3 * 64 + b * 64];
-            };
-            read_a(vi[i0]);
-#pragma unroll
-            for (int i = 0; i < NTW; i++) {
-                if (i < i0 || i >= i1) continue;
-                if (NVS > 1 && i > i0 && vi[i] != vi[i - 1]) read_a(vi[i]);
-                const u32x4 w = bw[set][i][k];
-                const i32x4 bf = i32x4{kv ? (int)w[0] : 0, kv ? (int)w[1] : 0, kv ? (int)w[2] : 0, kv ? (int)w[3] : 0};   // past the slice: zero weights
-#pragma unroll
-                for (int ms = 0; ms < (MTS ? 1 : 2); ms++)
-#pragma unroll
-                    for (int b = 0; b < 3; b++) {
-                        const i32x4 af = i32x4{(int)av[ms][b][0], (int)av[ms][b][1], (int)av[ms][b][2], (int)av[ms][b][3]};
-                        acc[i][ms][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[i][ms][b], 0, 0, 0);
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of the next k-block behind these MFMAs (register pressure)
-        }
-    };
-    if (MTS) {                        // single chunk: weights stay in registers for both row tiles
-        if (TB0 < NTW) {
-            for (int mt = 0; mt < 2; mt++) { zero_acc(); if (nchunk > 0) mult(0, 0, 0, mt, 0, TB0); emit(mt, 0, 0, TB0); }
-            tl_stamp(a.tl, 3);
-            for (int mt = 0; mt < 2; mt++) { zero_acc(); if (nchunk > 0) mult(0, 0, 0, mt, TB0, NTW); if (mt == 0) tl_stamp(a.tl, 4); emit(mt, 0, TB0, NTW); }
-        } else {
-            for (int mt = 0; mt < 2; mt++) {
-                zero_acc();
-                if (nchunk > 0) mult(0, 0, 0, mt);
-                emit(mt, 0);
-            }
-        }
-    } else if (!DB && TB0 < NTW && nchunk == 1) {          // one chunk, weights in registers: batch 0's epilogue under batch 1's stream
-        zero_acc();
-        mult(0, 0, 0, 0, 0, TB0);
-        emit(0, 0, 0, TB0); emit(1, 1, 0, TB0);
-        tl_stamp(a.tl, 3);
-        mult(0, 0, 0, 0, TB0, NTW);
-        tl_stamp(a.tl, 4);
-        emit(0, 0, TB0, NTW); emit(1, 1, TB0, NTW);
-    } else {
-        zero_acc();
-        for (int c = 0; c < nchunk; c++) {
-            const int cn = c + 1 < nchunk ? c + 1 : c;
-            if (DB) {
-                // next chunk: its activation image (one vector: att_out / ffn_v) straight into the other LDS buffer (whose readers
-                // passed the previous barrier), its weights into the other register set -- both under this chunk's MFMAs
-                if (c + 1 < nchunk) stage_a(c + 1, (c + 1) & 1);
-                if (c & 1) { load_b(0, cn); mult(1, 1, c, 0); } else { load_b(1, cn); mult(0, 0, c, 0); }
-                staged();
-            } else {
-                mult(0, 0, c, 0);
-                if (c + 1 < nchunk) {                     // one register set, one buffer: load, then multiply
-                    __syncthreads();
-                    stage_a(c + 1, 0); load_b(0, c + 1);
-                    staged();
-                }
-            }
-            if (c == 0) tl_stamp(a.tl, 3);
-        }
-        tl_stamp(a.tl, 4);
-        emit(0, 0);
-        emit(1, 1);
-    }
-    tl_stamp(a.tl, 5);
-}
-// ------------------------------------------------------------------------------------------
-// k_seq_gemm_p: the same GEMM as a SOFTWARE PIPELINE over the slice's k-blocks (round 3).  The phase timeline of k_seq_gemm
-// (tools/gemm_timeline.py, profiles/r03/gemm_timeline.txt) showed why it ran at 3.3 TB/s: a wave that requests all its weights up
-// front BLOCKS AT ISSUE (a CU's memory path holds ~16 KB of requests), the workgroup barrier behind the requests is reached when
-// three quarters of the stream have arrived (12.5 of 17 us for ffn k/r), and the MFMAs, the epilogue and the partial-value stores
-// run BEHIND the stream instead of under it.  Here a wave keeps DEPTH k-blocks of its NTW tiles in flight in a rolling register
-// buffer: step f requests block f + DEPTH - 1, waits for block f, multiplies it against both row tiles of the chunk (no second
-// pass: without the resident weights the accumulators of both fit).  Slices longer than NKB k-blocks (ffn_v: K = 4 D) re-stage
-// the activation image per NKB blocks into the other LDS buffer, requested at the head of the previous group of blocks.
+// k_seq_gemm_p -- "tile per wave, K over the XCDs": workgroup (rb, j): j = blockIdx % 8 = K-slice = octant (and the XCD the workgroup is
+// dispatched to), rb = block of 8 * ntw row tiles; wave w owns tiles (rb * 8 + w) * ntw + i for the whole slice.  NTW: tiles per wave
+// (registers), NKB: k-blocks of the slice's activation image resident in one LDS buffer, NVS: activation vectors the tiles of one
+// workgroup may span (LDS).  The K loop is a SOFTWARE PIPELINE over the slice's k-blocks (round 3; round 2's form requested a wave's whole
+// weight stream up front: a wave that does so BLOCKS AT ISSUE -- a CU's memory path holds ~16 KB of requests --, the barrier behind
+// the requests was reached when three quarters of the stream had arrived and the MFMAs, the epilogue and the partial-value stores ran
+// BEHIND the stream instead of under it: 3.3 TB/s, tools/gemm_timeline.py, profiles/r03/gemm_timeline.txt).  A wave keeps DEPTH
+// k-blocks of its NTW tiles in flight in a rolling register buffer: step f requests block f + DEPTH - 1, waits for block f, multiplies
+// it against both row tiles of the chunk.  Slices longer than NKB k-blocks (MULTI; ffn_v: K = 4 D) re-stage the activation image per
+// NKB blocks into the other LDS buffer, requested at the head of the previous group of blocks.
 // The weight loads are inline asm like the DMA: hipcc does not count asm in vmcnt, so its own waitcnt insertion would make every
 // wait for a weight block drain the DMA pieces requested behind it; all waits for them are explicit (in-order completion).
 __device__ __forceinline__ u32x4 load_b_asm(const u32x4 *p)
@@ -834,8 +615,6 @@ template <int TAG, int NTW, int NKB, int NVS, int DEPTH, bool MULTI, int NH = 1>
 __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    carry_kill_stamps(smem, (unsigned)seq_gemm_p_smem(NKB, NVS, MULTI, NH));
-    __syncthreads();      // (in front of this kernel's own copies into the same places)
     static_assert(NKB % DEPTH == 0, "the rolling buffer's slot of a k-block must be a compile-time value");
     constexpr int NBUF = MULTI ? 2 : 1;
     constexpr int CHU = NH * NVS * NKB * 384;           // units of one LDS buffer: [half][vector][k][row tile][limb][lane]
@@ -1064,8 +843,6 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_b(SeqGemmBArgs ba)
     const SeqGemmArgs &a = ba.g;
     const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
     const int nkbm = (KB + SEQ_O - 1) / SEQ_O;                    // longest slice
-    carry_kill_stamps(smem, (unsigned)seq_gemm_b_smem(nkbm, NH));
-    __syncthreads();      // (in front of this kernel's own copies into the same places)
     u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
     double *recl = reinterpret_cast<double *>(smem + (size_t)NH * nkbm * 384 * 16);   // [NH][SEQ_T]{scale, cA} of this slice
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1297,8 +1074,6 @@ __device__ __forceinline__ void seq_pass(i32x4 (&acc)[SEQ_TB][2][3], const u32x4
 __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_ks(SeqGemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    carry_kill_stamps(smem, (unsigned)SEQ_KS_SMEM);
-    __syncthreads();      // (this kernel does write the places it clears, later)
     float (*accl)[SEQ_TB][2][4][64] = reinterpret_cast<float (*)[SEQ_TB][2][4][64]>(smem);   // [octant][tile][row tile][reg][lane], 80 KiB
     float *sol = reinterpret_cast<float *>(smem + sizeof(float) * SEQ_O * SEQ_TB * 2 * 4 * 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1341,7 +1116,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_ks(SeqGemmArgs a)
         default: seq_pass<5, 2>(acc, wt, img, kb0, kb1, lane); break;
         }
         // this wave's octant: fold the limbs (exact in f64), scale with the octant's records; the octants meet in LDS as f32
-        // values and are added in a fixed order below (deterministic; the same arithmetic as k_seq_gemm's per-slice partials)
+        // values and are added in a fixed order below (deterministic; the same arithmetic as k_seq_gemm_p's per-slice partials)
 #pragma unroll
         for (int i = 0; i < SEQ_TB; i++)
             if (i < nt) {

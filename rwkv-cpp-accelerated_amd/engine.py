@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("RWKV_LIB") or os.path.join(_HERE, "csrc", "librwkv_mi
 MODE_PARRALEL, MODE_GPT = 0, 1   # reference enums/enum.h:2-5
 SAMPLE_BAN0, SAMPLE_RECIPE = 1, 2   # include/rwkv_mi355x.h
 N_KCLASS = 7
-ABI_VERSION = 5                   # RWKV_MI355X_ABI_VERSION of include/rwkv_mi355x.h
+ABI_VERSION = 6                   # RWKV_MI355X_ABI_VERSION of include/rwkv_mi355x.h
 KCLASS_NAMES = ["first", "att_kvr_wkv", "att_out", "ffn_rk", "ffn_v", "head", "argmax"]
 
 # every entry point declared in include/rwkv_mi355x.h (tests check the library exports all of them)
@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "rwkv_create", "rwkv_load_file", "rwkv_load_tensors", "rwkv_n_layers", "rwkv_n_embed", "rwkv_max_ctx",
     "rwkv_forward", "rwkv_set_state", "rwkv_get_output", "rwkv_reset_state", "rwkv_decode_greedy",
     "rwkv_free", "rwkv_last_error", "rwkv_logits_device", "rwkv_state_device", "rwkv_stream",
-    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_mm8_one", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_decode_form", "rwkv_debug_carry_hits", "rwkv_debug_carry_stats", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
+    "rwkv_bytes_per_token", "rwkv_profile_token", "rwkv_debug_launch", "rwkv_debug_read", "rwkv_debug_write", "rwkv_debug_grid", "rwkv_debug_timeline", "rwkv_profile_batched", "rwkv_abi_version", "rwkv_resident_bytes", "rwkv_decode_form", "rwkv_set_layer_range", "rwkv_stage_forward", "rwkv_x_device", "rwkv_sample_typical", "rwkv_decode_typical",
     "rwkv_stage_chunk", "rwkv_xseq_device", "rwkv_xseq_copy", "rwkv_sync", "rwkv_pipe_rccl_path", "rwkv_pipe_unique_id", "rwkv_pipe_init", "rwkv_pipe_decode", "rwkv_pipe_decode_streams", "rwkv_pipe_profile", "rwkv_pipe_hop_stats",
     "rwkv_pipe_prefill", "rwkv_pipe_free", "rwkv_tensor_device", "rwkv_pipe_info", "rwkv_pipe_decode_dual",
 ]
@@ -65,7 +65,10 @@ def lib():
     L.rwkv_stream.argtypes = [vp]; L.rwkv_stream.restype = vp
     L.rwkv_profile_token.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(C.c_uint32)]
     L.rwkv_profile_token.restype = i32
-    L.rwkv_mm8_one.argtypes = [vp, u64, u64, vp, vp, vp, vp, vp]; L.rwkv_mm8_one.restype = i32
+    L.rwkv_debug_launch.argtypes = [vp, i32, u64, u64, C.c_uint32]; L.rwkv_debug_launch.restype = i32
+    L.rwkv_debug_read.argtypes = [vp, i32, vp, u64]; L.rwkv_debug_read.restype = i32
+    L.rwkv_debug_write.argtypes = [vp, i32, vp, u64]; L.rwkv_debug_write.restype = i32
+    L.rwkv_debug_grid.argtypes = [vp]; L.rwkv_debug_grid.restype = u64
     L.rwkv_set_layer_range.argtypes = [vp, u64, u64]; L.rwkv_set_layer_range.restype = i32
     L.rwkv_stage_forward.argtypes = [vp, u64, C.c_uint32, C.POINTER(u64)]; L.rwkv_stage_forward.restype = i32
     L.rwkv_x_device.argtypes = [vp]; L.rwkv_x_device.restype = vp
@@ -74,10 +77,6 @@ def lib():
     L.rwkv_abi_version.argtypes = []; L.rwkv_abi_version.restype = i32
     L.rwkv_resident_bytes.argtypes = [vp]; L.rwkv_resident_bytes.restype = u64
     L.rwkv_decode_form.argtypes = [vp]; L.rwkv_decode_form.restype = i32
-    if hasattr(L, "rwkv_debug_carry_hits"):      # debug counters: absent from tuning variants built from older sources
-        L.rwkv_debug_carry_hits.argtypes = [vp, C.POINTER(u64)]; L.rwkv_debug_carry_hits.restype = i32
-    if hasattr(L, "rwkv_debug_carry_stats"):
-        L.rwkv_debug_carry_stats.argtypes = [vp, C.POINTER(u64)]; L.rwkv_debug_carry_stats.restype = i32
     if L.rwkv_abi_version() != ABI_VERSION:
         raise RWKVError(f"{LIB_PATH} has C-ABI version {L.rwkv_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
     L.rwkv_sample_typical.argtypes = [vp, u64, C.c_float, C.c_float, C.c_double, i32, C.POINTER(u64)]; L.rwkv_sample_typical.restype = i32
@@ -397,24 +396,28 @@ class RWKV:
         """Mask of the per-layer decode kernel classes that stream the tile image (bit 0 K/V/R, 1 att_out, 2 ffn k/r, 3 ffn_v)."""
         return int(lib().rwkv_decode_form(self._h))
 
-    def carry_hits(self):
-        """(found, not found): workgroup launches whose first weight rows were / were not waiting in LDS (needs RWKV_CARRY_COUNT=1 at load)"""
-        out = (C.c_uint64 * 2)()
-        _chk(lib().rwkv_debug_carry_hits(self._h, out))
-        return int(out[0]), int(out[1])
+    # ---- per-kernel parity hooks (include/rwkv_mi355x.h rwkv_debug_launch): the production decode kernels one launch at a time ----
+    DBG = dict(x=(0, np.float64), ybuf=(1, np.float32), part_att=(2, np.float64), pmax_att=(3, np.float32), hbuf=(4, np.float32),
+               rgate=(5, np.float32), part_ffn=(6, np.float64), pmax_ffn=(7, np.float32), lnstat=(8, np.float64))
 
-    def carry_stats(self):
-        """(found, not found, repaired) since the last call: workgroup launches whose first weight rows were / were not waiting in LDS, and
-        carried row groups re-loaded from memory after a failed check (kernels.hip.h carry_verify)"""
-        out = (C.c_uint64 * 3)()
-        _chk(lib().rwkv_debug_carry_stats(self._h, out))
-        return int(out[0]), int(out[1]), int(out[2])
+    def debug_launch(self, cls, layer=0, token=0, slot=0):
+        _chk(lib().rwkv_debug_launch(self._h, int(cls), int(layer), int(token), int(slot)))
 
-    def stream(self) -> int:
-        return int(lib().rwkv_stream(self._h) or 0)
+    def debug_grid(self):
+        return int(lib().rwkv_debug_grid(self._h))
 
-    def mm8_one(self, N, M, x_dev, w_dev, r_dev, o_dev, y_dev):
-        _chk(lib().rwkv_mm8_one(self._h, N, M, x_dev, w_dev, r_dev, o_dev, y_dev))
+    def debug_read(self, name):
+        which, dt = self.DBG[name]
+        D, G = self.num_embed, self.debug_grid()
+        n = dict(x=D, ybuf=D, part_att=G, pmax_att=G, hbuf=4 * D, rgate=D, part_ffn=G, pmax_ffn=G, lnstat=6)[name]
+        out = np.zeros(n, dt)
+        _chk(lib().rwkv_debug_read(self._h, which, out.ctypes.data, out.nbytes))
+        return out
+
+    def debug_write(self, name, arr):
+        which, dt = self.DBG[name]
+        a = np.ascontiguousarray(arr, dt)
+        _chk(lib().rwkv_debug_write(self._h, which, a.ctypes.data, a.nbytes))
 
     def close(self):
         if self._h:

@@ -24,8 +24,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def built():
     """build (or reuse) the HIP engine and the oracle; returns the dict of artefact paths"""
-    from rwkv_cpp_accelerated_amd import build
-    return build.build_all()
+    import build_checkers
+    return build_checkers.build_all()
 
 
 @pytest.fixture(scope="session")

@@ -34,6 +34,9 @@ class Oracle:
         L.oracle_meanvar.argtypes = [u64, vp, u64, vp, vp]
         L.oracle_layernorm.argtypes = [u64, vp, vp, u64, vp, vp, vp, u64]
         L.oracle_wkv.argtypes = [u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u64, u64, i32]
+        L.oracle_mm8_three.argtypes = [u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u64]
+        L.oracle_mixatt.argtypes = [u64, vp, vp, vp, vp, vp, vp, u64, u64, u64, i32]
+        L.oracle_mixffn.argtypes = [u64, vp, vp, vp, vp, vp, vp, u64, u64, u64, i32]
         L.oracle_quantize_matrix.argtypes = [vp, u64, u64, vp, vp, vp]
         L.oracle_argmax_ban0.argtypes = [vp]; L.oracle_argmax_ban0.restype = u64
         L.oracle_tensor_elems.argtypes = [u64, u64, u64]; L.oracle_tensor_elems.restype = u64
@@ -87,6 +90,40 @@ class Oracle:
         T, Cn = k.shape
         y = np.zeros((T, Cn))
         self.L.oracle_wkv(Cn, _p(w), _p(u), _p(k), _p(v), _p(r), _p(y), _p(aa), _p(bb), _p(pp), 0, 1, T, MODE_GPT)
+        return y
+
+    # -- the pieces of one layer, on a model's flat FILE-layout tensors (layer = l); T = 1, GPT mode ----------
+    def mm8_layer(self, x, w, r, o, N, M, layer, y0=None):
+        """kernelc_mm8_one on layer `layer` of a stacked matrix w[L][N][M] (rwkv.cu:267-311): x f64[N] or f32[N] -> f32[M] (+ y0)"""
+        x = np.ascontiguousarray(x)
+        y = np.zeros(M, np.float32) if y0 is None else np.array(y0, np.float32, copy=True)
+        f = self.L.oracle_mm8_one_f64 if x.dtype == np.float64 else self.L.oracle_mm8_one_f32
+        f(N, M, _p(x), _p(w), _p(y), _p(r), _p(o), layer, 1)
+        return y
+
+    def mm8_three(self, xy, km, vm, rm, kr, vr, rr, o1, o2, o3, D, layer):
+        """kernel_mm8_threec (rwkv.cu:58-142): xy f32[3][D] -> k, v, r f32[D]"""
+        xy = np.ascontiguousarray(xy, np.float32)
+        k, v, r = (np.zeros(D, np.float32) for _ in range(3))
+        self.L.oracle_mm8_three(D, _p(xy), _p(km), _p(vm), _p(rm), _p(kr), _p(vr), _p(rr), _p(o1), _p(o2), _p(o3), _p(k), _p(v), _p(r), layer, 1)
+        return k, v, r
+
+    def mixatt(self, ln, sxy, mixk, mixv, mixr, D, layer, layers):
+        """mixatt (rwkv.cu:351-392): ln f64[D], state xy (updated in place, whole [L][D] array) -> f32[3][D]"""
+        out = np.zeros(3 * D, np.float32)
+        self.L.oracle_mixatt(D, _p(np.ascontiguousarray(ln, np.float64)), _p(sxy), _p(mixk), _p(mixv), _p(mixr), _p(out), layer, layers, 1, MODE_GPT)
+        return out
+
+    def mixffn(self, ln, sdd, mixk, mixr, D, layer, layers):
+        """mixffn (rwkv.cu:313-349): ln f64[D], state dd (updated in place) -> ffn_k input, ffn_r input, f64[D] each"""
+        ok, orr = np.zeros(D), np.zeros(D)
+        self.L.oracle_mixffn(D, _p(np.ascontiguousarray(ln, np.float64)), _p(sdd), _p(mixk), _p(mixr), _p(ok), _p(orr), layer, layers, 1, MODE_GPT)
+        return ok, orr
+
+    def wkv_layer(self, w, u, k, v, r, aa, bb, pp, D, layer, layers):
+        """kernel_wkvc_forward (rwkv.cu:221-265) on layer `layer`: k, v, r f32[D]; aa, bb, pp whole [L][D] state arrays, updated in place -> y f64[D]"""
+        y = np.zeros(D)
+        self.L.oracle_wkv(D, _p(w), _p(u), _p(k), _p(v), _p(r), _p(y), _p(aa), _p(bb), _p(pp), layer, layers, 1, MODE_GPT)
         return y
 
     def quantize_matrix(self, xx):

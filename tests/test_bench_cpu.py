@@ -65,3 +65,49 @@ def test_counter_figures_are_keyed_on_the_sources_they_were_measured_on(tmp_path
     assert "read_over_weights" not in bench.prefill_traffic_lookup("7B", "prompt512")
     (csrc / "seq.hip.h").write_text("// changed")
     assert "read_over_weights" not in bench.prefill_traffic_lookup("7B", "chunk32")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_the_multi_gpu_line_is_assembled_from_per_rank_results(world):
+    """bench_pipeline's JSON assembler is a pure function (bench.pipeline_line): synthetic per-rank results for the N the driver runs -- the
+    one hardware run of the layer pipeline must not be lost to a field typo.  The line must serialise, carry the contract's fields, quote
+    the SLOWEST stage, and state the single-stream rate both as tokens/s and as a fraction of ONE GPU's HBM-read roofline (north_star)."""
+    from rwkv_cpp_accelerated_amd import modelfile as mf, pipeline
+    L, D = mf.SHAPES["14B"]
+    ranges = pipeline.partition_layers(L, world, D)
+    assert ranges[0][0] == 0 and ranges[-1][1] == L and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    per_stage = [4100.0 + 10 * r for r in range(world)]
+    per_stage[world // 2] = 3900.5                                  # the slowest stage
+    hop = dict(per_rank_us=[dict(mean=21.0, min=9.5, max=80.0)] * world, note="synthetic")
+    parity = dict(streams=world, steps=12, picks_identical=True, last_step_logits_bit_identical=True, max_rel_logit_err=0.0)
+    per_launch = {k: dict(traffic=v, traffic_source="profiles/r99/hbm_traffic.json") for k, v in
+                  dict(att_kvr_wkv=80e6, att_out=27e6, ffn_rk=133e6, ffn_v=106e6, head=258e6).items()}
+    steps, one_steps, dt, dt1 = 64, 128, 64 * 3.1e-3, 128 * 3.3e-3
+    line = bench.pipeline_line(model="14B", L=L, D=D, world=world, steps=steps, warmup=8, dt=dt, one_steps=one_steps, dt1=dt1, per_stage=per_stage,
+                               layer_ranges=ranges, transport="RCCL ncclSend/ncclRecv", hop=hop, parity=parity, cpu=dict(value=5.0, unit="tokens/s", cores=16, kind="port", sample="x"),
+                               prefill=dict(prompt_tokens=1024, tokens_per_s=30000.0), native_note=None, tinfo=[dict(rank=r) for r in range(world)],
+                               resident=[2_000_000_000 + r for r in range(world)], per_launch=per_launch)
+    line["two_streams_per_stage"] = None
+    back = json.loads(json.dumps(line))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "one_stream", "hop", "parity_vs_single_gpu", "hbm_resident_bytes", "transport_info"):
+        assert k in back, k
+    B = mf.bytes_per_token(L, D)
+    assert back["n_gpus"] == world and back["scaling"] == "weak" and back["vs_baseline"] is None and "model" not in back["config"]
+    assert back["value"] == pytest.approx(world * steps / dt, rel=1e-4) and back["ms_per_step"] == pytest.approx(1e3 * dt / steps, rel=1e-4)
+    r = back["roofline"]
+    assert r["achieved"] == 3900.5 and r["quoted_stage"] == world // 2 and r["frac"] == pytest.approx(3900.5 / 8000.0, abs=1e-4) and r["bound"] == "hbm"
+    ql0, ql1 = ranges[world // 2]
+    last = world // 2 == world - 1                                  # (N = 2: the quoted stage is the one that holds the head)
+    assert r["traffic"] == int((ql1 - ql0) * (80e6 + 27e6 + 133e6 + 106e6) + (258e6 if last else 0))
+    assert r["algorithmic_weight_bytes"] == (ql1 - ql0) * 13 * D * D + (mf.VOCAB * D if last else 0)
+    one = back["one_stream"]
+    assert one["tokens_per_s"] == pytest.approx(1 / 3.3e-3, rel=1e-3) and one["frac_of_8TBps"] == pytest.approx(B / 3.3e-3 / 8e12, rel=1e-3)
+    assert one["roofline_tokens_per_s"] == pytest.approx(8e12 / B, rel=1e-3)
+    assert back["hbm_resident_bytes"]["per_rank"] == [2_000_000_000 + q for q in range(world)] and back["hbm_resident_bytes"]["total"] == sum(2_000_000_000 + q for q in range(world))
+    # without a counter pass on record for these sources the traffic reads null, with the reason
+    none = {k: dict(traffic=None, traffic_source="no PMC pass on record") for k in per_launch}
+    line2 = bench.pipeline_line(model="14B", L=L, D=D, world=world, steps=steps, warmup=8, dt=dt, one_steps=one_steps, dt1=dt1, per_stage=per_stage,
+                                layer_ranges=ranges, transport="x", hop=None, parity=None, cpu=None, prefill=None, native_note="rank 1: boom", tinfo=[], resident=[1] * world, per_launch=none)
+    assert line2["roofline"]["traffic"] is None and line2["transport_fallback"] == "rank 1: boom" and json.dumps(line2)
+    assert bench.parity_failures(back) == []

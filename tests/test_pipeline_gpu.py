@@ -164,6 +164,13 @@ def _native_worker(rank, world, port, first_tokens, L, D, seed, steps, prompt, q
         st.m.reset_state()
         first2 = [(7 * g + 3) % 50000 + 2 for g in range(2 * world)]
         picks2 = pipeline.run_pipeline_native_dual(st, rank, world, first2, steps)
+        # ... and 20 more times on the same two communicators (a full-suite run once saw this leg time out): every repetition
+        # must finish and give the same picks -- a lost wake-up or an ordering hole between the comm streams and the compute stream shows here
+        for rep in range(20):
+            st.m.reset_state()
+            again = pipeline.run_pipeline_native_dual(st, rank, world, first2, steps)
+            if rank == world - 1 and not np.array_equal(again, picks2):
+                raise RuntimeError(f"two-communicator schedule, repetition {rep}: picks differ from the first run")
         if rank == 0:
             q.put(("rank0", bad))
         if rank == world - 1:
@@ -250,7 +257,6 @@ def test_native_transport_with_several_ranks_on_one_gpu(eng_mod, world):
 def _mismatch_worker(rank, world, port, L, D, q, rccl_lib):
     try:
         os.environ["RWKV_RCCL_LIB"] = rccl_lib
-        os.environ["RWKV_PIPE_LOG"] = "0"
         if rank == 1:
             os.environ["RWKV_SEQ_ROWS"] = "32"           # a per-rank environment difference: this rank would cut prompts into 32-row micro-batches
         import torch.distributed as dist

@@ -280,13 +280,13 @@ def test_64_row_gemm_forms_agree(eng_mod, T, L, D, monkeypatch):
 @pytest.mark.parametrize("T,L,D", [(150, 3, 768), (64, 2, 2048), (20, 2, 1024)])
 def test_captured_passes_replay_bit_identically(eng_mod, T, L, D, monkeypatch):
     """GPT-mode passes are captured as hipGraphs at first use (one per layer range, residual buffer, row count and logits row) and
-    replayed afterwards (engine.hip enqueue_pass; RWKV_SEQ_GRAPH=0: direct launches).  First call (capture + launch), second call
+    replayed afterwards (engine.hip enqueue_pass; RWKV_GRAPH bit 1 clear: direct launches).  First call (capture + launch), second call
     (replay) and the direct launches must agree bit for bit, logits and state, also when a different prompt goes through the same graphs."""
     t = mf.synthetic_tensors(L, D, seed=900 + T)
     toks, toks2 = _toks(T, 7 * T), _toks(T, 11 * T)
     outs = {}
     for gr in ("0", "1"):
-        monkeypatch.setenv("RWKV_SEQ_GRAPH", gr)
+        monkeypatch.setenv("RWKV_GRAPH", "1" if gr == "0" else "3")
         m = eng_mod.RWKV(resident=True)
         m.loadTensors(L, D, t, maxGPT=T)
         res = []

@@ -5,13 +5,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 kind = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-os.environ["RWKV_TL_CLASS"] = str(10 + kind)
 import numpy as np, torch                                                 # noqa: E402
 from rwkv_cpp_accelerated_amd import engine, modelfile as mf              # noqa: E402
 
 model = sys.argv[2] if len(sys.argv) > 2 else "7B"
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-os.environ["RWKV_TL_ROWS"] = str(rows)
+os.environ["RWKV_TL_CLASS"] = str((20 if rows > 32 else 10) + kind)      # 10 + kind: a 32-row chunk, 20 + kind: a 64-row pass
 L, D = mf.SHAPES[model]
 L = min(L, 8)
 m = engine.RWKV(resident=True)
