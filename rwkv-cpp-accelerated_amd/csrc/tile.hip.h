@@ -32,14 +32,13 @@ constexpr double TILE_CN = -1077952512.0;      // -16384 * 65793: coefficient of
 constexpr int TILE_NWP = NT / 2 / 64;          // prologue waves (0 .. 3)
 constexpr int TILE_NSTASH = NC - TILE_NWP;     // consumer waves that fetch the epilogues' inputs meanwhile (4 .. 6)
 struct TileCtl {                 // LDS control block of a tile-form ring
-    unsigned staged[4];          // [0]: waves that have done their part of what EVERY consumer needs first -- the TILE_NWP prologue waves (vector 0, or
-                                 // all vectors where a kernel does not stage per vector) + the TILE_NSTASH waves that fetch the epilogues' inputs into
-                                 // LDS; [m > 0] (kernels that stage per vector, k_att_t): prologue waves that have staged vector m
+    unsigned staged;             // waves that have done their part of what every consumer needs before its first unit: the TILE_NWP prologue waves (their
+                                 // share of the vectors) + the TILE_NSTASH waves that fetch the epilogues' inputs into LDS
     unsigned landed;             // ring units whose DMA has completed (loader -> consumers, monotonic)
     unsigned freed[8];           // freed[w]: units consumer wave w has copied out of the ring (in ITS order: runs of RUN units, run r belongs to wave r % 7)
     unsigned tcnt[32];           // per tile of the workgroup: units already added into tsum
     unsigned done[8];            // k_att_t: per channel block of the workgroup, tiles (K, V, R) whose values are in
-    unsigned pad[3];
+    unsigned pad[2];
     unsigned long long sq[4];    // per staged vector: sum of (q_j + 2^22) over its elements (one ds_add_u64 per staging wave)
     unsigned dump[64];           // where lanes 1..63 of the loader put their copy of `landed` (a store by ALL lanes needs no exec juggling: two instructions)
 };
@@ -68,9 +67,7 @@ __device__ __forceinline__ unsigned stage_quad_t(unsigned *xq, int qd, const flo
 
 // LayerNorm-site prologue of a tile-form kernel, run by waves 0..3 (the other consumer waves and the loader meet them at the order
 // barrier inside); same ownership split as ring_site (kernels.hip.h).  SD = ceil(D / 1024).
-// PERVEC: the vectors are announced one by one (staged[m]), in the order the tile image holds their classes: the consumers start on vector 0's
-// tiles while waves 0..3 still stage vector 1 (k_att_t: K's tiles are multiplied under the staging of V's and R's vectors)
-template <int NV, int SD, bool PERVEC = false>
+template <int NV, int SD>
 __device__ __forceinline__ void tile_site(const SiteStatic &st, const SiteDyn &dy, const double *x, int D, double *red, unsigned *xq, int xvd_t,
                                           bool publish_stats, TileCtl *tc, unsigned long long *tl)
 {
@@ -86,28 +83,14 @@ __device__ __forceinline__ void tile_site(const SiteStatic &st, const SiteDyn &d
     site_tuple_load(dy, tup);
     double xl[NQP][4];
     f32x4 Cq[NQP][NV], Bq[NQP][NV];
-    if (PERVEC) {
-        // requested in the order they are needed (data returns in order per CU): x, then vector 0's constants, then vector 1's, ...
 #pragma unroll
-        for (int i = 0; i < NQP; i++) { const int qd = threadIdx.x + i * NTP; load_quad_f64(x, qd < nqd ? qd : nqd - 1, xl[i]); }
+    for (int i = 0; i < NQP; i++) {
+        const int qd = threadIdx.x + i * NTP, qc = qd < nqd ? qd : nqd - 1;
+        load_quad_f64(x, qc, xl[i]);
 #pragma unroll
-        for (int m = 0; m < NV; m++)
-#pragma unroll
-            for (int i = 0; i < NQP; i++) {
-                const int qd = threadIdx.x + i * NTP, qc = qd < nqd ? qd : nqd - 1;
-                Cq[i][m] = reinterpret_cast<const f32x4 *>(st.C + (size_t)m * D)[qc];
-                Bq[i][m] = reinterpret_cast<const f32x4 *>(dy.B + (size_t)m * D)[qc];
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NQP; i++) {
-            const int qd = threadIdx.x + i * NTP, qc = qd < nqd ? qd : nqd - 1;
-            load_quad_f64(x, qc, xl[i]);
-#pragma unroll
-            for (int m = 0; m < NV; m++) {
-                Cq[i][m] = reinterpret_cast<const f32x4 *>(st.C + (size_t)m * D)[qc];
-                Bq[i][m] = reinterpret_cast<const f32x4 *>(dy.B + (size_t)m * D)[qc];
-            }
+        for (int m = 0; m < NV; m++) {
+            Cq[i][m] = reinterpret_cast<const f32x4 *>(st.C + (size_t)m * D)[qc];
+            Bq[i][m] = reinterpret_cast<const f32x4 *>(dy.B + (size_t)m * D)[qc];
         }
     }
     tl_stamp(tl, 1);
@@ -118,34 +101,38 @@ __device__ __forceinline__ void tile_site(const SiteStatic &st, const SiteDyn &d
     if (publish_stats && blockIdx.x == 0 && threadIdx.x == 0) { dy.lnstat[0] = r.mean; dy.lnstat[1] = r.rstd; }
     tl_stamp(tl, 4);
     const float rstdf = (float)r.rstd;
-    float xh[NQP][4];
+    unsigned long long sq[NV];
 #pragma unroll
-    for (int i = 0; i < NQP; i++)
+    for (int m = 0; m < NV; m++) sq[m] = 0ull;
 #pragma unroll
-        for (int e = 0; e < 4; e++) xh[i][e] = (float)(xl[i][e] - r.mean) * rstdf;
+    for (int i = 0; i < NQP; i++) {
+        const int qd = threadIdx.x + i * NTP;
+        if (qd < nqd) {
+            float xh[4];
 #pragma unroll
-    for (int m = 0; m < NV; m++) {
-        unsigned long long sq = 0ull;
-        const float inv = inv_scale(r.amax[m]);
+            for (int e = 0; e < 4; e++) xh[e] = (float)(xl[i][e] - r.mean) * rstdf;
 #pragma unroll
-        for (int i = 0; i < NQP; i++) {
-            const int qd = threadIdx.x + i * NTP;
-            if (qd < nqd) {
+            for (int m = 0; m < NV; m++) {
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = fmaf(Cq[i][m][e], xh[i][e], Bq[i][m][e]);
-                sq += stage_quad_t(xq + m * xvd_t, qd, v, inv);
+                for (int e = 0; e < 4; e++) v[e] = fmaf(Cq[i][m][e], xh[e], Bq[i][m][e]);
+                sq[m] += stage_quad_t(xq + m * xvd_t, qd, v, inv_scale(r.amax[m]));
             }
         }
-        // one LDS atomic per wave and vector (64 lanes on one address would serialise in the LDS pipe under the DMA stream): the thread sums
-        // (< 2^27 each) are folded on the DPP network in two 32-bit halves that cannot overflow
-        const unsigned lo = wave_sum_dpp((unsigned)sq & 0xffffu), hi = wave_sum_dpp((unsigned)(sq >> 16));
+    }
+    // one LDS atomic per wave and vector (64 lanes on one address would serialise in the LDS pipe under the DMA stream): the thread sums
+    // (< 2^27 each) are folded on the DPP network in two 32-bit halves that cannot overflow
+#pragma unroll
+    for (int m = 0; m < NV; m++) {
+        const unsigned lo = wave_sum_dpp((unsigned)sq[m] & 0xffffu), hi = wave_sum_dpp((unsigned)(sq[m] >> 16));
         if ((threadIdx.x & 63) == 0)
             __hip_atomic_fetch_add(&tc->sq[m], (unsigned long long)lo + ((unsigned long long)hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (threadIdx.x == 0) { bc[m] = (float)r.S[m]; bc[4 + m] = r.amax[m]; }
-        if ((PERVEC || m == NV - 1) && (threadIdx.x & 63) == 0)
-            __hip_atomic_fetch_add(&tc->staged[PERVEC ? m : 0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int m = 0; m < NV; m++) { bc[m] = (float)r.S[m]; bc[4 + m] = r.amax[m]; }
+    }
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&tc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // S KiB from ONE wave-uniform address (SGPR pair) + this lane's 32-bit offset: the per-unit address update is two scalar adds
@@ -298,14 +285,14 @@ __device__ __forceinline__ void tile_vec(const float *vec, const double *partS, 
         if (lane == 0) __hip_atomic_fetch_add(&tc->sq[0], (unsigned long long)lo + ((unsigned long long)hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (threadIdx.x == 0) { bc[0] = (float)ts; bc[4] = tm; }
-    if (lane == 0) __hip_atomic_fetch_add(&tc->staged[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_fetch_add(&tc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // waves TILE_NWP .. NC - 1 fetch the epilogues' inputs of the workgroup's rows into LDS while waves 0..3 stage: the wave's stores are announced on
-// the count every consumer waits for before its first unit (a tile's finisher may be ANY consumer wave, also one that took no unit beside these
-// waves: D = 5120 / 2048 with their small tiles -- the order barrier alone does not order these stores against it)
+// the count every consumer waits for before its first unit.  (a tile's finisher may be ANY consumer wave, also one that took no unit
+// beside these waves -- D = 5120 / 2048 with their small tiles --, and the order barrier alone does not order these stores against it.)
 __device__ __forceinline__ void tile_stash_done(TileCtl *tc, int lane)
 {
-    if (lane == 0) __hip_atomic_fetch_add(&tc->staged[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_fetch_add(&tc->staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // the loader wave's whole life: zero the control block and the tile sums, first units before the order barrier, the stream, the landing
@@ -356,8 +343,7 @@ __device__ __forceinline__ double tile_cA(const TileCtl *tc, int m, double n)
 // wait for it, copy its S KiB out of the ring, hand it back, multiply it with the limbs of vector vec_of(tile); when the wave's last
 // unit of a tile is in, its partial sums join the tile's in LDS and the unit count; the wave that completes the count calls on_tile(t)
 // (all lanes; the tile's row sums are final: tile_row_sum).
-// PERVEC: the wave waits for vector v (staged[v]) where it first meets a unit of a tile that multiplies it (vec_of is non-decreasing along the stream).
-template <int TH, int S, int UPT, int RUN, bool PERVEC = false, class VecOf, class OnTile>
+template <int TH, int S, int UPT, int RUN, class VecOf, class OnTile>
 __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, int ns, TileCtl *tc, int *tsum, const unsigned *xq, int xvd_t,
                                              int wave, int lane, unsigned &fail, VecOf vec_of, OnTile on_tile)
 {
@@ -367,7 +353,6 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
     int acc0 = 0, acc1 = 0, acc2 = 0, cnt = 0;
     unsigned taken = 0, seen = 0;
     unsigned p = (unsigned)(wave * RUN) % (unsigned)ns;      // ring position of the wave's next unit: advanced unit by unit, run by run
-    int vready = 0;                                          // vectors 0 .. vready are known to be staged (the caller has waited for vector 0)
     for (int run = wave; run * RUN < NU; run += NC) {
 #pragma unroll 1
         for (int cc = 0; cc < RUN; cc++) {
@@ -392,7 +377,6 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
             if (lane == 0) __hip_atomic_store(&tc->freed[wave], taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             p = p + 1 == (unsigned)ns ? 0u : p + 1;
             const int t = u / UPT, c = u - t * UPT;
-            if (PERVEC && vec_of(t) > vready) { vready = vec_of(t); wait_count(&tc->staged[vready], (unsigned)TILE_NWP, fail); }
             const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + pc) * 3;
 #pragma unroll
             for (int s = 0; s < S; s++) {
@@ -435,24 +419,7 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
 // Every tile-form kernel: workgroup b owns CPW = TH * TPC consecutive channels -- TPC tiles of TH rows per row class (TH = 16, TPC = 1: D = 4096
 // on 256 CUs, the chunk path's own image; TH = 4: a decode-only image, TPC = 5 at D = 5120, 2 at D = 2048).  KBT = fragments (1 KiB) of a
 // tile along K (K TH / 1024), S = fragments (KiB) per ring unit, SD = ceil(D / 1024).  The argument blocks are the row-form kernels' (site,
-// epilogue inputs and outputs, D, ns = ring units, tl, herr; w / rw / cy unused) + the image.
-// Which channel block a workgroup owns.  The hardware deals workgroup b to XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch"), so with the
-// identity an XCD's 32 workgroups own every eighth block and all their tile addresses agree in the bits that select block mod 8.  XCDMAP = 1
-// gives XCD x the CONTIGUOUS blocks 32 x .. 32 x + 31 instead (its addresses then cover every interleave granule below 2 MiB of a class's image).
-// Everything indexed per workgroup that a consumer later adds up in index order -- the partial sums / maxima / tuples -- is stored at the BLOCK's
-// index, not the workgroup's, so the results do not depend on the map (bit-identical; profiles/r06/spread.txt has the measurement).
-#ifndef RWKV_TILE_XCDMAP
-#define RWKV_TILE_XCDMAP 0
-#endif
-__device__ __forceinline__ int tile_bid()
-{
-#if RWKV_TILE_XCDMAP
-    const unsigned b = blockIdx.x, g = gridDim.x;
-    return (g & 7u) ? (int)b : (int)((b & 7u) * (g >> 3) + (b >> 3));
-#else
-    return (int)blockIdx.x;
-#endif
-}
+// epilogue inputs and outputs, D, ns = ring units, tl, herr; w unused) + the image.
 struct TileImage {
     const uint8_t *bimg;          // tile image of this layer's matrix (k_bimage: tile id = class * CB + block, TH rows per tile, signed bytes)
     int CB;                       // TH-row blocks per row class (channels / TH)
@@ -489,7 +456,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
     TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * TH * 3);
     unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
     RWKV_ARGS_NOW(a.x, a.st.C, a.st.TC, a.st.maxC, a.dy.B, a.dy.pd, a.dy.pf, a.dy.n_part);
-    const int bid = tile_bid(), cb0 = bid * TPC, ch0 = bid * CPW;
+    const int cb0 = blockIdx.x * TPC, ch0 = blockIdx.x * CPW;
     tl_stamp(a.tl, 0);
     auto unit_src = [&](int u) {          // tile t = class t / TPC, block cb0 + t % TPC
         const int t = u / UPT, c = u - t * UPT;
@@ -520,7 +487,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
             tile_stash_done(tc, lane);
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
-        wait_count(&tc->staged[0], TILE_NWP + TILE_NSTASH, fail);
+        wait_count(&tc->staged, TILE_NWP + TILE_NSTASH, fail);
         const double sck = scale_of(bc[4]), scr = scale_of(bc[5]);
         const float Sk = bc[0], Sr = bc[1];
         const double cAk = tile_cA(tc, 0, (double)D), cAr = tile_cA(tc, 1, (double)D);
@@ -550,7 +517,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
     tl_stamp(a.tl, 6);
     __syncthreads();   // every wave is past its last read of the reduction scratch
     block_sum_max(part, pmax, red + RED_PART);
-    if (threadIdx.x == 0) { a.partS[bid] = part; a.partM[bid] = pmax; }
+    if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
     ring_report(fail, a.herr);
     tl_stamp(a.tl, 7);
 }
@@ -578,7 +545,7 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
     TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * TH * 3);
     unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
     RWKV_ARGS_NOW(a.x, a.st.C, a.st.TC, a.st.maxC, a.dy.B, a.dy.pd, a.dy.pf, a.dy.n_part);
-    const int bid = tile_bid(), cb0 = bid * TPC, ch0 = bid * CPW;
+    const int cb0 = blockIdx.x * TPC, ch0 = blockIdx.x * CPW;
     tl_stamp(a.tl, 0);
     auto unit_src = [&](int u) {
         const int t = u / UPT, c = u - t * UPT;
@@ -593,7 +560,7 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
     } else {
         const size_t so = (size_t)a.ctl->slot * a.slot_stride;
         if (wave < TILE_NWP) {
-            tile_site<3, SD, true>(a.st, a.dy, a.x, D, red, xq, xvd_t, true, tc, a.tl);
+            tile_site<3, SD>(a.st, a.dy, a.x, D, red, xq, xvd_t, true, tc, a.tl);
         } else {
             // epilogue inputs of the CPW channels: wave 4 the 3 CPW row sums, wave 5 the state (aa | bb) and the decay terms (uw | ew), wave 6 att_out's scale / offset
             unsigned v0 = 0u, v1 = 0u;
@@ -610,7 +577,7 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
             tile_stash_done(tc, lane);
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
-        wait_count(&tc->staged[0], TILE_NWP + TILE_NSTASH, fail);
+        wait_count(&tc->staged, TILE_NWP + TILE_NSTASH, fail);
         tl_stamp(a.tl, 5);
         auto on_tile = [&](int t) {
             const int q = t / TPC, sub = t % TPC;
@@ -644,12 +611,12 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
                 pmax = fmaxf(pmax, fabsf(ys));
             }
         };
-        tile_consume<TH, S, UPT, RUN, true>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t / TPC; }, on_tile);
+        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t / TPC; }, on_tile);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
     block_sum_max(part, pmax, red + RED_PART);
-    if (threadIdx.x == 0) { a.partS[bid] = part; a.partM[bid] = pmax; }
+    if (threadIdx.x == 0) { a.partS[blockIdx.x] = part; a.partM[blockIdx.x] = pmax; }
     ring_report(fail, a.herr);
     tl_stamp(a.tl, 7);
 }
@@ -665,17 +632,17 @@ __device__ __forceinline__ void tile_site_leave(const SiteAcc<NV> &acc, double *
 #pragma unroll
     for (int k = 0; k < 4; k++) scf[li * 4 + k] = acc.f[k];
 }
-__device__ __forceinline__ void tile_site_publish(const SiteDyn &dy, const double *scr, int cpw, int bid)
+__device__ __forceinline__ void tile_site_publish(const SiteDyn &dy, const double *scr, int cpw)
 {
     const float *scf = reinterpret_cast<const float *>(scr + cpw * 8);
     if (threadIdx.x < 8) {
         double t = 0.0;
         for (int i = 0; i < cpw; i++) t += scr[i * 8 + threadIdx.x];
-        dy.pd[(size_t)bid * 8 + threadIdx.x] = t;
+        dy.pd[(size_t)blockIdx.x * 8 + threadIdx.x] = t;
     } else if (threadIdx.x < 12) {
         float t = 0.f;
         for (int i = 0; i < cpw; i++) t = fmaxf(t, scf[i * 4 + (threadIdx.x - 8)]);
-        dy.pf[(size_t)bid * 4 + (threadIdx.x - 8)] = t;
+        dy.pf[(size_t)blockIdx.x * 4 + (threadIdx.x - 8)] = t;
     }
 }
 
@@ -699,7 +666,7 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
     TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * TH * 3);
     unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
     RWKV_ARGS_NOW(a.ybuf, a.partS, a.partM, a.n_part);
-    const int bid = tile_bid(), cb0 = bid * TPC, ch0 = bid * CPW;
+    const int cb0 = blockIdx.x * TPC, ch0 = blockIdx.x * CPW;
     tl_stamp(a.tl, 0);
     auto unit_src = [&](int u) {
         const int t = u / UPT, c = u - t * UPT;
@@ -729,7 +696,7 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
             tile_stash_done(tc, lane);
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
-        wait_count(&tc->staged[0], TILE_NWP + TILE_NSTASH, fail);
+        wait_count(&tc->staged, TILE_NWP + TILE_NSTASH, fail);
         const float Sf = bc[0];
         const double sc = scale_of(bc[4]), cA = tile_cA(tc, 0, (double)D);
         tl_stamp(a.tl, 5);
@@ -755,7 +722,7 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
-    tile_site_publish(a.dy, scr, CPW, bid);
+    tile_site_publish(a.dy, scr, CPW);
     ring_report(fail, a.herr);
     tl_stamp(a.tl, 7);
 }
@@ -781,7 +748,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
     TileCtl *tc = reinterpret_cast<TileCtl *>(tsum + NTILE * TH * 3);
     unsigned char *ring = reinterpret_cast<unsigned char *>(tc + 1);
     RWKV_ARGS_NOW(a.hbuf, a.partS, a.partM, a.n_part);
-    const int bid = tile_bid(), cb0 = bid * TPC, ch0 = bid * CPW;
+    const int cb0 = blockIdx.x * TPC, ch0 = blockIdx.x * CPW;
     tl_stamp(a.tl, 0);
     auto unit_src = [&](int u) {
         const int t = u / UPT, c = u - t * UPT;
@@ -812,7 +779,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
             tile_stash_done(tc, lane);
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
-        wait_count(&tc->staged[0], TILE_NWP + TILE_NSTASH, fail);
+        wait_count(&tc->staged, TILE_NWP + TILE_NSTASH, fail);
         const float Sf = bc[0];
         const double sc = scale_of(bc[4]), cA = tile_cA(tc, 0, 4.0 * (double)D);
         tl_stamp(a.tl, 5);
@@ -838,7 +805,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
-    tile_site_publish(a.dy, scr, CPW, bid);
+    tile_site_publish(a.dy, scr, CPW);
     ring_report(fail, a.herr);
     tl_stamp(a.tl, 7);
 }
