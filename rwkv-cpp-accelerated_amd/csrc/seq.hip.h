@@ -230,29 +230,59 @@ template <int MODE>
 __global__ __launch_bounds__(SEQ_ENT) void k_seq_resid(SeqResidArgs a)
 {
     __shared__ double red[SEQ_ENW * 4];
+    // (every pointer with the kernel's FIRST scalar loads: hipcc sinks an argument's s_load to its first use, and every such use behind a wait
+    // is one more scalar-cache round trip on a kernel that is a launch and a handful of round trips long -- DESIGN.md 4.3, round 6 for this path)
+    RWKV_ARGS_NOW(a.x, a.pk, a.qpart, a.pk_gate, a.qpart_gate, a.stat);
     const int D = a.D, tg = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;      // tg: row of the pass; t: row of its half
     const int hh = tg / SEQ_T, t = tg % SEQ_T;
     const float *pk = a.pk + hh * a.pk_h, *pkg = a.pk_gate + hh * a.pkg_h;
     int c0, c1;
     octant_range(D, o, c0, c1);
-    const float so = MODE != 0 ? seq_so(a.qpart + hh * a.part_h, 0, t) : 0.f;
-    const float sog = MODE == 2 ? seq_so(a.qpart_gate + hh * a.partg_h, 0, t) : 0.f;
-    double s[2] = {0.0, 0.0};
-    for (int j = c0 + threadIdx.x; j < c1; j += SEQ_ENT) {
-        const size_t e = (size_t)tg * D + j;
-        double x = a.x[e];
-        if (MODE != 0) {
-            const int CB = (D + 15) >> 4;
-            const float v = seq_val(pk, CB, j >> 4, t, j & 15, so);
-            if (MODE == 1) x = (double)((float)x + v);
-            else {
-                const float r = seq_val(pkg, 5 * CB, 4 * CB + (j >> 4), t, j & 15, sog);
-                const float gt = (float)(1.0 / (1.0 + exp(-(double)r)));
-                x = x + (double)(v * gt);
-            }
-            a.x[e] = x;
+    // Every load of the workgroup is requested before the first one is used: the octants' offset terms, then x and the partial values of up to
+    // SEQ_RJ channels per thread (D / 8 <= SEQ_RJ * SEQ_ENT).  (Written as "offset terms first, then a loop over the channels" the kernel was a
+    // chain of dependent round trips -- the sum of the offset terms in front of the channels' loads -- on a launch that is a few round trips long.)
+    constexpr int SEQ_RJ = 3;
+    const SeqPart *qp = a.qpart + hh * a.part_h + (size_t)t * SEQ_O, *qg = a.qpart_gate + hh * a.partg_h + (size_t)t * SEQ_O;
+    float sov[SEQ_O], sgv[SEQ_O];
+#pragma unroll
+    for (int q = 0; q < SEQ_O; q++) { sov[q] = MODE != 0 ? qp[q].So : 0.f; sgv[q] = MODE == 2 ? qg[q].So : 0.f; }
+    const int CB = (D + 15) >> 4;
+    double xs[SEQ_RJ];
+    float pv[SEQ_RJ][SEQ_O], pg[SEQ_RJ][SEQ_O];
+#pragma unroll
+    for (int i = 0; i < SEQ_RJ; i++) {
+        const int j = c0 + threadIdx.x + i * SEQ_ENT, jc = j < c1 ? j : (c1 > 0 ? c1 - 1 : 0);      // (an octant of a narrow model may be empty: any valid address)
+        xs[i] = a.x[(size_t)tg * D + jc];
+#pragma unroll
+        for (int q = 0; q < SEQ_O; q++) {
+            pv[i][q] = MODE != 0 ? pk[pk_index(CB, q, jc >> 4, t, jc & 15)] : 0.f;
+            pg[i][q] = MODE == 2 ? pkg[pk_index(5 * CB, q, 4 * CB + (jc >> 4), t, jc & 15)] : 0.f;
         }
-        s[0] += x; s[1] += x * x;
+    }
+    float so = 0.f, sog = 0.f;          // (seq_so: the octants' So added up in f32, fixed order)
+#pragma unroll
+    for (int q = 0; q < SEQ_O; q++) { so += sov[q]; sog += sgv[q]; }
+    double s[2] = {0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < SEQ_RJ; i++) {
+        const int j = c0 + threadIdx.x + i * SEQ_ENT;
+        if (j < c1) {
+            double x = xs[i];
+            if (MODE != 0) {
+                double vd = 0.0, rd = 0.0;      // (seq_val: the slices added up in f64, fixed order)
+#pragma unroll
+                for (int q = 0; q < SEQ_O; q++) { vd += (double)pv[i][q]; rd += (double)pg[i][q]; }
+                const float v = (float)vd + so;
+                if (MODE == 1) x = (double)((float)x + v);
+                else {
+                    const float r = (float)rd + sog;
+                    const float gt = (float)(1.0 / (1.0 + exp(-(double)r)));
+                    x = x + (double)(v * gt);
+                }
+                a.x[(size_t)tg * D + j] = x;
+            }
+            s[0] += x; s[1] += x * x;
+        }
     }
     eblock_sum<2>(s, red);
     if (threadIdx.x == 0) {
@@ -292,12 +322,28 @@ __device__ __forceinline__ void seq_row_stats(const SeqStat *stat, int t, int D,
     mean = sx / (double)D;
     rstd = 1.0 / sqrt((sxx - sx * mean) / (double)(D - 1));    // reference: (D-1), no epsilon (rwkv.cu:43-44,53)
 }
+__device__ __forceinline__ void seq_row_stats2(const SeqStat *stat, int t, int tp, int D, double &mean, double &rstd, double &meanp, double &rstdp)
+{
+    SeqStat r[SEQ_O], rp[SEQ_O];
+#pragma unroll
+    for (int o = 0; o < SEQ_O; o++) { r[o] = stat[t * SEQ_O + o]; rp[o] = stat[tp * SEQ_O + o]; }
+    double sx = 0.0, sxx = 0.0, px = 0.0, pxx = 0.0;
+#pragma unroll
+    for (int o = 0; o < SEQ_O; o++) { sx += r[o].sx; sxx += r[o].sxx; px += rp[o].sx; pxx += rp[o].sxx; }
+    mean = sx / (double)D;
+    rstd = 1.0 / sqrt((sxx - sx * mean) / (double)(D - 1));
+    meanp = px / (double)D;
+    rstdp = 1.0 / sqrt((pxx - px * meanp) / (double)(D - 1));
+}
 // (row, octant) workgroups, one quad (4 channels) per thread: LayerNorm + shift mix of the octant, its exact max|.| per
 // vector (one workgroup reduction), quantisation into the A image.  D / 32 <= SEQ_ENT quads per octant.
 template <int NV>
 __global__ __launch_bounds__(SEQ_ENT) void k_seq_site(SeqSiteArgs a)
 {
     __shared__ double red[SEQ_ENW * 4];
+    RWKV_ARGS_NOW(a.x, a.stat, a.lnw, a.lnb, a.state, a.state_par, a.state_new, a.part);      // (see k_seq_resid)
+    RWKV_ARGS_NOW(a.mix[0], a.r[0], a.o[0], a.img[0]);
+    if (NV > 1) RWKV_ARGS_NOW(a.mix[NV - 1], a.r[NV - 1], a.o[NV - 1], a.img[NV - 1], a.mix[NV > 2 ? 1 : 0], a.r[NV > 2 ? 1 : 0], a.o[NV > 2 ? 1 : 0], a.img[NV > 2 ? 1 : 0]);
     const int D = a.D, t = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;      // t: row of the pass (0 .. 63)
     const int hh = t / SEQ_T, th = t % SEQ_T;                                 // its half and the row inside the half (images, records)
     int c0, c1;
@@ -305,9 +351,10 @@ __global__ __launch_bounds__(SEQ_ENT) void k_seq_site(SeqSiteArgs a)
     const bool shift = a.mix[0] != nullptr;
     const bool lnprev = shift && t > 0 && !a.par;   // the shift input is a LayerNorm output: of the previous row (GPT) or already stored (state)
     const double *xprow = !shift ? a.x : a.par ? a.state_par + (size_t)(a.slot0 + t) * a.slot_stride : (t > 0 ? a.x + (size_t)(t - 1) * D : a.state);
-    double mean, rstd, meanp = 0.0, rstdp = 1.0;
-    seq_row_stats(a.stat, t, D, mean, rstd);
-    if (lnprev) seq_row_stats(a.stat, t - 1, D, meanp, rstdp);
+    // both rows' statistics in ONE round trip (unconditionally: a branch around the second read is a second trip where it is taken)
+    double mean, rstd, meanp, rstdp;
+    seq_row_stats2(a.stat, t, lnprev ? t - 1 : t, D, mean, rstd, meanp, rstdp);
+    if (!lnprev) { meanp = 0.0; rstdp = 1.0; }
     const int qd = (c0 >> 2) + threadIdx.x;
     const bool live = qd < (c1 >> 2);
     float v[NV][4];
@@ -372,6 +419,7 @@ template <int KIND>
 __global__ __launch_bounds__(SEQ_ENT) void k_seq_stage(SeqStageArgs a)
 {
     __shared__ double red[SEQ_ENW * 4];
+    RWKV_ARGS_NOW(a.src, a.pk, a.qpart_k, a.r, a.o, a.img, a.part);      // (see k_seq_resid)
     const int K = a.K, tg = blockIdx.x / SEQ_O, o = blockIdx.x % SEQ_O;
     const int hh = tg / SEQ_T, t = tg % SEQ_T;
     const float *pk = a.pk + hh * a.pk_h;
@@ -441,6 +489,7 @@ template <int TCAP>
 __global__ __launch_bounds__(TCAP * WKV_CH) void k_seq_wkv(SeqWkvArgs a)
 {
     __shared__ double e1s[TCAP][WKV_CH], eks[TCAP][WKV_CH], vs[TCAP][WKV_CH], sgs[TCAP][WKV_CH], aas[TCAP][WKV_CH];
+    RWKV_ARGS_NOW(a.pk, a.qpart, a.uw, a.ew, a.saa, a.sbb, a.y);      // (see k_seq_resid)
     const int ch = threadIdx.x & (WKV_CH - 1), t = threadIdx.x / WKV_CH;     // t: row of the pass
     const int i = blockIdx.x * WKV_CH + ch;
     const bool live = i < a.D && t < a.T;
@@ -623,6 +672,15 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
     u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
     double *recl = reinterpret_cast<double *>(smem + (size_t)NBUF * CHU * 16);   // [NH][NVS][SEQ_T]{scale, cA} of this slice
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // every pointer and the class -> vector table with the kernel's FIRST scalar loads (round 6: the ISA of this kernel's head was a chain of ten
+    // dependent scalar-cache round trips in front of the first request -- arguments fetched where they are first used, and `vec_of_q[dynamic index]`
+    // as one s_load per lookup behind the division that makes the index)
+    RWKV_ARGS_NOW(a.bimg, a.rs8, a.img[0], a.img[NVS > 1 ? 1 : 0], a.img[NVS > 2 ? 2 : 0], a.part, a.pk, a.tl);
+    const int vq0 = a.vec_of_q[0], vq1 = a.vec_of_q[1], vq2 = a.vec_of_q[2], vq3 = a.vec_of_q[3], vq4 = a.vec_of_q[4];
+    RWKV_ARGS_NOW(vq0, vq1, vq2, vq3, vq4, a.N, a.K, a.Q);
+    auto vec_of = [&](int q) { return q <= 0 ? vq0 : q == 1 ? vq1 : q == 2 ? vq2 : q == 3 ? vq3 : vq4; };
+    const u32x4 *const im0 = a.img[0], *const im1 = a.img[1], *const im2 = a.img[2];
+    auto img_of = [&](int v) { return v <= 0 ? im0 : v == 1 ? im1 : im2; };      // (a.img[dynamic index] is one scalar load per DMA piece)
     tl_stamp(a.tl, 0);
     const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
     const int nch = (N + Q - 1) / Q, CB = (nch + 15) >> 4, ntiles = Q * CB;
@@ -634,7 +692,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
     const int ntw = a.ntw;
     const int id0 = (rb * SEQ_NW + wave) * ntw;          // this wave's tiles: id0 .. id0 + ntw - 1
     const int wg0 = rb * SEQ_NW * ntw, wg1 = min(wg0 + SEQ_NW * ntw, ntiles) - 1;
-    const int vlo = a.vec_of_q[min(wg0, ntiles - 1) / CB], vhi = a.vec_of_q[max(wg1, 0) / CB];
+    const int vlo = vec_of(min(wg0, ntiles - 1) / CB), vhi = vec_of(max(wg1, 0) / CB);
     SeqPart rc;
     {
         const int tr = threadIdx.x < NH * NVS * SEQ_T ? (int)threadIdx.x : 0;
@@ -655,7 +713,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
             rsv[i] = a.rs8[(size_t)j * N + ((ch < nch && row < N) ? row : 0)];
         }
         wt[i] = a.bimg + ((size_t)idc * KB) * 64 + lane;
-        vi[i] = a.vec_of_q[idc / CB] - vlo;
+        vi[i] = vec_of(idc / CB) - vlo;
         vi[i] = vi[i] < 0 ? 0 : (vi[i] >= NVS ? NVS - 1 : vi[i]);
         vi[i] = __builtin_amdgcn_readfirstlane(vi[i]);
     }
@@ -671,9 +729,9 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_p(SeqGemmArgs a)
         int hv = p / (NKB * 6), pc = p % (NKB * 6);
         int hh = hv / NVS, v = hv % NVS;
         if (hh >= NH || v >= nvec || pc >= np) { hh = 0; v = 0; pc = 0; }
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(a.img[vlo + v] + hh * a.img_h + (size_t)kbs * 384) + lane * 16 + (size_t)pc * 1024;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(img_of(vlo + v) + hh * a.img_h + (size_t)kbs * 384) + lane * 16 + (size_t)pc * 1024;
         const unsigned dst = abuf_lds + (unsigned)(((size_t)buf * CHU + (size_t)(hh * NVS + v) * NKB * 384) * 16) + (unsigned)pc * 1024u;
-        dma_piece_shared(np > 0 ? src : reinterpret_cast<const uint8_t *>(a.img[vlo]) + lane * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+        dma_piece_shared(np > 0 ? src : reinterpret_cast<const uint8_t *>(img_of(vlo)) + lane * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
     };
     auto stage_a = [&](int c, int buf) {
         const int kbs = kb0 + c * NKB, n = max(min(NKB, nkb - c * NKB), 0);
@@ -841,6 +899,7 @@ __global__ __launch_bounds__(SEQ_NT) void k_seq_gemm_b(SeqGemmBArgs ba)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert((DEPTH - 1) * 2 * NTW <= 40, "k_seq_gemm_b: the wait dispatch covers 40 requests");
     const SeqGemmArgs &a = ba.g;
+    RWKV_ARGS_NOW(a.bimg, a.rs8, a.img[0], a.img[1], a.img[2], a.part, a.pk, a.tl);      // (see k_seq_gemm_p)
     const int K = a.K, KB = K >> 6, N = a.N, Q = a.Q;
     const int nkbm = (KB + SEQ_O - 1) / SEQ_O;                    // longest slice
     u32x4 *abuf = reinterpret_cast<u32x4 *>(smem);
