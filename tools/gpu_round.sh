@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU-box session that produces everything profiles/rNN/ holds: GPU tests, the full bench line (reference-kernel
 # gate + CPU baseline legs included), rocprofv3 kernel-trace stats of the bench command, a separate PMC pass (FETCH_SIZE
-# only, no trace domains), the prefill report with per-kernel statistics, the other model sizes, the N = 2 dry runs of the multi-GPU bench line.  usage: tools/gpu_round.sh [r05]
+# only, no trace domains), the prefill report with per-kernel statistics, the other model sizes, the N = 2 dry runs of the multi-GPU bench line.  usage: tools/gpu_round.sh [r06]
 cd "$(dirname "$0")/.."
-R=$PWD; TAG=${1:-r05}; O=$R/gpurun_out/$TAG
+R=$PWD; TAG=${1:-r06}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 export PYTHONUNBUFFERED=1
 if [ -z "$SKIP_TESTS" ]; then

@@ -1,9 +1,9 @@
 #!/bin/bash
 # only the HBM-traffic pass of tools/gpu_round.sh: rocprofv3 --pmc FETCH_SIZE (own pass, counters only) over a short bench.py, per-kernel means x 2 (gfx950
 # correction), written with the digest of the decode sources it profiled (merged into <out>/hbm_traffic.json under the model's key; a
-# file with another digest is started over).  usage: tools/pmc_traffic.sh [r05] [7B|14B|...]
+# file with another digest is started over).  usage: tools/pmc_traffic.sh [r06] [7B|14B|...]
 cd "$(dirname "$0")/.."
-R=$PWD; TAG=${1:-r05}; MODEL=${2:-7B}; O=$R/gpurun_out/$TAG
+R=$PWD; TAG=${1:-r06}; MODEL=${2:-7B}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/pmc

@@ -2,9 +2,9 @@
 # HBM traffic of the chunk path from counters: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one counter per pass, counters only) over
 # (a) BASELINE config 5, one 32-token chunk per call, and (b) a 512-token prompt in one call (64-row passes, three stage streams), summed over
 # the k_seq_* kernels per weight pass and set against the weight bytes of a pass -> <out>/prefill_traffic.json (what bench.py's prefill /
-# long_prompt legs quote, keyed on the digest of seq.hip.h + engine.hip) + the per-kernel tables.  usage: tools/prefill_traffic.sh [r05]
+# long_prompt legs quote, keyed on the digest of seq.hip.h + engine.hip) + the per-kernel tables.  usage: tools/prefill_traffic.sh [r06]
 cd "$(dirname "$0")/.."
-R=$PWD; TAG=${1:-r05}; O=$R/gpurun_out/$TAG
+R=$PWD; TAG=${1:-r06}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for CFG in "chunk32 32 2" "prompt512 512 1"; do
