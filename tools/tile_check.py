@@ -15,7 +15,6 @@ t = mf.synthetic_tensors_torch(L, D, seed=0)
 
 def make(tile):
     os.environ["RWKV_TILE"] = str(tile)
-    os.environ["RWKV_CARRY"] = "0"
     m = engine.RWKV(resident=True); m.loadTensors(L, D, t, maxGPT=32)
     return m
 
@@ -40,7 +39,7 @@ for mask in (1, 2, 4, 8, 15):
 if tlc:
     names = ["entry", "prologue issued", "loader done", "tuple arrived", "site reduced", "staged", "loop end", "end"]
     os.environ["RWKV_TL_CLASS"] = str(tlc)
-    for label, m in ((f"class {tlc} row form (RWKV_CARRY=0)", a), (f"class {tlc} tile form", b)):
+    for label, m in ((f"class {tlc} row form", a), (f"class {tlc} tile form", b)):
         for rep in range(2):
             buf = m.debug_timeline(9).reshape(-1, 8, 8)[:256].astype(np.int64)
             t0 = buf[:, :, 0][buf[:, :, 0] > 0].min()
