@@ -131,3 +131,32 @@ def test_each_production_decode_kernel_against_its_oracle_piece(built, oracle, m
     note("head", _close(m.logits(1)[:V], logits_ref, "k_head: logits"))
     print(f"D={D} RWKV_TILE={tile} decode_form={m.decode_form()} grid={G}: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
     m.close()
+
+
+def test_debug_hooks_refuse_what_they_cannot_run_and_round_trip_a_buffer(built):
+    """rwkv_debug_launch / _read / _write (include/rwkv_mi355x.h): bad class, foreign layer, bad slot and a wrong-sized write fail with a
+    message instead of launching; a vector written into the context comes back unchanged; a context that owns a layer range runs only its own
+    layers and, without the head, neither class 5 nor 6."""
+    from rwkv_cpp_accelerated_amd import engine, pipeline
+    L, D = 3, 768
+    t = mf.synthetic_tensors(L, D, seed=77)
+    m = engine.RWKV(resident=True); m.loadTensors(L, D, t)
+    for bad in (dict(cls=7), dict(cls=-1), dict(cls=2, layer=L), dict(cls=0, slot=5), dict(cls=0, token=mf.VOCAB)):
+        with pytest.raises(engine.RWKVError):
+            m.debug_launch(bad.get("cls"), bad.get("layer", 0), bad.get("token", 1), bad.get("slot", 0))
+    x = np.random.default_rng(1).standard_normal(D)
+    m.debug_write("x", x)
+    assert np.array_equal(m.debug_read("x"), x)
+    with pytest.raises(engine.RWKVError):
+        m.debug_write("x", x[: D // 2])
+    assert m.debug_grid() >= 1 and m.debug_read("lnstat").shape == (6,)
+    m.close()
+    st = pipeline.EngineStage(t, L, D, 0, 2, n_slots=1)          # layers [0, 2): no head
+    st.m.debug_launch(0, 0, 9, 0)
+    for cls in (1, 2, 3, 4):
+        st.m.debug_launch(cls, 0)
+    st.m.debug_launch(1, 1)
+    for cls, layer in ((1, 2), (5, 0), (6, 0)):
+        with pytest.raises(engine.RWKVError):
+            st.m.debug_launch(cls, layer)
+    st.m.close()
