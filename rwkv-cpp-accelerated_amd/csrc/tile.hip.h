@@ -296,7 +296,7 @@ __device__ __forceinline__ void tile_stash_done(TileCtl *tc, int lane)
 }
 
 // the loader wave's whole life: zero the control block and the tile sums, first units before the order barrier, the stream, the landing
-template <int S, int UPT, int RUN, int TH, class Src>
+template <int S, int UPT, int RUN, int TH, int PRE = RWKV_RING_PRE, class Src>
 __device__ __forceinline__ unsigned tile_loader(int NU, int ntile, unsigned char *ring, int ns, TileCtl *tc, int *tsum, int lane, Src unit_src)
 {
     static_assert(UPT % 2 == 0, "pairs of units never straddle a tile");
@@ -311,7 +311,7 @@ __device__ __forceinline__ unsigned tile_loader(int NU, int ntile, unsigned char
         u += 2; c += 2; src += 2 * S * 1024;
         if (c == UPT) { c = 0; src = unit_src(u < NU ? u : 0); }
     };
-    const int pre = RWKV_RING_PRE < ns - 2 ? RWKV_RING_PRE : ns - 2;
+    const int pre = PRE < ns - 2 ? PRE : ns - 2;
     for (; u < NU && u < pre; next()) ld.template pair<RWKV_RING_PRE_DEPTH>(src);
     __syncthreads();   // order: the control block is zero, the prologue's requests are in the pipe
     // (TEST build -DRWKV_TEST_DROP_GROUP=1, tests/test_engine_gpu.py: the loader "loses" the workgroup's last pair of units -- the consumers'
@@ -416,6 +416,21 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
     }
 }
 
+// Units (of S KiB) a tile-form loader requests IN FRONT of the workgroup's order barrier, per kernel class.  The row-form default (RWKV_RING_PRE = 8
+// rows) puts 32 KiB of weights into the CU's in-order memory path ahead of the prologue's loads (rule 1): round 6 measured the
+// kernels whose prologue is their critical path with fewer (profiles/r06/tile_pre_ab.txt).
+#ifndef RWKV_TILE_PRE_ATT
+#define RWKV_TILE_PRE_ATT 0
+#endif
+#ifndef RWKV_TILE_PRE_ATTOUT
+#define RWKV_TILE_PRE_ATTOUT 4
+#endif
+#ifndef RWKV_TILE_PRE_FRK
+#define RWKV_TILE_PRE_FRK 4
+#endif
+#ifndef RWKV_TILE_PRE_FV
+#define RWKV_TILE_PRE_FV RWKV_RING_PRE
+#endif
 // Every tile-form kernel: workgroup b owns CPW = TH * TPC consecutive channels -- TPC tiles of TH rows per row class (TH = 16, TPC = 1: D = 4096
 // on 256 CUs, the chunk path's own image; TH = 4: a decode-only image, TPC = 5 at D = 5120, 2 at D = 2048).  KBT = fragments (1 KiB) of a
 // tile along K (K TH / 1024), S = fragments (KiB) per ring unit, SD = ceil(D / 1024).  The argument blocks are the row-form kernels' (site,
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
     float pmax = 0.f;
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_FRK>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
         tl_stamp(a.tl, 2);
     } else {
         if (wave < TILE_NWP) {
@@ -555,7 +570,7 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
     float pmax = 0.f;
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_ATT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
         tl_stamp(a.tl, 2);
     } else {
         const size_t so = (size_t)a.ctl->slot * a.slot_stride;
@@ -674,7 +689,7 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
     };
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_ATTOUT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
         tl_stamp(a.tl, 2);
     } else {
         const double mean1 = a.lnstat[0], rstd1 = a.lnstat[1];
@@ -756,7 +771,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
     };
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_FV>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
         tl_stamp(a.tl, 2);
     } else {
         const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
