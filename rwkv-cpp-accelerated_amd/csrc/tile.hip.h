@@ -29,6 +29,14 @@ namespace rwkvk {
 constexpr double TILE_CU = 4227200.0;          // 128 * (1 + 256 + 65536) - 2^22: coefficient of the unsigned row sum (= seq.hip.h SEQ_CU)
 constexpr double TILE_CN = -1077952512.0;      // -16384 * 65793: coefficient of N (elements of the vector) beside 128 * sum_j (q_j + 2^22)
 
+// TUNING builds (tools/stream_profile.py; never the shipped library): -DRWKV_TL_STREAM=1 the loader stamps the stream's progress (slot 1 behind the
+// order barrier, 3 / 4 / 5 a quarter / half / three quarters of its units requested) and every consumer wave records the time it waited for
+// units (slot 2); =2 every wave stamps its arrival at and departure from the order barrier (slots 1 and 2; the loader 3 and 1)
+#if RWKV_TL_STREAM == 2
+#define TL_BAR(tl, ph) tl_stamp(tl, ph)
+#else
+#define TL_BAR(tl, ph)
+#endif
 constexpr int TILE_NWP = NT / 2 / 64;          // prologue waves (0 .. 3)
 constexpr int TILE_NSTASH = NC - TILE_NWP;     // consumer waves that fetch the epilogues' inputs meanwhile (4 .. 6)
 struct TileCtl {                 // LDS control block of a tile-form ring
@@ -96,6 +104,7 @@ __device__ __forceinline__ void tile_site(const SiteStatic &st, const SiteDyn &d
     tl_stamp(tl, 1);
     if (threadIdx.x == 0) *spin = 0u;
     __syncthreads();   // order
+    TL_BAR(tl, 2);
     SiteRed<NV> r;
     site_reduce<NV, NWP>(st, dy, tup, D, red, r, tcs, mc, tl, spin);
     if (publish_stats && blockIdx.x == 0 && threadIdx.x == 0) { dy.lnstat[0] = r.mean; dy.lnstat[1] = r.rstd; }
@@ -257,6 +266,7 @@ __device__ __forceinline__ void tile_vec(const float *vec, const double *partS, 
     tl_stamp(tl, 1);
     if (threadIdx.x == 0) *spin = 0u;
     __syncthreads();   // order
+    TL_BAR(tl, 2);
     if ((int)threadIdx.x >= n_part) { ps = 0.0; pm = 0.f; }
     float *redf = reinterpret_cast<float *>(red + RED_MAX);
     const double ws = wave_sum(ps);
@@ -297,7 +307,8 @@ __device__ __forceinline__ void tile_stash_done(TileCtl *tc, int lane)
 
 // the loader wave's whole life: zero the control block and the tile sums, first units before the order barrier, the stream, the landing
 template <int S, int UPT, int RUN, int TH, int PRE = RWKV_RING_PRE, class Src>
-__device__ __forceinline__ unsigned tile_loader(int NU, int ntile, unsigned char *ring, int ns, TileCtl *tc, int *tsum, int lane, Src unit_src)
+__device__ __forceinline__ unsigned tile_loader(int NU, int ntile, unsigned char *ring, int ns, TileCtl *tc, int *tsum, int lane, Src unit_src,
+                                                unsigned long long *tl = nullptr)
 {
     static_assert(UPT % 2 == 0, "pairs of units never straddle a tile");
     loader_clean_slate();
@@ -313,7 +324,18 @@ __device__ __forceinline__ unsigned tile_loader(int NU, int ntile, unsigned char
     };
     const int pre = PRE < ns - 2 ? PRE : ns - 2;
     for (; u < NU && u < pre; next()) ld.template pair<RWKV_RING_PRE_DEPTH>(src);
+    TL_BAR(tl, 3);
     __syncthreads();   // order: the control block is zero, the prologue's requests are in the pipe
+    TL_BAR(tl, 1);
+#if RWKV_TL_STREAM == 1
+    tl_stamp(tl, 1);
+    for (; u < NU; next()) {
+        ld.template pair<(RWKV_RING_DEPTH < 63 ? RWKV_RING_DEPTH : 63)>(src);
+        if (u + 2 == (NU / 4 & ~1)) tl_stamp(tl, 3);
+        if (u + 2 == (NU / 2 & ~1)) tl_stamp(tl, 4);
+        if (u + 2 == (3 * NU / 4 & ~1)) tl_stamp(tl, 5);
+    }
+#endif
     // (TEST build -DRWKV_TEST_DROP_GROUP=1, tests/test_engine_gpu.py: the loader "loses" the workgroup's last pair of units -- the consumers'
     // bounded wait must give up and the call must fail with RWKV_E_DEVICE instead of returning garbage)
     for (; u < NU - (RWKV_TEST_DROP_GROUP ? 2 : 0); next()) ld.template pair<(RWKV_RING_DEPTH < 63 ? RWKV_RING_DEPTH : 63)>(src);
@@ -345,19 +367,25 @@ __device__ __forceinline__ double tile_cA(const TileCtl *tc, int m, double n)
 // (all lanes; the tile's row sums are final: tile_row_sum).
 template <int TH, int S, int UPT, int RUN, class VecOf, class OnTile>
 __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, int ns, TileCtl *tc, int *tsum, const unsigned *xq, int xvd_t,
-                                             int wave, int lane, unsigned &fail, VecOf vec_of, OnTile on_tile)
+                                             int wave, int lane, unsigned &fail, VecOf vec_of, OnTile on_tile, unsigned long long *tl = nullptr)
 {
     static_assert(UPT % RUN == 0, "a run of units never straddles a tile");
     constexpr int PPB = 64 / TH;                         // 16-byte pieces of k per row and fragment
     const int pc = lane / TH, r = lane % TH;
     int acc0 = 0, acc1 = 0, acc2 = 0, cnt = 0;
     unsigned taken = 0, seen = 0;
+#if RWKV_TL_STREAM == 1
+    unsigned long long waited = 0;
+#endif
     unsigned p = (unsigned)(wave * RUN) % (unsigned)ns;      // ring position of the wave's next unit: advanced unit by unit, run by run
     for (int run = wave; run * RUN < NU; run += NC) {
 #pragma unroll 1
         for (int cc = 0; cc < RUN; cc++) {
             const int u = run * RUN + cc;
             if ((int)(seen - (unsigned)(u + 1)) < 0) {       // (`landed` only grows: what an earlier look saw still holds)
+#if RWKV_TL_STREAM == 1
+                const unsigned long long w0 = wall_clock64();
+#endif
                 bool ok = false;
                 for (int it = 0; it < GLDS_SPIN; it++) {
                     seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tc->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -365,6 +393,9 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
                     __builtin_amdgcn_s_sleep(1);
                 }
                 fail = ok ? fail : 2u;
+#if RWKV_TL_STREAM == 1
+                waited += wall_clock64() - w0;
+#endif
             }
             const u32x4 *wp = reinterpret_cast<const u32x4 *>(ring + (size_t)p * (S * 1024)) + lane;
             u32x4 w[S];
@@ -414,6 +445,9 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
         p += (unsigned)((NC - 1) * RUN);
         while (p >= (unsigned)ns) p -= (unsigned)ns;
     }
+#if RWKV_TL_STREAM == 1
+    if (tl && lane == 0) tl[((size_t)blockIdx.x * NW + wave) * 8 + 2] = waited;
+#endif
 }
 
 // Units (of S KiB) a tile-form loader requests IN FRONT of the workgroup's order barrier, per kernel class.  The row-form default (RWKV_RING_PRE = 8
@@ -481,7 +515,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
     float pmax = 0.f;
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_FRK>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_FRK>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
         tl_stamp(a.tl, 2);
     } else {
         if (wave < TILE_NWP) {
@@ -495,7 +529,9 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
             const unsigned *src = wave == 4 ? a.rs + ch0 * 5 : reinterpret_cast<const unsigned *>(wave == 5 ? a.r_fv + ch0 * 4 : a.o_fv + ch0 * 4);
             if (lane < n) v0 = src[lane];
             if (lane + 64 < n) v1 = src[lane + 64];
+            TL_BAR(a.tl, 1);
             __syncthreads();   // order
+            TL_BAR(a.tl, 2);
             unsigned *dst = stash + (wave == 4 ? 0 : wave == 5 ? 5 * CPW : 9 * CPW);
             if (lane < n) dst[lane] = v0;
             if (lane + 64 < n) dst[lane + 64] = v1;
@@ -527,7 +563,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
                 }
             }
         };
-        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t / TPC < 4 ? 0 : 1; }, on_tile);
+        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t / TPC < 4 ? 0 : 1; }, on_tile, a.tl);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();   // every wave is past its last read of the reduction scratch
@@ -570,7 +606,7 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
     float pmax = 0.f;
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_ATT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_ATT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
         tl_stamp(a.tl, 2);
     } else {
         const size_t so = (size_t)a.ctl->slot * a.slot_stride;
@@ -585,7 +621,9 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
             else if (wave == 5) { if (lane < 4 * CPW) d0 = dsrc(lane); if (lane + 64 < 4 * CPW) d1 = dsrc(lane + 64); }
             else if (lane < 2 * CPW) v0 = __float_as_uint(lane < CPW ? a.r_att[ch0 + lane] : a.o_att[ch0 + lane - CPW]);
             (void)v1;
+            TL_BAR(a.tl, 1);
             __syncthreads();   // order
+            TL_BAR(a.tl, 2);
             if (wave == 4) { if (lane < 3 * CPW) stash[lane] = v0; }
             else if (wave == 5) { if (lane < 4 * CPW) sd[lane] = d0; if (lane + 64 < 4 * CPW) sd[lane + 64] = d1; }
             else if (lane < 2 * CPW) sf[lane] = __uint_as_float(v0);
@@ -626,7 +664,7 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
                 pmax = fmaxf(pmax, fabsf(ys));
             }
         };
-        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t / TPC; }, on_tile);
+        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t / TPC; }, on_tile, a.tl);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
@@ -689,7 +727,7 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
     };
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_ATTOUT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_ATTOUT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
         tl_stamp(a.tl, 2);
     } else {
         const double mean1 = a.lnstat[0], rstd1 = a.lnstat[1];
@@ -704,7 +742,9 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
             if (wave == 4) { if (lane < 4 * CPW) d0 = dsrc(lane); if (lane + 64 < 4 * CPW) d1 = dsrc(lane + 64); }
             else if (wave == 5) { if (lane < 3 * CPW) p0 = reinterpret_cast<const f32x4 *>(a.st.P + (size_t)ch0 * 12)[lane]; }
             else if (lane < CPW) v0 = a.rs[ch0 + lane];
+            TL_BAR(a.tl, 1);
             __syncthreads();   // order
+            TL_BAR(a.tl, 2);
             if (wave == 4) { if (lane < 4 * CPW) sd[lane] = d0; if (lane + 64 < 4 * CPW) sd[lane + 64] = d1; }
             else if (wave == 5) { if (lane < 3 * CPW) reinterpret_cast<f32x4 *>(sp)[lane] = p0; }
             else if (lane < CPW) srs[lane] = v0;
@@ -733,7 +773,7 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
                 tile_site_leave<2>(acc, scr, CPW, li);
             }
         };
-        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile);
+        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile, a.tl);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
@@ -771,7 +811,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
     };
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_FV>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src);
+        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_FV>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
         tl_stamp(a.tl, 2);
     } else {
         const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
@@ -787,7 +827,9 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
             if (wave == 4) { if (lane < 4 * CPW) d0 = dsrc(lane); if (lane + 64 < 4 * CPW) d1 = dsrc(lane + 64); }
             else if (wave == 5) { if (lane < NP4) p0 = reinterpret_cast<const f32x4 *>(a.st.P + (size_t)ch0 * PW)[lane]; if (lane + 64 < NP4) p1 = reinterpret_cast<const f32x4 *>(a.st.P + (size_t)ch0 * PW)[lane + 64]; }
             else if (lane < 2 * CPW) v0 = lane < CPW ? a.rs[ch0 + lane] : __float_as_uint(a.rgate[ch0 + lane - CPW]);
+            TL_BAR(a.tl, 1);
             __syncthreads();   // order
+            TL_BAR(a.tl, 2);
             if (wave == 4) { if (lane < 4 * CPW) sd[lane] = d0; if (lane + 64 < 4 * CPW) sd[lane + 64] = d1; }
             else if (wave == 5) { if (lane < NP4) reinterpret_cast<f32x4 *>(sp)[lane] = p0; if (lane + 64 < NP4) reinterpret_cast<f32x4 *>(sp)[lane + 64] = p1; }
             else if (lane < 2 * CPW) srs[lane] = v0;          // (rs[CPW] and rgate[CPW] are adjacent)
@@ -816,7 +858,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
                 tile_site_leave<NVN>(acc, scr, CPW, li);
             }
         };
-        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile);
+        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile, a.tl);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
