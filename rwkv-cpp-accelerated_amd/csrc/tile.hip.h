@@ -20,7 +20,12 @@
 //     coefficient 4227200 the chunk path uses (seq.hip.h SEQ_CU).  Every row value is the SAME exact integer as in row form: logits and
 //     state are bit-identical to the row-form kernels' for every mix of forms (tests/test_engine_gpu.py);
 //   * staged vector layout [16-byte piece along k][limb][16 B]: a lane's operand is one ds_read_b128, TH lanes share an address (broadcast).
-// Integer contraction on the VALU, like row form; MFMA stays where the north_star puts it (the batched mm8_seq case).
+// Integer contraction, since round 6 on the matrix cores: a 16-row fragment IS v_mfma_i32_16x16x64_i8's B operand as it lies in the ring, with the staged
+// vector as the A operand (its three limbs = rows 0..2 of 16); a 4-row fragment is the B operand of 16 virtual rows (row, piece % 4) against an A whose
+// twelve rows are (limb, piece % 4), the diagonal blocks of the product being what belongs together (tile_consume).  Per fragment one 16-byte LDS read and
+// one instruction where the VALU form (v_dot4_i32_i8, kept behind RWKV_TILE_MFMA / RWKV_TILE_MFMA4 = 0) needs three reads and twelve dot instructions.
+// Not a reshaping of the GEMV into a GEMM: a launch streams the same bytes once and stays HBM-bound; the consumers leave the LDS pipe to the DMA and
+// follow the stream more closely (+1.2 % on the 7B token, +2.8 % at 14B, +1.7 % at 1B5).
 #pragma once
 #include "kernels.hip.h"
 
@@ -37,6 +42,17 @@ constexpr double TILE_CN = -1077952512.0;      // -16384 * 65793: coefficient of
 #else
 #define TL_BAR(tl, ph)
 #endif
+// Tiles are multiplied on the matrix cores (1; round 6, profiles/r06/mfma_consumer_ab.txt: 16-row tiles 614.4 -> 621.8 tokens/s at 7B; 4-row tiles
+// 355.4 -> 365.4 at 14B, 1351 -> 1374 at 1B5) or with v_dot4 on the VALU (0: round 5's form).  Same exact integers either way; tile form == row form
+// bit for bit is a GPU test (tests/test_engine_gpu.py).
+#ifndef RWKV_TILE_MFMA           // 16-row tiles
+#define RWKV_TILE_MFMA 1
+#endif
+#ifndef RWKV_TILE_MFMA4          // 4-row tiles
+#define RWKV_TILE_MFMA4 1
+#endif
+constexpr bool TILE_MFMA = RWKV_TILE_MFMA != 0, TILE_MFMA4 = RWKV_TILE_MFMA4 != 0;
+typedef int tile_i32x4 __attribute__((ext_vector_type(4)));
 constexpr int TILE_NWP = NT / 2 / 64;          // prologue waves (0 .. 3)
 constexpr int TILE_NSTASH = NC - TILE_NWP;     // consumer waves that fetch the epilogues' inputs meanwhile (4 .. 6)
 struct TileCtl {                 // LDS control block of a tile-form ring
@@ -373,6 +389,7 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
     constexpr int PPB = 64 / TH;                         // 16-byte pieces of k per row and fragment
     const int pc = lane / TH, r = lane % TH;
     int acc0 = 0, acc1 = 0, acc2 = 0, cnt = 0;
+    tile_i32x4 ma = tile_i32x4{0, 0, 0, 0}, mb = tile_i32x4{0, 0, 0, 0};
     unsigned taken = 0, seen = 0;
 #if RWKV_TL_STREAM == 1
     unsigned long long waited = 0;
@@ -408,28 +425,75 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
             if (lane == 0) __hip_atomic_store(&tc->freed[wave], taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             p = p + 1 == (unsigned)ns ? 0u : p + 1;
             const int t = u / UPT, c = u - t * UPT;
-            const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + pc) * 3;
+            if constexpr (TILE_MFMA && TH == 16) {
+                // a 16-row fragment IS the B operand of v_mfma_i32_16x16x64_i8 and the staged vector's (k-block, piece, limb) order its A operand with
+                // the three limbs as rows 0..2: one 16-byte LDS read and one matrix instruction per fragment where the VALU form needs three reads and
+                // twelve dot instructions.  Rows 3..15 of A are whatever those lanes read (limb 2 again): their outputs are never looked at.
+                // The sums are the same exact integers.
+                const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + pc) * 3 + (r < 3 ? r : 2);
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                const u32x4 x0 = xp[s * PPB * 3], x1 = xp[s * PPB * 3 + 1], x2 = xp[s * PPB * 3 + 2];
+                for (int s = 0; s < S; s++) {
+                    const u32x4 x = xp[s * PPB * 3];
+                    const tile_i32x4 af = tile_i32x4{(int)x[0], (int)x[1], (int)x[2], (int)x[3]}, bf = tile_i32x4{(int)w[s][0], (int)w[s][1], (int)w[s][2], (int)w[s][3]};
+                    if (s & 1) mb = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, mb, 0, 0, 0);
+                    else ma = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, ma, 0, 0, 0);
+                }
+            } else if constexpr (TILE_MFMA4 && TH == 4) {
+                // a 4-row fragment (lane l = piece l / 4 of row l % 4; 16 pieces = 256 inputs) read as a B operand is 16 VIRTUAL rows n = (row, piece % 4)
+                // whose k-piece j is the row's piece 4 j + (piece % 4).  A's rows are (limb b, q): A[(b, q)][j] = limb b of piece 4 j + q, so that
+                // D[(b, q)][(row, q)] -- the diagonal blocks -- are the products that belong together; a row's limb sum is the sum of its four q.
+                // Twelve of A's sixteen rows carry data; one instruction per fragment, like the 16-row form.
+                const int m = (lane & 15) < 12 ? (lane & 15) : 11;
+                const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + 4 * (lane >> 4) + (m & 3)) * 3 + (m >> 2);
 #pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    acc0 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x0[d], acc0, false);
-                    acc1 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x1[d], acc1, false);
-                    acc2 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x2[d], acc2, false);
+                for (int s = 0; s < S; s++) {
+                    const u32x4 x = xp[s * PPB * 3];
+                    const tile_i32x4 af = tile_i32x4{(int)x[0], (int)x[1], (int)x[2], (int)x[3]}, bf = tile_i32x4{(int)w[s][0], (int)w[s][1], (int)w[s][2], (int)w[s][3]};
+                    if (s & 1) mb = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, mb, 0, 0, 0);
+                    else ma = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, ma, 0, 0, 0);
+                }
+            } else {
+                const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + pc) * 3;
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    const u32x4 x0 = xp[s * PPB * 3], x1 = xp[s * PPB * 3 + 1], x2 = xp[s * PPB * 3 + 2];
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        acc0 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x0[d], acc0, false);
+                        acc1 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x1[d], acc1, false);
+                        acc2 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x2[d], acc2, false);
+                    }
                 }
             }
             cnt++;
             const int un = cc + 1 < RUN ? u + 1 : (run + NC) * RUN;      // this wave's next unit
             if (un >= NU || un / UPT != t) {
-                if (TH == 4) {
+                if constexpr (TILE_MFMA4 && TH == 4) {
+                    // accumulator image: lane (n = l % 16, g = l / 16) holds D[(g, i)][n] in register i: limb g of virtual row n = (row n % 4, q = n / 4)
+                    // is register n / 4; the four q of a row sit 4 lanes apart inside the 16 lanes
+                    const int n = lane & 15;
+                    const tile_i32x4 sa = ma + mb;
+                    int v = n < 4 ? sa[0] : n < 8 ? sa[1] : n < 12 ? sa[2] : sa[3];
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);
+                    if (n < 4 && lane < 48) __hip_atomic_fetch_add(tsum + (t * TH + n) * 3 + (lane >> 4), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ma = mb = tile_i32x4{0, 0, 0, 0};
+                } else if (TH == 4) {
                     // 16 lanes hold pieces of one row: fold the pieces 4 apart inside every row of 16 lanes first (DPP), then the four rows of
                     // 16 lanes meet in LDS like the four k-quarters of the 16-row form
                     acc0 += __builtin_amdgcn_update_dpp(0, acc0, 0x124, 0xf, 0xf, true); acc0 += __builtin_amdgcn_update_dpp(0, acc0, 0x128, 0xf, 0xf, true);
                     acc1 += __builtin_amdgcn_update_dpp(0, acc1, 0x124, 0xf, 0xf, true); acc1 += __builtin_amdgcn_update_dpp(0, acc1, 0x128, 0xf, 0xf, true);
                     acc2 += __builtin_amdgcn_update_dpp(0, acc2, 0x124, 0xf, 0xf, true); acc2 += __builtin_amdgcn_update_dpp(0, acc2, 0x128, 0xf, 0xf, true);
                 }
-                if (TH == 16 || (lane & 15) < 4) {
+                if constexpr (TILE_MFMA && TH == 16) {      // (accumulator image: lane n < 16 holds row n's three limb sums in registers 0..2)
+                    if (lane < 16) {
+                        int *ts = tsum + (t * TH + lane) * 3;
+                        __hip_atomic_fetch_add(ts + 0, ma[0] + mb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(ts + 1, ma[1] + mb[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(ts + 2, ma[2] + mb[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    ma = mb = tile_i32x4{0, 0, 0, 0};
+                } else if constexpr (TILE_MFMA4 && TH == 4) {
+                } else if (TH == 16 || (lane & 15) < 4) {
                     int *ts = tsum + (t * TH + r) * 3;
                     __hip_atomic_fetch_add(ts + 0, acc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(ts + 1, acc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -452,7 +516,7 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
 
 // Units (of S KiB) a tile-form loader requests IN FRONT of the workgroup's order barrier, per kernel class.  The row-form default (RWKV_RING_PRE = 8
 // rows) puts 32 KiB of weights into the CU's in-order memory path ahead of the prologue's loads (rule 1): round 6 measured the
-// kernels whose prologue is their critical path with fewer (profiles/r06/tile_pre_ab.txt).
+// kernels whose prologue is their critical path with fewer (profiles/r06/tile_pre_ab.txt; 4-row tiles at D = 5120: tile_pre_14b_ab.txt).
 #ifndef RWKV_TILE_PRE_ATT
 #define RWKV_TILE_PRE_ATT 0
 #endif
@@ -464,6 +528,9 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
 #endif
 #ifndef RWKV_TILE_PRE_FV
 #define RWKV_TILE_PRE_FV RWKV_RING_PRE
+#endif
+#ifndef RWKV_TILE_PRE_FV4        // k_ffnv_t on 4-row tiles (D = 5120: 80 KB of hidden units to stage per workgroup): 14B 350.3 -> 354.9 tokens/s with none in front
+#define RWKV_TILE_PRE_FV4 0
 #endif
 // Every tile-form kernel: workgroup b owns CPW = TH * TPC consecutive channels -- TPC tiles of TH rows per row class (TH = 16, TPC = 1: D = 4096
 // on 256 CUs, the chunk path's own image; TH = 4: a decode-only image, TPC = 5 at D = 5120, 2 at D = 2048).  KBT = fragments (1 KiB) of a
@@ -811,7 +878,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
     };
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_FV>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
+        fail = tile_loader<S, UPT, RUN, TH, (TH == 16 ? RWKV_TILE_PRE_FV : RWKV_TILE_PRE_FV4)>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
         tl_stamp(a.tl, 2);
     } else {
         const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
