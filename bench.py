@@ -211,7 +211,7 @@ def main():
         metric="tokens/sec single-stream RWKV-4 uint8 greedy decode",
         value=round(tok_s, 2), unit="tokens/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
         ms_per_step=round(1e3 * dt / args.steps, 5), higher_is_better=True, scaling="weak",
-        vs_baseline=None, dtype="u8 weights x 23-bit fixed-point activations, exact 32-bit integer accumulate (v_dot4 on the VALU: i32_i8 on signed limbs in tile form, u32_u8 in row form); f32/f64 epilogues, f64 state", data="synthetic",
+        vs_baseline=None, dtype="u8 weights x 23-bit fixed-point activations, exact 32-bit integer accumulate (tile form: v_mfma_i32_16x16x64_i8 on signed limbs; row form: v_dot4_u32_u8 on the VALU); f32/f64 epilogues, f64 state", data="synthetic",
         config=dict(workload=f"RWKV-4-Raven-{args.model} uint8 single-stream greedy decode "
                              f"(L={L}, D={D}, V={mf.VOCAB}), 32-token prompt then {args.steps}-token continuation, "
                              "device-resident state",
@@ -402,7 +402,7 @@ def pipeline_line(*, model, L, D, world, steps, warmup, dt, one_steps, dt1, per_
         value=round(tok_s, 2), unit="tokens/s",
         n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(1e3 * dt / steps, 5),
         higher_is_better=True, scaling="weak", vs_baseline=None,
-        dtype="u8 weights x 23-bit fixed-point activations, exact 32-bit integer accumulate (v_dot4 on the VALU: i32_i8 on signed limbs in tile form, u32_u8 in row form); f32/f64 epilogues, f64 state",
+        dtype="u8 weights x 23-bit fixed-point activations, exact 32-bit integer accumulate (tile form: v_mfma_i32_16x16x64_i8 on signed limbs; row form: v_dot4_u32_u8 on the VALU); f32/f64 epilogues, f64 state",
         data="synthetic",
         config=dict(workload=f"RWKV-4-Raven-{model} uint8 greedy decode (L={L}, D={D}), layers pipelined over {world} GPUs, "
                              f"{world} independent streams in flight (one per stage), {steps} tokens per stream",

@@ -180,7 +180,7 @@ struct rwkv_ctx {
                              // a wave's tiles in batches, one round of workgroups (env RWKV_SEQ_B; 0: k_seq_gemm_p<.., true, 2>; -1: ffn k/r always, K/V/R at D >= 4096:
                              // +1-2 % there, -1.5 % at D = 2048, profiles/r04/gemm_b_ab2.txt)
     int tile = -1;           // decode kernel classes that run in TILE form (tile.hip.h; bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv; env RWKV_TILE; -1 = auto: 15 at
-                             // D = 4096 and 5120 on 256 CUs, ffn k/r alone at D = 2048, else 0).  15: the context holds ONLY the tile image of the per-layer
+                             // D = 4096 and 5120 on 256 CUs, 13 at D = 2048, else 0).  15: the context holds ONLY the tile image of the per-layer
                              // matrices; a partial mask keeps both layouts (tuning)
     int ring = RWKV_RING;    // decode kernels that stream their weights through the LDS ring (bit 0 k_att, 1 k_attout, 2 k_ffn_rk, 3 k_ffnv, 4 k_head; env RWKV_RING)
 
@@ -774,10 +774,10 @@ int load_common(rwkv_ctx *c, Source &src, uint64_t L, uint64_t D, uint64_t max_c
     // (+ its tile image for the chunk path).
     const bool want_seq = [&] { const char *e = getenv("RWKV_SEQ"); return max_ctx > 1 && D % 64 == 0 && !(e && e[0] == '0'); }();
     const TileCfg tcfg = tile_cfg_for(D, c->grid);
-    // auto: every class where a workgroup owns exactly one 16-channel block (D = 4096) and, on 4-row tiles, at D = 5120; ffn k/r alone at D = 2048.
-    // (Measured per mask with the per-class heads of round 6, profiles/r06/tile_masks_ab.txt: 14B 345.7 -> 350.5 tokens/s, 1B5 1345 -> 1359; round 5's
-    // constants had the other classes faster in row form at both widths, profiles/r05/tile_14B_masks.txt.)
-    if (c->tile < 0) c->tile = tcfg.th == 16 || tcfg.tpc == 5 ? 15 : tcfg.tpc == 2 ? 4 : 0;
+    // auto: every class where a workgroup owns exactly one 16-channel block (D = 4096) and, on 4-row tiles, at D = 5120; K/V/R, ffn k/r and ffn_v at
+    // D = 2048 (att_out: 4.8 us in row form, 5.2 in tile form).  Measured per mask with round 6's per-class heads and matrix-core consumers
+    // (profiles/r06/tile_masks_ab.txt: 14B 345.7 -> 365 tokens/s, 1B5 1345 -> 1417); round 5's kernels had every class but 14B's ffn k/r faster in row form.
+    if (c->tile < 0) c->tile = tcfg.th == 16 || tcfg.tpc == 5 ? 15 : tcfg.tpc == 2 ? 13 : 0;
     if (tcfg.th == 0) c->tile = 0;
     c->tile &= 15;
     if (c->tile) { c->tile_th = tcfg.th; c->tile_s = tcfg.s; c->tile_tpc = tcfg.tpc; }
