@@ -188,7 +188,16 @@ template <> __device__ __forceinline__ void dma_unit_s<5>(const uint8_t *src, un
 // `landed` is stored by all lanes at once (lane 0 into the control block, the others into dump slots).  Consumers free units by
 // per-wave counters (unit u belongs to wave u % NC, which takes its units in order), so the first unit still in use is
 // min_w (NC * freed[w] + w): looked at only when the cached value says the ring is full.
-template <int S, int RUN = 1> struct TileLoader {
+// Who takes which unit when the stream has a HEAD (round 6; RUN = 1 only): the first HEAD units belong to the three consumer waves that do not stage
+// (waves 4 .. 6, round robin), who copy them into REGISTERS as they land -- while waves 0 .. 3 are still staging -- and hand their ring slots back: the ring's
+// capacity grows by HEAD units, the loader is not stopped by a slot whose owner is busy elsewhere (its tail only moves over LEADING free units).  Behind the
+// head: round robin over all seven.  The k-th unit of wave w:
+template <int HEAD> __host__ __device__ constexpr int tile_unit_of(int w, int k)
+{
+    constexpr int NE = HEAD / TILE_NSTASH;
+    return w >= TILE_NWP ? (k < NE ? TILE_NSTASH * k + (w - TILE_NWP) : HEAD + NC * (k - NE) + w) : HEAD + NC * k + w;
+}
+template <int S, int RUN = 1, int HEAD = 0> struct TileLoader {
     TileCtl *tc;
     unsigned ring, nu;
     unsigned issued = 0, pub = 0, tailu = 0, pos = 0;
@@ -221,8 +230,9 @@ template <int S, int RUN = 1> struct TileLoader {
     {
         const unsigned f = __hip_atomic_load(&tc->freed[lane & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
-        // the f-th unit wave w takes is unit ((f / RUN) NC + w) RUN + f % RUN: the first one it has NOT taken yet
-        const unsigned v = ((f / (unsigned)RUN) * (unsigned)NC + (unsigned)(lane & 7)) * (unsigned)RUN + f % (unsigned)RUN;
+        // the f-th unit wave w takes is unit ((f / RUN) NC + w) RUN + f % RUN: the first one it has NOT taken yet (HEAD > 0: tile_unit_of)
+        const unsigned v = HEAD > 0 ? (unsigned)tile_unit_of<HEAD>(lane & 7, (int)f)
+                                    : ((f / (unsigned)RUN) * (unsigned)NC + (unsigned)(lane & 7)) * (unsigned)RUN + f % (unsigned)RUN;
         unsigned m = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
 #pragma unroll
         for (int w = 1; w < NC; w++) { const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)v, w); m = o < m ? o : m; }
@@ -322,7 +332,7 @@ __device__ __forceinline__ void tile_stash_done(TileCtl *tc, int lane)
 }
 
 // the loader wave's whole life: zero the control block and the tile sums, first units before the order barrier, the stream, the landing
-template <int S, int UPT, int RUN, int TH, int PRE = RWKV_RING_PRE, class Src>
+template <int S, int UPT, int RUN, int TH, int PRE = RWKV_RING_PRE, int HEAD = 0, class Src>
 __device__ __forceinline__ unsigned tile_loader(int NU, int ntile, unsigned char *ring, int ns, TileCtl *tc, int *tsum, int lane, Src unit_src,
                                                 unsigned long long *tl = nullptr)
 {
@@ -330,7 +340,8 @@ __device__ __forceinline__ unsigned tile_loader(int NU, int ntile, unsigned char
     loader_clean_slate();
     for (int i = lane; i < (int)(sizeof(TileCtl) / 4); i += 64) reinterpret_cast<unsigned *>(tc)[i] = 0u;
     for (int i = lane; i < ntile * TH * 3; i += 64) tsum[i] = 0;
-    TileLoader<S, RUN> ld(tc, lds_addr(ring), ns, lane);
+    static_assert(HEAD == 0 || RUN == 1, "a head of the stream: round robin only");
+    TileLoader<S, RUN, HEAD> ld(tc, lds_addr(ring), ns, lane);
     // units in stream order = tile after tile, S k-blocks at a time: contiguous within a tile; the loader moves PAIRS of units
     const uint8_t *src = unit_src(0);
     int u = 0, c = 0;
@@ -374,151 +385,195 @@ __device__ __forceinline__ double tile_cA(const TileCtl *tc, int m, double n)
     return 128.0 * (double)__hip_atomic_load(&tc->sq[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + TILE_CN * n;
 }
 
+// per-wave state of a consumer's walk through the ring: units it has copied out (what it announces in freed[wave]), the last `landed` it saw
+struct TileWalk { unsigned taken = 0, seen = 0; unsigned long long waited = 0; };
+// wait for unit u, copy its S KiB out of ring slot p, hand the slot back
+template <int S>
+__device__ __forceinline__ void tile_take(const unsigned char *ring, unsigned p, int u, TileCtl *tc, int wave, int lane, TileWalk &wk, unsigned &fail, u32x4 (&w)[S])
+{
+    if ((int)(wk.seen - (unsigned)(u + 1)) < 0) {       // (`landed` only grows: what an earlier look saw still holds)
+#if RWKV_TL_STREAM == 1
+        const unsigned long long w0 = wall_clock64();
+#endif
+        bool ok = false;
+        for (int it = 0; it < GLDS_SPIN; it++) {
+            wk.seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tc->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if ((int)(wk.seen - (unsigned)(u + 1)) >= 0) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        fail = ok ? fail : 2u;
+#if RWKV_TL_STREAM == 1
+        wk.waited += wall_clock64() - w0;
+#endif
+    }
+    const u32x4 *wp = reinterpret_cast<const u32x4 *>(ring + (size_t)p * (S * 1024)) + lane;
+#pragma unroll
+    for (int s = 0; s < S; s++) w[s] = wp[s * 64];
+    wk.taken++;
+    // (relaxed + a compiler barrier: a wave's LDS operations execute in order, so the loader that sees the count finds the reads done;
+    // a release store would make the wave WAIT for its reads before it may even request the activation limbs)
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&tc->freed[wave], wk.taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the three non-staging consumer waves copy their units of the stream's head into registers while the vectors are being staged (tile_unit_of)
+template <int S, int HEAD>
+__device__ __forceinline__ void tile_pretake(int NU, const unsigned char *ring, int ns, TileCtl *tc, int wave, int lane, TileWalk &wk, unsigned &fail,
+                                             u32x4 (&wpre)[HEAD / TILE_NSTASH > 0 ? HEAD / TILE_NSTASH : 1][S])
+{
+    if constexpr (HEAD > 0) {
+        if (HEAD > ns) fail = 2u;                        // (the head lies in the ring's first lap: slot = unit; engine.hip sizes the ring)
+#pragma unroll
+        for (int k = 0; k < HEAD / TILE_NSTASH; k++) {
+            const int u = TILE_NSTASH * k + (wave - TILE_NWP);
+            if (u < NU && HEAD <= ns) tile_take<S>(ring, (unsigned)u, u, tc, wave, lane, wk, fail, wpre[k]);
+        }
+    }
+}
+
 // The consumer waves' streaming loop (wave < NC).  A tile is TH rows (16: the chunk path's image; 4: the decode-only image of widths
 // whose channels do not split into 16-row blocks per workgroup) x K inputs; a fragment (1 KiB, one wave instruction) holds TH rows x
 // 64 / TH 16-byte pieces of k: lane l = piece l / TH of row l % TH.  Unit u (tile u / UPT, fragments S (u % UPT) ..) belongs to the wave
-// that owns its RUN of units (run u / RUN -> wave (u / RUN) % NC; RUN = 1: round robin; RUN = UPT: a wave multiplies whole small tiles):
-// wait for it, copy its S KiB out of the ring, hand it back, multiply it with the limbs of vector vec_of(tile); when the wave's last
-// unit of a tile is in, its partial sums join the tile's in LDS and the unit count; the wave that completes the count calls on_tile(t)
-// (all lanes; the tile's row sums are final: tile_row_sum).
-template <int TH, int S, int UPT, int RUN, class VecOf, class OnTile>
+// that owns its RUN of units (run u / RUN -> wave (u / RUN) % NC; RUN = 1: round robin; RUN = UPT: a wave multiplies whole small tiles;
+// HEAD > 0: tile_unit_of): wait for it, copy its S KiB out of the ring, hand it back (tile_take), multiply it with the limbs of vector
+// vec_of(tile); when the wave's last unit of a tile is in, its partial sums join the tile's in LDS and the unit count; the wave that
+// completes the count calls on_tile(t) (all lanes; the tile's row sums are final: tile_row_sum).
+template <int TH, int S, int UPT, int RUN, int HEAD, class VecOf, class OnTile>
 __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, int ns, TileCtl *tc, int *tsum, const unsigned *xq, int xvd_t,
-                                             int wave, int lane, unsigned &fail, VecOf vec_of, OnTile on_tile, unsigned long long *tl = nullptr)
+                                             int wave, int lane, unsigned &fail, TileWalk &wk, const u32x4 (&wpre)[HEAD / TILE_NSTASH > 0 ? HEAD / TILE_NSTASH : 1][S],
+                                             VecOf vec_of, OnTile on_tile, unsigned long long *tl = nullptr)
 {
     static_assert(UPT % RUN == 0, "a run of units never straddles a tile");
+    static_assert(HEAD == 0 || (RUN == 1 && HEAD % TILE_NSTASH == 0), "a head of the stream: round robin only, whole rounds of the three waves");
     constexpr int PPB = 64 / TH;                         // 16-byte pieces of k per row and fragment
     const int pc = lane / TH, r = lane % TH;
     int acc0 = 0, acc1 = 0, acc2 = 0, cnt = 0;
     tile_i32x4 ma = tile_i32x4{0, 0, 0, 0}, mb = tile_i32x4{0, 0, 0, 0};
-    unsigned taken = 0, seen = 0;
-#if RWKV_TL_STREAM == 1
-    unsigned long long waited = 0;
-#endif
-    unsigned p = (unsigned)(wave * RUN) % (unsigned)ns;      // ring position of the wave's next unit: advanced unit by unit, run by run
-    for (int run = wave; run * RUN < NU; run += NC) {
-#pragma unroll 1
-        for (int cc = 0; cc < RUN; cc++) {
-            const int u = run * RUN + cc;
-            if ((int)(seen - (unsigned)(u + 1)) < 0) {       // (`landed` only grows: what an earlier look saw still holds)
-#if RWKV_TL_STREAM == 1
-                const unsigned long long w0 = wall_clock64();
-#endif
-                bool ok = false;
-                for (int it = 0; it < GLDS_SPIN; it++) {
-                    seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tc->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                    if ((int)(seen - (unsigned)(u + 1)) >= 0) { ok = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                fail = ok ? fail : 2u;
-#if RWKV_TL_STREAM == 1
-                waited += wall_clock64() - w0;
-#endif
+    // multiply unit u (in registers) and, when this wave's next unit `un` lies in another tile (or nowhere), add the tile's partial sums up
+    auto mul = [&](const u32x4 (&w)[S], int u, int un) {
+        const int t = u / UPT, c = u - t * UPT;
+        if constexpr (TILE_MFMA && TH == 16) {
+            // a 16-row fragment IS the B operand of v_mfma_i32_16x16x64_i8 and the staged vector's (k-block, piece, limb) order its A operand with
+            // the three limbs as rows 0..2: one 16-byte LDS read and one matrix instruction per fragment where the VALU form needs three reads and
+            // twelve dot instructions.  Rows 3..15 of A are whatever those lanes read (limb 2 again): their outputs are never looked at.
+            // The sums are the same exact integers.
+            const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + pc) * 3 + (r < 3 ? r : 2);
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                const u32x4 x = xp[s * PPB * 3];
+                const tile_i32x4 af = tile_i32x4{(int)x[0], (int)x[1], (int)x[2], (int)x[3]}, bf = tile_i32x4{(int)w[s][0], (int)w[s][1], (int)w[s][2], (int)w[s][3]};
+                if (s & 1) mb = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, mb, 0, 0, 0);
+                else ma = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, ma, 0, 0, 0);
             }
-            const u32x4 *wp = reinterpret_cast<const u32x4 *>(ring + (size_t)p * (S * 1024)) + lane;
-            u32x4 w[S];
+        } else if constexpr (TILE_MFMA4 && TH == 4) {
+            // a 4-row fragment (lane l = piece l / 4 of row l % 4; 16 pieces = 256 inputs) read as a B operand is 16 VIRTUAL rows n = (row, piece % 4)
+            // whose k-piece j is the row's piece 4 j + (piece % 4).  A's rows are (limb b, q): A[(b, q)][j] = limb b of piece 4 j + q, so that
+            // D[(b, q)][(row, q)] -- the diagonal blocks -- are the products that belong together; a row's limb sum is the sum of its four q.
+            // Twelve of A's sixteen rows carry data; one instruction per fragment, like the 16-row form.
+            const int m = (lane & 15) < 12 ? (lane & 15) : 11;
+            const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + 4 * (lane >> 4) + (m & 3)) * 3 + (m >> 2);
 #pragma unroll
-            for (int s = 0; s < S; s++) w[s] = wp[s * 64];
-            taken++;
-            // (relaxed + a compiler barrier: a wave's LDS operations execute in order, so the loader that sees the count finds the reads done;
-            // a release store would make the wave WAIT for its reads before it may even request the activation limbs)
-            asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&tc->freed[wave], taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            p = p + 1 == (unsigned)ns ? 0u : p + 1;
-            const int t = u / UPT, c = u - t * UPT;
-            if constexpr (TILE_MFMA && TH == 16) {
-                // a 16-row fragment IS the B operand of v_mfma_i32_16x16x64_i8 and the staged vector's (k-block, piece, limb) order its A operand with
-                // the three limbs as rows 0..2: one 16-byte LDS read and one matrix instruction per fragment where the VALU form needs three reads and
-                // twelve dot instructions.  Rows 3..15 of A are whatever those lanes read (limb 2 again): their outputs are never looked at.
-                // The sums are the same exact integers.
-                const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + pc) * 3 + (r < 3 ? r : 2);
-#pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const u32x4 x = xp[s * PPB * 3];
-                    const tile_i32x4 af = tile_i32x4{(int)x[0], (int)x[1], (int)x[2], (int)x[3]}, bf = tile_i32x4{(int)w[s][0], (int)w[s][1], (int)w[s][2], (int)w[s][3]};
-                    if (s & 1) mb = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, mb, 0, 0, 0);
-                    else ma = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, ma, 0, 0, 0);
-                }
-            } else if constexpr (TILE_MFMA4 && TH == 4) {
-                // a 4-row fragment (lane l = piece l / 4 of row l % 4; 16 pieces = 256 inputs) read as a B operand is 16 VIRTUAL rows n = (row, piece % 4)
-                // whose k-piece j is the row's piece 4 j + (piece % 4).  A's rows are (limb b, q): A[(b, q)][j] = limb b of piece 4 j + q, so that
-                // D[(b, q)][(row, q)] -- the diagonal blocks -- are the products that belong together; a row's limb sum is the sum of its four q.
-                // Twelve of A's sixteen rows carry data; one instruction per fragment, like the 16-row form.
-                const int m = (lane & 15) < 12 ? (lane & 15) : 11;
-                const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + 4 * (lane >> 4) + (m & 3)) * 3 + (m >> 2);
-#pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const u32x4 x = xp[s * PPB * 3];
-                    const tile_i32x4 af = tile_i32x4{(int)x[0], (int)x[1], (int)x[2], (int)x[3]}, bf = tile_i32x4{(int)w[s][0], (int)w[s][1], (int)w[s][2], (int)w[s][3]};
-                    if (s & 1) mb = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, mb, 0, 0, 0);
-                    else ma = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, ma, 0, 0, 0);
-                }
-            } else {
-                const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + pc) * 3;
-#pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const u32x4 x0 = xp[s * PPB * 3], x1 = xp[s * PPB * 3 + 1], x2 = xp[s * PPB * 3 + 2];
-#pragma unroll
-                    for (int d = 0; d < 4; d++) {
-                        acc0 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x0[d], acc0, false);
-                        acc1 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x1[d], acc1, false);
-                        acc2 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x2[d], acc2, false);
-                    }
-                }
+            for (int s = 0; s < S; s++) {
+                const u32x4 x = xp[s * PPB * 3];
+                const tile_i32x4 af = tile_i32x4{(int)x[0], (int)x[1], (int)x[2], (int)x[3]}, bf = tile_i32x4{(int)w[s][0], (int)w[s][1], (int)w[s][2], (int)w[s][3]};
+                if (s & 1) mb = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, mb, 0, 0, 0);
+                else ma = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, ma, 0, 0, 0);
             }
-            cnt++;
-            const int un = cc + 1 < RUN ? u + 1 : (run + NC) * RUN;      // this wave's next unit
-            if (un >= NU || un / UPT != t) {
-                if constexpr (TILE_MFMA4 && TH == 4) {
-                    // accumulator image: lane (n = l % 16, g = l / 16) holds D[(g, i)][n] in register i: limb g of virtual row n = (row n % 4, q = n / 4)
-                    // is register n / 4; the four q of a row sit 4 lanes apart inside the 16 lanes
-                    const int n = lane & 15;
-                    const tile_i32x4 sa = ma + mb;
-                    int v = n < 4 ? sa[0] : n < 8 ? sa[1] : n < 12 ? sa[2] : sa[3];
-                    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);
-                    if (n < 4 && lane < 48) __hip_atomic_fetch_add(tsum + (t * TH + n) * 3 + (lane >> 4), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    ma = mb = tile_i32x4{0, 0, 0, 0};
-                } else if (TH == 4) {
-                    // 16 lanes hold pieces of one row: fold the pieces 4 apart inside every row of 16 lanes first (DPP), then the four rows of
-                    // 16 lanes meet in LDS like the four k-quarters of the 16-row form
-                    acc0 += __builtin_amdgcn_update_dpp(0, acc0, 0x124, 0xf, 0xf, true); acc0 += __builtin_amdgcn_update_dpp(0, acc0, 0x128, 0xf, 0xf, true);
-                    acc1 += __builtin_amdgcn_update_dpp(0, acc1, 0x124, 0xf, 0xf, true); acc1 += __builtin_amdgcn_update_dpp(0, acc1, 0x128, 0xf, 0xf, true);
-                    acc2 += __builtin_amdgcn_update_dpp(0, acc2, 0x124, 0xf, 0xf, true); acc2 += __builtin_amdgcn_update_dpp(0, acc2, 0x128, 0xf, 0xf, true);
+        } else {
+            const u32x4 *xp = reinterpret_cast<const u32x4 *>(xq + vec_of(t) * xvd_t) + ((c * S) * PPB + pc) * 3;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                const u32x4 x0 = xp[s * PPB * 3], x1 = xp[s * PPB * 3 + 1], x2 = xp[s * PPB * 3 + 2];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    acc0 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x0[d], acc0, false);
+                    acc1 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x1[d], acc1, false);
+                    acc2 = __builtin_amdgcn_sdot4((int)w[s][d], (int)x2[d], acc2, false);
                 }
-                if constexpr (TILE_MFMA && TH == 16) {      // (accumulator image: lane n < 16 holds row n's three limb sums in registers 0..2)
-                    if (lane < 16) {
-                        int *ts = tsum + (t * TH + lane) * 3;
-                        __hip_atomic_fetch_add(ts + 0, ma[0] + mb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(ts + 1, ma[1] + mb[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(ts + 2, ma[2] + mb[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    ma = mb = tile_i32x4{0, 0, 0, 0};
-                } else if constexpr (TILE_MFMA4 && TH == 4) {
-                } else if (TH == 16 || (lane & 15) < 4) {
-                    int *ts = tsum + (t * TH + r) * 3;
-                    __hip_atomic_fetch_add(ts + 0, acc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(ts + 1, acc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(ts + 2, acc2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                unsigned old = 0u;
-                if (lane == 0) old = __hip_atomic_fetch_add(&tc->tcnt[t], (unsigned)cnt, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-                old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-                if (old + (unsigned)cnt == (unsigned)UPT) on_tile(t);
-                acc0 = acc1 = acc2 = 0; cnt = 0;
             }
         }
-        p += (unsigned)((NC - 1) * RUN);
-        while (p >= (unsigned)ns) p -= (unsigned)ns;
+        cnt++;
+        if (un >= NU || un / UPT != t) {
+            if constexpr (TILE_MFMA4 && TH == 4) {
+                // accumulator image: lane (n = l % 16, g = l / 16) holds D[(g, i)][n] in register i: limb g of virtual row n = (row n % 4, q = n / 4)
+                // is register n / 4; the four q of a row sit 4 lanes apart inside the 16 lanes
+                const int n = lane & 15;
+                const tile_i32x4 sa = ma + mb;
+                int v = n < 4 ? sa[0] : n < 8 ? sa[1] : n < 12 ? sa[2] : sa[3];
+                v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);
+                if (n < 4 && lane < 48) __hip_atomic_fetch_add(tsum + (t * TH + n) * 3 + (lane >> 4), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ma = mb = tile_i32x4{0, 0, 0, 0};
+            } else if (TH == 4) {
+                // 16 lanes hold pieces of one row: fold the pieces 4 apart inside every row of 16 lanes first (DPP), then the four rows of
+                // 16 lanes meet in LDS like the four k-quarters of the 16-row form
+                acc0 += __builtin_amdgcn_update_dpp(0, acc0, 0x124, 0xf, 0xf, true); acc0 += __builtin_amdgcn_update_dpp(0, acc0, 0x128, 0xf, 0xf, true);
+                acc1 += __builtin_amdgcn_update_dpp(0, acc1, 0x124, 0xf, 0xf, true); acc1 += __builtin_amdgcn_update_dpp(0, acc1, 0x128, 0xf, 0xf, true);
+                acc2 += __builtin_amdgcn_update_dpp(0, acc2, 0x124, 0xf, 0xf, true); acc2 += __builtin_amdgcn_update_dpp(0, acc2, 0x128, 0xf, 0xf, true);
+            }
+            if constexpr (TILE_MFMA && TH == 16) {      // (accumulator image: lane n < 16 holds row n's three limb sums in registers 0..2)
+                if (lane < 16) {
+                    int *ts = tsum + (t * TH + lane) * 3;
+                    __hip_atomic_fetch_add(ts + 0, ma[0] + mb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(ts + 1, ma[1] + mb[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(ts + 2, ma[2] + mb[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                ma = mb = tile_i32x4{0, 0, 0, 0};
+            } else if constexpr (TILE_MFMA4 && TH == 4) {
+            } else if (TH == 16 || (lane & 15) < 4) {
+                int *ts = tsum + (t * TH + r) * 3;
+                __hip_atomic_fetch_add(ts + 0, acc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(ts + 1, acc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(ts + 2, acc2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            unsigned old = 0u;
+            if (lane == 0) old = __hip_atomic_fetch_add(&tc->tcnt[t], (unsigned)cnt, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+            if (old + (unsigned)cnt == (unsigned)UPT) on_tile(t);
+            acc0 = acc1 = acc2 = 0; cnt = 0;
+        }
+    };
+    if constexpr (HEAD > 0) {
+        constexpr int NE = HEAD / TILE_NSTASH;
+        if (wave >= TILE_NWP) {
+#pragma unroll
+            for (int k = 0; k < NE; k++) {
+                const int u = tile_unit_of<HEAD>(wave, k);
+                if (u < NU) mul(wpre[k], u, tile_unit_of<HEAD>(wave, k + 1));
+            }
+        }
+        unsigned p = (unsigned)(HEAD + wave) % (unsigned)ns;
+#pragma unroll 1
+        for (int u = HEAD + wave; u < NU; u += NC) {
+            u32x4 w[S];
+            tile_take<S>(ring, p, u, tc, wave, lane, wk, fail, w);
+            p += (unsigned)NC;
+            while (p >= (unsigned)ns) p -= (unsigned)ns;
+            mul(w, u, u + NC);
+        }
+    } else {
+        unsigned p = (unsigned)(wave * RUN) % (unsigned)ns;      // ring position of the wave's next unit: advanced unit by unit, run by run
+        for (int run = wave; run * RUN < NU; run += NC) {
+#pragma unroll 1
+            for (int cc = 0; cc < RUN; cc++) {
+                const int u = run * RUN + cc;
+                u32x4 w[S];
+                tile_take<S>(ring, p, u, tc, wave, lane, wk, fail, w);
+                p = p + 1 == (unsigned)ns ? 0u : p + 1;
+                mul(w, u, cc + 1 < RUN ? u + 1 : (run + NC) * RUN);
+            }
+            p += (unsigned)((NC - 1) * RUN);
+            while (p >= (unsigned)ns) p -= (unsigned)ns;
+        }
     }
 #if RWKV_TL_STREAM == 1
-    if (tl && lane == 0) tl[((size_t)blockIdx.x * NW + wave) * 8 + 2] = waited;
+    if (tl && lane == 0) tl[((size_t)blockIdx.x * NW + wave) * 8 + 2] = wk.waited;
 #endif
 }
 
 // Units (of S KiB) a tile-form loader requests IN FRONT of the workgroup's order barrier, per kernel class.  The row-form default (RWKV_RING_PRE = 8
 // rows) puts 32 KiB of weights into the CU's in-order memory path ahead of the prologue's loads (rule 1): round 6 measured the
 // kernels whose prologue is their critical path with fewer (profiles/r06/tile_pre_ab.txt; 4-row tiles at D = 5120: tile_pre_14b_ab.txt).
-#ifndef RWKV_TILE_PRE_ATT
-#define RWKV_TILE_PRE_ATT 0
+#ifndef RWKV_TILE_PRE_ATT         // (0 without the head in registers; 4 with it)
+#define RWKV_TILE_PRE_ATT 4
 #endif
 #ifndef RWKV_TILE_PRE_ATTOUT
 #define RWKV_TILE_PRE_ATTOUT 4
@@ -528,6 +583,25 @@ __device__ __forceinline__ void tile_consume(int NU, const unsigned char *ring, 
 #endif
 #ifndef RWKV_TILE_PRE_FV
 #define RWKV_TILE_PRE_FV RWKV_RING_PRE
+#endif
+// Units of the stream's HEAD that the three non-staging consumer waves keep in registers (tile_unit_of; 16-row tiles, multiples of 3; 0: none).
+// Measured at 7B (profiles/r06/tile_head_ab.txt): K/V/R with 9 units in registers and 4 in front of the barrier 12.3 -> 12.0 us (+0.5-0.7 % on the
+// token); the other classes +-0, 4-row tiles (14B) -1 ... 0 %; streaming 16-24 units ahead of the prologue loses whatever the capacity (its loads
+// return behind the stream's).
+#ifndef RWKV_TILE_HEAD_ATT
+#define RWKV_TILE_HEAD_ATT 9
+#endif
+#ifndef RWKV_TILE_PRE4_ATT        // K/V/R on 4-row tiles (no head there)
+#define RWKV_TILE_PRE4_ATT 0
+#endif
+#ifndef RWKV_TILE_HEAD_ATTOUT
+#define RWKV_TILE_HEAD_ATTOUT 0
+#endif
+#ifndef RWKV_TILE_HEAD_FRK
+#define RWKV_TILE_HEAD_FRK 0
+#endif
+#ifndef RWKV_TILE_HEAD_FV
+#define RWKV_TILE_HEAD_FV 0
 #endif
 #ifndef RWKV_TILE_PRE_FV4        // k_ffnv_t on 4-row tiles (D = 5120: 80 KB of hidden units to stage per workgroup): 14B 350.3 -> 354.9 tokens/s with none in front
 #define RWKV_TILE_PRE_FV4 0
@@ -561,6 +635,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FfnRKArgs &a = ta.a;
     constexpr int CPW = TH * TPC, NTILE = 5 * TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC);
+    constexpr int HEAD = TH == 16 && RUN == 1 ? RWKV_TILE_HEAD_FRK : 0, NE = HEAD / TILE_NSTASH > 0 ? HEAD / TILE_NSTASH : 1;
     static_assert(KBT % S == 0 && NTILE <= 32, "whole units per tile; TileCtl::tcnt");
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
@@ -582,7 +657,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
     float pmax = 0.f;
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_FRK>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
+        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_FRK, HEAD>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
         tl_stamp(a.tl, 2);
     } else {
         if (wave < TILE_NWP) {
@@ -605,6 +680,9 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
             tile_stash_done(tc, lane);
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
+        TileWalk wk;
+        u32x4 wpre[NE][S];
+        if (wave >= TILE_NWP) tile_pretake<S, HEAD>(NU, ring, a.ns, tc, wave, lane, wk, fail, wpre);
         wait_count(&tc->staged, TILE_NWP + TILE_NSTASH, fail);
         const double sck = scale_of(bc[4]), scr = scale_of(bc[5]);
         const float Sk = bc[0], Sr = bc[1];
@@ -630,7 +708,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
                 }
             }
         };
-        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t / TPC < 4 ? 0 : 1; }, on_tile, a.tl);
+        tile_consume<TH, S, UPT, RUN, HEAD>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, wk, wpre, [](int t) { return t / TPC < 4 ? 0 : 1; }, on_tile, a.tl);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();   // every wave is past its last read of the reduction scratch
@@ -648,6 +726,7 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AttArgs &a = ta.a;
     constexpr int CPW = TH * TPC, NTILE = 3 * TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC);
+    constexpr int HEAD = TH == 16 && RUN == 1 ? RWKV_TILE_HEAD_ATT : 0, NE = HEAD / TILE_NSTASH > 0 ? HEAD / TILE_NSTASH : 1;
     static_assert(KBT % S == 0 && NTILE <= 32 && TPC <= 8, "whole units per tile; TileCtl::tcnt / done");
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
@@ -673,7 +752,7 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
     float pmax = 0.f;
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_ATT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
+        fail = tile_loader<S, UPT, RUN, TH, (TH == 16 ? RWKV_TILE_PRE_ATT : RWKV_TILE_PRE4_ATT), HEAD>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
         tl_stamp(a.tl, 2);
     } else {
         const size_t so = (size_t)a.ctl->slot * a.slot_stride;
@@ -697,6 +776,9 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
             tile_stash_done(tc, lane);
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
+        TileWalk wk;
+        u32x4 wpre[NE][S];
+        if (wave >= TILE_NWP) tile_pretake<S, HEAD>(NU, ring, a.ns, tc, wave, lane, wk, fail, wpre);
         wait_count(&tc->staged, TILE_NWP + TILE_NSTASH, fail);
         tl_stamp(a.tl, 5);
         auto on_tile = [&](int t) {
@@ -731,7 +813,7 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
                 pmax = fmaxf(pmax, fabsf(ys));
             }
         };
-        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int t) { return t / TPC; }, on_tile, a.tl);
+        tile_consume<TH, S, UPT, RUN, HEAD>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, wk, wpre, [](int t) { return t / TPC; }, on_tile, a.tl);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
@@ -773,6 +855,7 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AttOutArgs &a = ta.a;
     constexpr int CPW = TH * TPC, NTILE = TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC);
+    constexpr int HEAD = TH == 16 && RUN == 1 ? RWKV_TILE_HEAD_ATTOUT : 0, NE = HEAD / TILE_NSTASH > 0 ? HEAD / TILE_NSTASH : 1;
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
     const int xvd_t = (D >> 4) * 12;
@@ -794,7 +877,7 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
     };
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_ATTOUT>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
+        fail = tile_loader<S, UPT, RUN, TH, RWKV_TILE_PRE_ATTOUT, HEAD>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
         tl_stamp(a.tl, 2);
     } else {
         const double mean1 = a.lnstat[0], rstd1 = a.lnstat[1];
@@ -818,6 +901,9 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
             tile_stash_done(tc, lane);
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
+        TileWalk wk;
+        u32x4 wpre[NE][S];
+        if (wave >= TILE_NWP) tile_pretake<S, HEAD>(NU, ring, a.ns, tc, wave, lane, wk, fail, wpre);
         wait_count(&tc->staged, TILE_NWP + TILE_NSTASH, fail);
         const float Sf = bc[0];
         const double sc = scale_of(bc[4]), cA = tile_cA(tc, 0, (double)D);
@@ -840,7 +926,7 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
                 tile_site_leave<2>(acc, scr, CPW, li);
             }
         };
-        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile, a.tl);
+        tile_consume<TH, S, UPT, RUN, HEAD>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, wk, wpre, [](int) { return 0; }, on_tile, a.tl);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
@@ -856,6 +942,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FfnVArgs &a = ta.a;
     constexpr int CPW = TH * TPC, NTILE = TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC), PW = site_pw<NVN>();
+    constexpr int HEAD = TH == 16 && RUN == 1 ? RWKV_TILE_HEAD_FV : 0, NE = HEAD / TILE_NSTASH > 0 ? HEAD / TILE_NSTASH : 1;
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
     const int xvd_t = (D >> 2) * 12;                       // the 4 D hidden units as ONE vector
@@ -878,7 +965,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
     };
     unsigned fail = 0u;
     if (wave == NC) {
-        fail = tile_loader<S, UPT, RUN, TH, (TH == 16 ? RWKV_TILE_PRE_FV : RWKV_TILE_PRE_FV4)>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
+        fail = tile_loader<S, UPT, RUN, TH, (TH == 16 ? RWKV_TILE_PRE_FV : RWKV_TILE_PRE_FV4), HEAD>(NU, NTILE, ring, a.ns, tc, tsum, lane, unit_src, a.tl);
         tl_stamp(a.tl, 2);
     } else {
         const double mean2 = a.lnstat[0], rstd2 = a.lnstat[1];
@@ -903,6 +990,9 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
             tile_stash_done(tc, lane);
         }
         float *bc = reinterpret_cast<float *>(red + RED_BC);
+        TileWalk wk;
+        u32x4 wpre[NE][S];
+        if (wave >= TILE_NWP) tile_pretake<S, HEAD>(NU, ring, a.ns, tc, wave, lane, wk, fail, wpre);
         wait_count(&tc->staged, TILE_NWP + TILE_NSTASH, fail);
         const float Sf = bc[0];
         const double sc = scale_of(bc[4]), cA = tile_cA(tc, 0, 4.0 * (double)D);
@@ -925,7 +1015,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
                 tile_site_leave<NVN>(acc, scr, CPW, li);
             }
         };
-        tile_consume<TH, S, UPT, RUN>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, [](int) { return 0; }, on_tile, a.tl);
+        tile_consume<TH, S, UPT, RUN, HEAD>(NU, ring, a.ns, tc, tsum, xq, xvd_t, wave, lane, fail, wk, wpre, [](int) { return 0; }, on_tile, a.tl);
     }
     tl_stamp(a.tl, 6);
     __syncthreads();
