@@ -636,6 +636,7 @@ __global__ __launch_bounds__(NT) void k_ffn_rk_t(FfnRKTArgs ta)
     const FfnRKArgs &a = ta.a;
     constexpr int CPW = TH * TPC, NTILE = 5 * TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC);
     constexpr int HEAD = TH == 16 && RUN == 1 ? RWKV_TILE_HEAD_FRK : 0, NE = HEAD / TILE_NSTASH > 0 ? HEAD / TILE_NSTASH : 1;
+    static_assert(HEAD <= NU && HEAD % TILE_NSTASH == 0, "the head: whole rounds of the three non-staging waves, inside the stream");
     static_assert(KBT % S == 0 && NTILE <= 32, "whole units per tile; TileCtl::tcnt");
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
@@ -727,6 +728,7 @@ __global__ __launch_bounds__(NT) void k_att_t(AttTArgs ta)
     const AttArgs &a = ta.a;
     constexpr int CPW = TH * TPC, NTILE = 3 * TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC);
     constexpr int HEAD = TH == 16 && RUN == 1 ? RWKV_TILE_HEAD_ATT : 0, NE = HEAD / TILE_NSTASH > 0 ? HEAD / TILE_NSTASH : 1;
+    static_assert(HEAD <= NU && HEAD % TILE_NSTASH == 0, "the head: whole rounds of the three non-staging waves, inside the stream");
     static_assert(KBT % S == 0 && NTILE <= 32 && TPC <= 8, "whole units per tile; TileCtl::tcnt / done");
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
@@ -856,6 +858,7 @@ __global__ __launch_bounds__(NT) void k_attout_t(AttOutTArgs ta)
     const AttOutArgs &a = ta.a;
     constexpr int CPW = TH * TPC, NTILE = TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC);
     constexpr int HEAD = TH == 16 && RUN == 1 ? RWKV_TILE_HEAD_ATTOUT : 0, NE = HEAD / TILE_NSTASH > 0 ? HEAD / TILE_NSTASH : 1;
+    static_assert(HEAD <= NU && HEAD % TILE_NSTASH == 0, "the head: whole rounds of the three non-staging waves, inside the stream");
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
     const int xvd_t = (D >> 4) * 12;
@@ -943,6 +946,7 @@ __global__ __launch_bounds__(NT) void k_ffnv_t(FfnVTArgs ta)
     const FfnVArgs &a = ta.a;
     constexpr int CPW = TH * TPC, NTILE = TPC, UPT = KBT / S, NU = NTILE * UPT, RUN = tile_run(TH, UPT, TPC), PW = site_pw<NVN>();
     constexpr int HEAD = TH == 16 && RUN == 1 ? RWKV_TILE_HEAD_FV : 0, NE = HEAD / TILE_NSTASH > 0 ? HEAD / TILE_NSTASH : 1;
+    static_assert(HEAD <= NU && HEAD % TILE_NSTASH == 0, "the head: whole rounds of the three non-staging waves, inside the stream");
     double *red = reinterpret_cast<double *>(smem);
     const int D = a.D, lane = threadIdx.x & 63, wave = wave_id();
     const int xvd_t = (D >> 2) * 12;                       // the 4 D hidden units as ONE vector
