@@ -893,8 +893,10 @@ constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
 // DMA pieces (1 KiB) the loader keeps in flight.  By Little's law the queueing delay of EVERY access of the CU is in-flight bytes /
 // stream rate: 63 KiB at 23 KB/us = 2.7 us -- paid by the prologue's loads and, after the last issue, by the kernel's tail --
 // while the stream itself is at full rate from ~24 KiB up (tools/dmabench.hip: depth 63 / 32 / 16 -> 7.3 / 7.3 / 6.0 TB/s).
+// Round 6, with the matrix-core consumers (profiles/r06/depth_ab.txt): 24 .. 30 are a plateau 0.5 % above 32 at 7B, 20 falls off a cliff (-7.5 %);
+// 28 with 20 in front of the barrier: 7B +0.55 %, 14B +0.8 %, 1B5 / 3B +0.1-0.2 %.
 #ifndef RWKV_RING_DEPTH
-#define RWKV_RING_DEPTH 32
+#define RWKV_RING_DEPTH 28
 #endif
 // The weight stream starts BEFORE the workgroup's order barrier: the loader issues its first RWKV_RING_PRE rows at once, thinly
 // (RWKV_RING_PRE_DEPTH pieces in flight: the prologue's loads, issued ~1.4 us into the kernel, queue behind at most that), and
@@ -912,7 +914,7 @@ constexpr int GLDS_FQ = 32;             // groups the ring bookkeeping can hold
 #define RWKV_LOADER_PRIO 0        // s_setprio of the loader wave (0..3)
 #endif
 #ifndef RWKV_RING_PRE_DEPTH
-#define RWKV_RING_PRE_DEPTH 16
+#define RWKV_RING_PRE_DEPTH 20
 #endif
 struct GldsCtl {            // LDS control block of the ring
     unsigned staged;        // prologue waves that have staged their part of the vector
